@@ -1,0 +1,87 @@
+"""Seeded synthetic text-line crops and charsets (there is no network for real
+data).  Crops follow the reference's input contract (PageOCR hands
+`uint8 [line_px_height, w, 3]` BGR arrays to process_lines,
+pero_ocr/document_ocr/page_parser.py:418-423): light background, dark glyph-like
+strokes, three identical channels ("grayscale" lines of BASELINE.json's configs).
+
+Only integer hashing and IEEE +,-,*,/ and comparisons are used, so the same
+(seed, index, width) gives the same bytes on every machine.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+
+from .netspec import splitmix64, uniform01
+
+
+def make_crop(seed: int, index: int, width: int, height: int = 40) -> np.ndarray:
+    """One `uint8 [height, width, 3]` crop."""
+    stream = 0x5EED0000 + index
+    # per-pixel background noise
+    noise = uniform01(seed, stream, height * width).reshape(height, width)
+    img = 215.0 + 30.0 * noise
+    # glyph-like strokes: one pseudo-glyph every ~14 px, 2-4 segments each
+    n_glyph = max(1, width // 14)
+    par = uniform01(seed, stream ^ 0xABCDEF, n_glyph * 4 * 6).reshape(n_glyph, 4, 6)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    for g in range(n_glyph):
+        gx0 = 2.0 + g * 14.0
+        nseg = 2 + int(par[g, 0, 5] * 3.0)
+        for s in range(min(nseg, 4)):
+            p = par[g, s]
+            x0 = gx0 + p[0] * 10.0
+            y0 = 6.0 + p[1] * (height - 12.0)
+            x1 = gx0 + p[2] * 10.0
+            y1 = 6.0 + p[3] * (height - 12.0)
+            thick = 0.9 + p[4] * 1.3
+            dx, dy = x1 - x0, y1 - y0
+            den = dx * dx + dy * dy + 1e-6
+            t = ((xx - x0) * dx + (yy - y0) * dy) / den
+            t = np.minimum(1.0, np.maximum(0.0, t))
+            ex, ey = xx - (x0 + t * dx), yy - (y0 + t * dy)
+            d2 = ex * ex + ey * ey
+            ink = np.minimum(1.0, np.maximum(0.0, (thick * thick + 1.0 - d2) / (2.0 * thick)))
+            img = img * (1.0 - ink) + (25.0 + 30.0 * p[5]) * ink
+    g8 = np.minimum(255.0, np.maximum(0.0, np.floor(img + 0.5))).astype(np.uint8)
+    return np.ascontiguousarray(np.repeat(g8[:, :, None], 3, axis=2))
+
+
+def make_crops(seed: int, widths: Sequence[int], height: int = 40) -> List[np.ndarray]:
+    return [make_crop(seed, i, int(w), height) for i, w in enumerate(widths)]
+
+
+def make_widths(seed: int, n: int, lo: int = 128, hi: int = 1024) -> List[int]:
+    """n widths uniform in [lo, hi] (BASELINE config 3's seeded width distribution)."""
+    u = uniform01(seed, 0x71D7, n)
+    return [int(lo + np.floor(x * (hi - lo + 1))) for x in u]
+
+
+def make_charset(n_symbols: int) -> List[str]:
+    """A fixed printable charset with n_symbols entries (blank NOT included; the
+    engine appends the blank placeholder itself, pytorch_ocr_engine.py:42).
+    Latin + Czech diacritics + digits + punctuation first, then further
+    Latin-Extended code points to fill up."""
+    base = list("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789"
+                " .,;:!?-()[]\"'/&%+=*§")
+    base += list("áčďéěíňóřšťúůýžÁČĎÉĚÍŇÓŘŠŤÚŮÝŽäöüÄÖÜß")
+    seen, out = set(), []
+    for ch in base:
+        if ch not in seen:
+            seen.add(ch)
+            out.append(ch)
+    cp = 0x0100
+    while len(out) < n_symbols:
+        ch = chr(cp)
+        if ch not in seen:
+            seen.add(ch)
+            out.append(ch)
+        cp += 1
+    return out[:n_symbols]
+
+
+def random_u8_batch(seed: int, n: int, height: int, width: int) -> np.ndarray:
+    """White-noise `uint8 [n, height, width, 3]` (edge-case / stress tests only)."""
+    h = splitmix64(np.arange(n * height * width * 3, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x10001))
+    return (h >> np.uint64(56)).astype(np.uint8).reshape(n, height, width, 3)
