@@ -1,0 +1,111 @@
+/* pocr.h — C ABI of the MI355X-native text-line recogniser (libpocr_hip.so).
+ *
+ * This is the drop-in boundary for pero-ocr's batched line-recognition hot path.
+ * The reference has no native code; its Python engine does all device work inside
+ *
+ *   PytorchEngineLineOCR.run_ocr        pero_ocr/ocr_engine/pytorch_ocr_engine.py:59-74
+ *   greedy_decode_ctc                   pero_ocr/ocr_engine/pytorch_ocr_engine.py:13-34
+ *   BaseEngineLineOCR.process_lines     pero_ocr/ocr_engine/line_ocr_engine.py:121-129 (batch assembly + run_ocr)
+ *
+ * Each entry point below names the reference lines it replaces.  Plain pointers and
+ * sizes only; the caller owns every host buffer, the library owns all device memory.
+ * One engine = one GPU + one HIP stream; an engine is NOT thread-safe; every call
+ * blocks until its outputs are in the caller's host buffers.
+ * Every function returning int returns 0 on success, non-zero on failure with the
+ * message available from pocr_last_error() (thread-local).
+ */
+#ifndef POCR_H
+#define POCR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POCR_ABI_VERSION 1
+
+typedef struct pocr_engine pocr_engine;
+
+/* Network geometry ("vgg_blstm_ctc", see pero_ocr_amd/netspec.py).  Replaces what
+ * torch.jit.load() reads from the TorchScript file (pytorch_ocr_engine.py:52-57). */
+typedef struct pocr_config {
+    int32_t abi_version;   /* POCR_ABI_VERSION */
+    int32_t height;        /* line_px_height, multiple of 8 (line_ocr_engine.py:22) */
+    int32_t num_classes;   /* C, blank = C-1 (pytorch_ocr_engine.py:12) */
+    int32_t conv_out;      /* E: aggregation conv output channels, multiple of 16 */
+    int32_t lstm_hidden;   /* multiple of 16 */
+    int32_t lstm_layers;   /* >= 1 */
+} pocr_config;
+
+/* Number of float32 values pocr_create() expects (tensor order = netspec.tensor_table). */
+size_t pocr_num_weight_floats(const pocr_config *cfg);
+
+/* Build an engine on HIP device `device_id`: uploads and re-lays-out the weights
+ * (MFMA fragment order), creates the stream.  Replaces _load_exported_model
+ * (pytorch_ocr_engine.py:52-57).  Fails (non-zero) when no gfx950 device is usable:
+ * there is NO CPU fallback. */
+int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats,
+                int device_id, pocr_engine **out);
+void pocr_destroy(pocr_engine *e);
+
+const char *pocr_last_error(void);
+int pocr_abi_version(void);
+/* Number of visible HIP devices (0 when none / no driver). */
+int pocr_device_count(void);
+
+/* ---- one padded batch: replaces run_ocr(batch_data) (pytorch_ocr_engine.py:59-74) ----
+ * batch_nhwc : uint8 [n, height, w_pad, 3] (the array line_ocr_engine.py:121-127 builds);
+ *              w_pad >= 4; T = (w_pad / 2) / 2 (two floor-mode 2x pools; = w_pad / 4 for the
+ *              reference's widths, which are multiples of 32).
+ * logits_ntc : float32 [n, T, C] or NULL  (= logits.permute(0,2,1), :72)
+ * frame_argmax_nt : int32 [n, T] or NULL  (torch.argmax over C, first index wins, :19)
+ * labels_nt  : int32 [n, T]  greedy-CTC-collapsed label ids, row i valid in [0, label_len_n[i])
+ * label_len_n: int32 [n]
+ */
+int pocr_run_batch(pocr_engine *e, const uint8_t *batch_nhwc, int32_t n, int32_t w_pad,
+                   float *logits_ntc, int32_t *frame_argmax_nt,
+                   int32_t *labels_nt, int32_t *label_len_n);
+
+/* ---- ragged chunk: fuses the zero-pad batch assembly (line_ocr_engine.py:121-127) into
+ * the first kernel's HBM->LDS staging.  crops = the chunk's line crops packed back to
+ * back, crop i = uint8 [height, widths[i], 3] starting at byte crop_offsets[i].
+ * Every line is placed at x = pad_left (32 = line_padding_px, line_ocr_engine.py:54)
+ * inside a zero row of w_pad pixels; columns beyond w_pad are dropped (:125-127).
+ * pocr_stage_lines uploads the chunk and leaves it resident in HBM;
+ * pocr_run_staged runs the network on the resident chunk (may be called repeatedly). */
+int pocr_stage_lines(pocr_engine *e, const uint8_t *crops, const int64_t *crop_offsets,
+                     const int32_t *widths, int32_t n, int32_t w_pad, int32_t pad_left);
+int pocr_run_staged(pocr_engine *e, float *logits_ntc, int32_t *frame_argmax_nt,
+                    int32_t *labels_nt, int32_t *label_len_n);
+
+/* ---- measurement / test taps (not part of the reference surface) ----
+ * Per-stage GPU time of the last pocr_run_* call in milliseconds, measured with HIP
+ * events on the engine's stream.  Stage ids: POCR_STAGE_*.  Returns the number of
+ * stages written (<= cap). */
+enum {
+    POCR_STAGE_CONV1 = 0,   /* stage+normalise+conv1 (u8 -> f32, K0 fused with conv1) */
+    POCR_STAGE_CONV2, POCR_STAGE_CONV3, POCR_STAGE_CONV4, POCR_STAGE_CONV5,
+    POCR_STAGE_CONV6, POCR_STAGE_CONV7, POCR_STAGE_CONV8, POCR_STAGE_CONV9,
+    POCR_STAGE_AGG,         /* aggregation conv */
+    POCR_STAGE_LSTM,        /* all BiLSTM layers: input projections + recurrence */
+    POCR_STAGE_HEAD,        /* projection to C classes */
+    POCR_STAGE_CTC,         /* argmax + collapse */
+    POCR_STAGE_TOTAL,       /* first kernel start -> last kernel end */
+    POCR_NUM_STAGES
+};
+int pocr_last_stage_ms(pocr_engine *e, float *ms, int32_t cap);
+/* Enable/disable per-stage event recording (default off: events cost a little). */
+int pocr_set_profiling(pocr_engine *e, int32_t enabled);
+
+/* Copy an intermediate activation of the last run to the host (tests only).
+ * what: 0..8 = output of conv1..conv9 (NHWC, after activation/pool/BN),
+ *       9 = aggregation features [n, T, E], 10+l = BiLSTM layer l output [n, T, 2*hidden].
+ * Writes min(cap, size) floats, stores the full size in *n_floats. */
+int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t *n_floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POCR_H */

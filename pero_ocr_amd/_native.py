@@ -1,0 +1,168 @@
+"""ctypes binding of libpocr_hip.so (C ABI: include/pocr.h).
+
+The HIP library is the product path; there is no CPU fallback.  If the shared
+object is missing or no gfx950 device is usable, everything here raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .netspec import NetSpec
+
+LIB_NAME = "libpocr_hip.so"
+ABI_VERSION = 1
+STAGE_NAMES = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv8", "conv9",
+               "agg", "lstm", "head", "ctc", "total")
+
+_lib: Optional[C.CDLL] = None
+
+
+class PocrConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("height", C.c_int32), ("num_classes", C.c_int32),
+                ("conv_out", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_layers", C.c_int32)]
+
+
+# every symbol include/pocr.h declares: name -> (restype, argtypes)
+_u8p, _f32p, _i32p, _i64p = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+SYMBOLS = {
+    "pocr_num_weight_floats": (C.c_size_t, [C.POINTER(PocrConfig)]),
+    "pocr_create": (C.c_int, [C.POINTER(PocrConfig), _f32p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "pocr_destroy": (None, [C.c_void_p]),
+    "pocr_last_error": (C.c_char_p, []),
+    "pocr_abi_version": (C.c_int, []),
+    "pocr_device_count": (C.c_int, []),
+    "pocr_run_batch": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, _f32p, _i32p, _i32p, _i32p]),
+    "pocr_stage_lines": (C.c_int, [C.c_void_p, _u8p, _i64p, _i32p, C.c_int32, C.c_int32, C.c_int32]),
+    "pocr_run_staged": (C.c_int, [C.c_void_p, _f32p, _i32p, _i32p, _i32p]),
+    "pocr_last_stage_ms": (C.c_int, [C.c_void_p, _f32p, C.c_int32]),
+    "pocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "pocr_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
+}
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype, fn.argtypes = res, args
+    if lib.pocr_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_NAME} ABI {lib.pocr_abi_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def _ptr(arr: Optional[np.ndarray], typ):
+    return None if arr is None else arr.ctypes.data_as(typ)
+
+
+class NativeEngine:
+    """Owns one pocr_engine handle (one GPU, one stream)."""
+
+    def __init__(self, spec: NetSpec, flat_weights: np.ndarray, device_id: int = 0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        self.spec = spec
+        cfg = PocrConfig(ABI_VERSION, spec.height, spec.num_classes, spec.conv_out, spec.lstm_hidden,
+                         spec.lstm_layers)
+        w = np.ascontiguousarray(flat_weights, dtype=np.float32)
+        rc = self._lib.pocr_create(C.byref(cfg), _ptr(w, _f32p), w.size, int(device_id), C.byref(self._h))
+        if rc:
+            raise RuntimeError("pocr_create: " + self._err())
+        self._n = 0
+        self._T = 0
+
+    def _err(self) -> str:
+        return (self._lib.pocr_last_error() or b"").decode("utf8", "replace")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pocr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def frames_for(w_pad: int) -> int:
+        return (w_pad // 2) // 2
+
+    def _alloc_out(self, n, T, want_logits, want_argmax):
+        logits = np.empty((n, T, self.spec.num_classes), dtype=np.float32) if want_logits else None
+        amax = np.empty((n, T), dtype=np.int32) if want_argmax else None
+        labels = np.empty((n, T), dtype=np.int32)
+        lens = np.empty((n,), dtype=np.int32)
+        return logits, amax, labels, lens
+
+    def run_batch(self, batch_u8: np.ndarray, want_logits=True, want_argmax=True):
+        """u8 [n,H,w_pad,3] -> (logits [n,T,C] | None, frame_argmax [n,T] | None, labels [n,T], lens [n])"""
+        b = np.ascontiguousarray(batch_u8, dtype=np.uint8)
+        if b.ndim != 4 or b.shape[1] != self.spec.height or b.shape[3] != 3:
+            raise ValueError(f"expected uint8 [n,{self.spec.height},w,3], got {b.shape}")
+        n, _, w_pad, _ = b.shape
+        T = self.frames_for(w_pad)
+        logits, amax, labels, lens = self._alloc_out(n, T, want_logits, want_argmax)
+        rc = self._lib.pocr_run_batch(self._h, _ptr(b, _u8p), n, w_pad, _ptr(logits, _f32p), _ptr(amax, _i32p),
+                                      _ptr(labels, _i32p), _ptr(lens, _i32p))
+        if rc:
+            raise RuntimeError("pocr_run_batch: " + self._err())
+        self._n, self._T = n, T
+        return logits, amax, labels, lens
+
+    def stage_lines(self, pool_u8: np.ndarray, offsets: np.ndarray, widths: np.ndarray, w_pad: int, pad_left: int):
+        pool = np.ascontiguousarray(pool_u8, dtype=np.uint8).reshape(-1)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        wd = np.ascontiguousarray(widths, dtype=np.int32)
+        if pool.size == 0:
+            pool = np.zeros(1, dtype=np.uint8)
+        rc = self._lib.pocr_stage_lines(self._h, _ptr(pool, _u8p), _ptr(off, _i64p), _ptr(wd, _i32p),
+                                        int(wd.size), int(w_pad), int(pad_left))
+        if rc:
+            raise RuntimeError("pocr_stage_lines: " + self._err())
+        self._n, self._T = int(wd.size), self.frames_for(w_pad)
+
+    def run_staged(self, want_logits=True, want_argmax=True):
+        logits, amax, labels, lens = self._alloc_out(self._n, self._T, want_logits, want_argmax)
+        rc = self._lib.pocr_run_staged(self._h, _ptr(logits, _f32p), _ptr(amax, _i32p), _ptr(labels, _i32p),
+                                       _ptr(lens, _i32p))
+        if rc:
+            raise RuntimeError("pocr_run_staged: " + self._err())
+        return logits, amax, labels, lens
+
+    def set_profiling(self, on: bool):
+        self._lib.pocr_set_profiling(self._h, 1 if on else 0)
+
+    def last_stage_ms(self) -> dict:
+        buf = np.zeros(len(STAGE_NAMES), dtype=np.float32)
+        k = self._lib.pocr_last_stage_ms(self._h, _ptr(buf, _f32p), buf.size)
+        return {STAGE_NAMES[i]: float(buf[i]) for i in range(k)}
+
+    def debug_read(self, what: int) -> np.ndarray:
+        n = C.c_size_t(0)
+        if self._lib.pocr_debug_read(self._h, what, None, 0, C.byref(n)):
+            raise RuntimeError("pocr_debug_read: " + self._err())
+        out = np.empty(n.value, dtype=np.float32)
+        if self._lib.pocr_debug_read(self._h, what, _ptr(out, _f32p), out.size, C.byref(n)):
+            raise RuntimeError("pocr_debug_read: " + self._err())
+        return out
+
+
+def device_count() -> int:
+    return int(load().pocr_device_count())

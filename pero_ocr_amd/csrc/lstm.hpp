@@ -1,0 +1,96 @@
+// lstm.hpp — one time step of a bidirectional LSTM layer (torch.nn.LSTM semantics: gate
+// order i,f,g,o; gates = W_ih x + b_ih + W_hh h + b_hh; c' = f*c + i*g; h' = o*tanh(c')).
+// The reference runs it inside its opaque TorchScript model (pytorch_ocr_engine.py:66-69;
+// aten::lstm / mkldnn_rnn_layer in the CPU profile).
+//
+// The input projections W_ih x + (b_ih + b_hh) for ALL time steps are hoisted into one
+// MFMA GEMM (conv_igemm_kernel as a 1x1 conv) -> xproj [n][T][2*4H] (dir-major).
+// This kernel does the serial part for step s: fwd direction at t = s, bwd at t = T-1-s.
+//
+// Work split: grid = (H/16 unit groups, ceil(n/16) line slices, 2 directions); a workgroup
+// computes the 4 gates of 16 hidden units for 16 lines: a [16 lines] x [4 x 16 gate columns]
+// x [K = H] GEMM on v_mfma_f32_16x16x4_f32.  Its 4 waves split K; partial sums meet in LDS,
+// then thread (line, unit) applies the gate non-linearities.  h ping-pongs between two
+// HBM buffers (kernel boundary = the step barrier); W_hh is read from L2 in fragment order
+//   whh_frag[dir][unit_group][k/16][gate][lane][j] = W_hh[gate*H + 16*ug + (lane&15)][16*kg + 4*(lane>>4) + j].
+#pragma once
+#include <hip/hip_runtime.h>
+#include "conv_igemm.hpp"
+
+namespace pocr {
+
+struct LstmStepArgs {
+    const float *xproj;     // [n][T][8H]   (dir, gate, unit)
+    const float *whh_frag;  // [2][H/16][H/16][4][64][4]
+    const float *h_in;      // [2][npad][H]
+    float *h_out;           // [2][npad][H]
+    float *c;               // [2][npad][H]  (in place)
+    float *y;               // [n][T][2H]    layer output, fwd in [0,H), bwd in [H,2H)
+    int32_t n, npad, T, H, step;
+};
+
+__device__ __forceinline__ float sigmoid_f32(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
+    __shared__ float part[4 * 4 * 64 * 4];      // [wave][gate][lane][reg]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int ug = blockIdx.x, slice = blockIdx.y, dir = blockIdx.z;
+    const int H = a.H, KGT = H / 16;
+    const int t = dir == 0 ? a.step : a.T - 1 - a.step;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float *hrow = a.h_in + ((size_t)dir * a.npad + slice * 16 + li) * H;
+    const f32x4 *wf = reinterpret_cast<const f32x4 *>(a.whh_frag) + ((size_t)(dir * KGT + ug) * KGT) * 4 * 64 + lane;
+    // this wave's share of K: 16-wide groups kg = wave, wave+4, ...
+    for (int kg = wave; kg < KGT; kg += 4) {
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(hrow + kg * 16 + kq * 4);
+        f32x4 bv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[g] = wf[((size_t)kg * 4 + g) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[g][j], acc[g], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4 *>(&part[((wave * 4 + g) * 64 + lane) * 4]) = acc[g];
+    __syncthreads();
+
+    // thread -> (line i, unit u); D layout: lane = (i/4)*16 + u, reg = i%4
+    const int u = tid & 15, i = tid >> 4;
+    const int line = slice * 16 + i;
+    const int src = (((i >> 2) * 16 + u) * 4) + (i & 3);
+    float gate[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float s = part[(0 * 4 + g) * 256 + src];
+        s += part[(1 * 4 + g) * 256 + src];
+        s += part[(2 * 4 + g) * 256 + src];
+        s += part[(3 * 4 + g) * 256 + src];
+        gate[g] = s;
+    }
+    const int unit = ug * 16 + u;
+    const size_t sidx = ((size_t)dir * a.npad + line) * H + unit;
+    if (line < a.n) {
+        const float *xp = a.xproj + ((size_t)line * a.T + t) * (8 * H) + (size_t)dir * 4 * H + unit;
+        const float gi = sigmoid_f32(gate[0] + xp[0]);
+        const float gf = sigmoid_f32(gate[1] + xp[H]);
+        const float gg = tanhf(gate[2] + xp[2 * H]);
+        const float go = sigmoid_f32(gate[3] + xp[3 * H]);
+        const float cn = gf * a.c[sidx] + gi * gg;
+        const float hn = go * tanhf(cn);
+        a.c[sidx] = cn;
+        a.h_out[sidx] = hn;
+        a.y[((size_t)line * a.T + t) * (2 * H) + (size_t)dir * H + unit] = hn;
+    } else {
+        a.h_out[sidx] = 0.f;    // padding lines of the last slice stay zero
+    }
+}
+
+}  // namespace pocr

@@ -1,0 +1,565 @@
+// pocr_hip.hip — C ABI (include/pocr.h) + host-side orchestration of the gfx950 kernels.
+// One engine = one GPU, one HIP stream.  No CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/pocr.h"
+#include "conv_igemm.hpp"
+#include "ctc.hpp"
+#include "lstm.hpp"
+
+using namespace pocr;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// (cin, cout, act, poolh, poolw) — same table as pero_ocr_amd/netspec.py CONV_PLAN
+struct ConvLayer { int cin, cout, act, ph, pw; };
+const ConvLayer kConvPlan[9] = {
+    {3, 64, ACT_RELU, 1, 1},    {64, 64, ACT_RELU, 2, 2},   {64, 128, ACT_RELU, 1, 1},
+    {128, 128, ACT_RELU, 2, 2}, {128, 256, ACT_RELU, 1, 1}, {256, 256, ACT_RELU, 1, 1},
+    {256, 256, ACT_RELU, 2, 1}, {256, 512, ACT_LEAKY, 1, 1}, {512, 512, ACT_LEAKY, 1, 1},
+};
+const float kBnEps = 1e-5f;
+
+// fragment-order weights: wfrag[tap][cin/16][cout16][lane][j]
+//   = W(cout = 16*s + (lane & 15), cin = 16*g + 4*(lane >> 4) + j, tap), zero outside the valid range.
+std::vector<float> build_wfrag(int ntaps, int cin_pad, int cout16,
+                               const std::function<float(int, int, int)> &W, int cin_valid, int cout_valid) {
+    std::vector<float> out((size_t)ntaps * (cin_pad / 16) * cout16 * 256, 0.f);
+    size_t o = 0;
+    for (int tap = 0; tap < ntaps; ++tap)
+        for (int g = 0; g < cin_pad / 16; ++g)
+            for (int s = 0; s < cout16; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j, ++o) {
+                        const int co = 16 * s + (lane & 15), ci = 16 * g + 4 * (lane >> 4) + j;
+                        if (co < cout_valid && ci < cin_valid) out[o] = W(co, ci, tap);
+                    }
+    return out;
+}
+
+template <class Kern>
+int launch_conv(Kern kern, int TH, int TW, int NT, int nthreads, ConvArgs a, hipStream_t st) {
+    a.tiles_w = (a.Wo + TW - 1) / TW;
+    a.tiles_h = (a.Ho + TH - 1) / TH;
+    a.tiles_n = (a.cout16 * 16) / NT;
+    const size_t blocks = (size_t)a.tiles_w * a.tiles_h * a.tiles_n * a.n;
+    if (blocks == 0) return 0;
+    if (blocks > 0x7fffffffull) return fail("conv grid too large (%zu blocks)", blocks);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(nthreads), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// tile configurations (KH,KW,PADH,PADW, TH,MW,NS,NWAVE,KC, POOLH,POOLW, ACT,BN, STAGER)
+#define POCR_CONV(name, KH, KW, PH, PW, TH, MW, NS, NWAVE, KC, POOLH, POOLW, ACT, BN, STG)                       \
+    int name(ConvArgs a, hipStream_t st) {                                                                     \
+        return launch_conv(conv_igemm_kernel<KH, KW, PH, PW, TH, MW, NS, NWAVE, KC, POOLH, POOLW, ACT, BN, STG>, \
+                           TH, 16 * MW, NS * NWAVE * 16, NWAVE * 64, a, st);                                  \
+    }
+//                 KH KW P  P  TH MW NS NW KC PH PW
+POCR_CONV(conv1_u8,  1, 1, 0, 0, 4, 2, 1, 4, 32, 1, 1, ACT_RELU, false, STAGE_U8_LINES)   // 3->64 (im2col K=27->32)
+POCR_CONV(conv2_k,   3, 3, 1, 1, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, STAGE_F32_NHWC)   // 64->64   + pool 2x2
+POCR_CONV(conv3_k,   3, 3, 1, 1, 4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC)   // 64->128
+POCR_CONV(conv4_k,   3, 3, 1, 1, 4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, STAGE_F32_NHWC)   // 128->128 + pool 2x2
+POCR_CONV(conv56_k,  3, 3, 1, 1, 10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC)  // ->256
+POCR_CONV(conv7_k,   3, 3, 1, 1, 10, 1, 2, 4, 16, 2, 1, ACT_RELU, false, STAGE_F32_NHWC)  // 256->256 + pool 2x1
+POCR_CONV(conv8_k,   3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC)  // 256->512
+POCR_CONV(conv9_k,   3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, STAGE_F32_NHWC)   // 512->512 + BN
+POCR_CONV(agg4_k,    4, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC)
+POCR_CONV(agg5_k,    5, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC)
+POCR_CONV(agg6_k,    6, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC)
+POCR_CONV(agg8_k,    8, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC)
+POCR_CONV(gemm128_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC)   // rows x 128 cols per WG
+POCR_CONV(gemm64_k,  1, 1, 0, 0, 1, 8, 1, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC)   // rows x 64 cols per WG
+const int kConvNT[9] = {64, 64, 128, 128, 128, 128, 128, 256, 256};
+const int kAggNT = 256, kProjNT = 128, kHeadNT = 64;
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct pocr_engine {
+    pocr_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // weights (device)
+    DevBuf conv_w[9], conv_b[9], bn_scale, bn_shift, agg_w, agg_b, head_w, head_b, lut;
+    std::vector<DevBuf> proj_w, proj_b, whh;       // per LSTM layer
+    int conv_cout16[9]{};
+    int agg_cout16 = 0, head_cout16 = 0, proj_cout16 = 0;
+    // staged chunk
+    DevBuf crops, lines;
+    int n = 0, w_pad = 0;
+    bool staged = false;
+    // activations
+    DevBuf act[9], feat, xproj, hbuf, cbuf, logits, best, labels, lens;
+    std::vector<DevBuf> lstm_y;
+    int act_h[9]{}, act_w[9]{}, act_c[9]{};
+    // host pinned staging for the small outputs
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[POCR_NUM_STAGES + 1]{};
+    float stage_ms[POCR_NUM_STAGES]{};
+    bool have_ms = false;
+};
+
+namespace {
+
+int upload(DevBuf &b, const std::vector<float> &v, hipStream_t st) {
+    if (b.reserve(v.size() * sizeof(float))) return 1;
+    HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int check_cfg(const pocr_config *c) {
+    if (!c) return fail("config is NULL");
+    if (c->abi_version != POCR_ABI_VERSION) return fail("ABI version mismatch: got %d, library is %d", c->abi_version, POCR_ABI_VERSION);
+    if (c->height <= 0 || c->height % 8) return fail("height must be a positive multiple of 8 (got %d)", c->height);
+    const int ah = c->height / 8;
+    if (ah != 4 && ah != 5 && ah != 6 && ah != 8) return fail("unsupported height %d (aggregation height %d; built for 32/40/48/64)", c->height, ah);
+    if (c->num_classes < 2) return fail("num_classes must be >= 2");
+    if (c->conv_out <= 0 || c->conv_out % 16) return fail("conv_out must be a positive multiple of 16");
+    if (c->lstm_hidden <= 0 || c->lstm_hidden % 16) return fail("lstm_hidden must be a positive multiple of 16");
+    if (c->lstm_layers < 1) return fail("lstm_layers must be >= 1");
+    return 0;
+}
+
+struct WeightCursor {
+    const float *p;
+    const float *take(size_t n) { const float *r = p; p += n; return r; }
+};
+
+int run_network(pocr_engine *e) {
+    const pocr_config &c = e->cfg;
+    hipStream_t st = e->stream;
+    const int n = e->n, H = c.height, W = e->w_pad;
+    const bool prof = e->profiling;
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(e->ev[i], st); };
+
+    // ---- conv stack
+    int h = H, w = W;
+    for (int i = 0; i < 9; ++i) {
+        const ConvLayer &L = kConvPlan[i];
+        const int ho = h / L.ph, wo = w / L.pw;
+        if (e->act[i].reserve((size_t)n * ho * wo * L.cout * sizeof(float))) return 1;
+        ConvArgs a{};
+        a.n = n; a.H = h; a.W = w; a.Ho = h; a.Wo = w;
+        a.cout16 = e->conv_cout16[i]; a.cout_valid = L.cout; a.out_stride = L.cout;
+        a.wfrag = e->conv_w[i].as<float>(); a.bias = e->conv_b[i].as<float>();
+        a.y = e->act[i].as<float>();
+        mark(i);
+        int rc = 0;
+        if (i == 0) {
+            a.crops = e->crops.as<uint8_t>(); a.lines = e->lines.as<LineDesc>(); a.lut = e->lut.as<float>();
+            a.cin = 32;
+            rc = conv1_u8(a, st);
+        } else {
+            a.x = e->act[i - 1].as<float>(); a.cin = L.cin;
+            if (i == 8) { a.bn_scale = e->bn_scale.as<float>(); a.bn_shift = e->bn_shift.as<float>(); }
+            switch (i) {
+                case 1: rc = conv2_k(a, st); break;
+                case 2: rc = conv3_k(a, st); break;
+                case 3: rc = conv4_k(a, st); break;
+                case 4: case 5: rc = conv56_k(a, st); break;
+                case 6: rc = conv7_k(a, st); break;
+                case 7: rc = conv8_k(a, st); break;
+                default: rc = conv9_k(a, st); break;
+            }
+        }
+        if (rc) return rc;
+        h = ho; w = wo;
+        e->act_h[i] = h; e->act_w[i] = w; e->act_c[i] = L.cout;
+    }
+    // ---- aggregation conv: [n][H/8][T][512] -> [n][T][E]
+    const int T = w, E = c.conv_out, AH = h;
+    {
+        if (e->feat.reserve((size_t)n * T * E * sizeof(float))) return 1;
+        ConvArgs a{};
+        a.x = e->act[8].as<float>(); a.n = n; a.H = AH; a.W = T; a.Ho = 1; a.Wo = T; a.cin = 512;
+        a.cout16 = e->agg_cout16; a.cout_valid = E; a.out_stride = E;
+        a.wfrag = e->agg_w.as<float>(); a.bias = e->agg_b.as<float>(); a.y = e->feat.as<float>();
+        mark(POCR_STAGE_AGG);
+        int rc = AH == 4 ? agg4_k(a, st) : AH == 5 ? agg5_k(a, st) : AH == 6 ? agg6_k(a, st) : agg8_k(a, st);
+        if (rc) return rc;
+    }
+    // ---- BiLSTM stack
+    const int Hh = c.lstm_hidden, npad = round_up(n, 16);
+    mark(POCR_STAGE_LSTM);
+    if (e->xproj.reserve((size_t)n * T * 8 * Hh * sizeof(float))) return 1;
+    if (e->hbuf.reserve((size_t)2 * 2 * npad * Hh * sizeof(float))) return 1;
+    if (e->cbuf.reserve((size_t)2 * npad * Hh * sizeof(float))) return 1;
+    const float *layer_in = e->feat.as<float>();
+    int din = E;
+    for (int l = 0; l < c.lstm_layers; ++l) {
+        if (e->lstm_y[l].reserve((size_t)n * T * 2 * Hh * sizeof(float))) return 1;
+        ConvArgs a{};
+        a.x = layer_in; a.n = 1; a.H = 1; a.W = n * T; a.Ho = 1; a.Wo = n * T; a.cin = din;
+        a.cout16 = e->proj_cout16; a.cout_valid = 8 * Hh; a.out_stride = 8 * Hh;
+        a.wfrag = e->proj_w[l].as<float>(); a.bias = e->proj_b[l].as<float>(); a.y = e->xproj.as<float>();
+        if (gemm128_k(a, st)) return 1;
+        const size_t hsz = (size_t)2 * npad * Hh;
+        HIP_TRY(hipMemsetAsync(e->hbuf.p, 0, 2 * hsz * sizeof(float), st));
+        HIP_TRY(hipMemsetAsync(e->cbuf.p, 0, hsz * sizeof(float), st));
+        for (int s = 0; s < T; ++s) {
+            LstmStepArgs la{};
+            la.xproj = e->xproj.as<float>(); la.whh_frag = e->whh[l].as<float>();
+            la.h_in = e->hbuf.as<float>() + (size_t)(s & 1) * hsz;
+            la.h_out = e->hbuf.as<float>() + (size_t)((s + 1) & 1) * hsz;
+            la.c = e->cbuf.as<float>(); la.y = e->lstm_y[l].as<float>();
+            la.n = n; la.npad = npad; la.T = T; la.H = Hh; la.step = s;
+            hipLaunchKernelGGL(lstm_step_kernel, dim3(Hh / 16, npad / 16, 2), dim3(256), 0, st, la);
+        }
+        HIP_TRY(hipGetLastError());
+        layer_in = e->lstm_y[l].as<float>();
+        din = 2 * Hh;
+    }
+    // ---- head: [n*T][2H] -> logits [n][T][C]
+    const int C = c.num_classes;
+    {
+        if (e->logits.reserve((size_t)n * T * C * sizeof(float))) return 1;
+        ConvArgs a{};
+        a.x = layer_in; a.n = 1; a.H = 1; a.W = n * T; a.Ho = 1; a.Wo = n * T; a.cin = 2 * Hh;
+        a.cout16 = e->head_cout16; a.cout_valid = C; a.out_stride = C;
+        a.wfrag = e->head_w.as<float>(); a.bias = e->head_b.as<float>(); a.y = e->logits.as<float>();
+        mark(POCR_STAGE_HEAD);
+        if (gemm64_k(a, st)) return 1;
+    }
+    // ---- greedy CTC
+    {
+        if (e->best.reserve((size_t)n * T * sizeof(int32_t))) return 1;
+        if (e->labels.reserve((size_t)n * T * sizeof(int32_t))) return 1;
+        if (e->lens.reserve((size_t)n * sizeof(int32_t))) return 1;
+        mark(POCR_STAGE_CTC);
+        const int frames = n * T;
+        hipLaunchKernelGGL(frame_argmax_kernel, dim3((frames + 3) / 4), dim3(256), 0, st,
+                           e->logits.as<float>(), e->best.as<int32_t>(), frames, C);
+        hipLaunchKernelGGL(ctc_collapse_kernel, dim3(n), dim3(64), 0, st, e->best.as<int32_t>(),
+                           e->labels.as<int32_t>(), e->lens.as<int32_t>(), T, C - 1);
+        HIP_TRY(hipGetLastError());
+        mark(POCR_NUM_STAGES);
+    }
+    return 0;
+}
+
+int fetch_outputs(pocr_engine *e, float *logits_ntc, int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n) {
+    const int n = e->n, T = (e->w_pad / 2) / 2, C = e->cfg.num_classes;
+    hipStream_t st = e->stream;
+    const size_t nt_bytes = (size_t)n * T * sizeof(int32_t);
+    const size_t need = 2 * nt_bytes + (size_t)n * sizeof(int32_t);
+    if (need > e->pinned_cap) {
+        if (e->pinned) (void)hipHostFree(e->pinned);
+        e->pinned = nullptr; e->pinned_cap = 0;
+        HIP_TRY(hipHostMalloc(&e->pinned, need + need / 4, hipHostMallocDefault));
+        e->pinned_cap = need + need / 4;
+    }
+    char *pin = static_cast<char *>(e->pinned);
+    if (labels_nt) HIP_TRY(hipMemcpyAsync(pin, e->labels.p, nt_bytes, hipMemcpyDeviceToHost, st));
+    if (frame_argmax_nt) HIP_TRY(hipMemcpyAsync(pin + nt_bytes, e->best.p, nt_bytes, hipMemcpyDeviceToHost, st));
+    if (label_len_n) HIP_TRY(hipMemcpyAsync(pin + 2 * nt_bytes, e->lens.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (logits_ntc) HIP_TRY(hipMemcpyAsync(logits_ntc, e->logits.p, (size_t)n * T * C * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (labels_nt) memcpy(labels_nt, pin, nt_bytes);
+    if (frame_argmax_nt) memcpy(frame_argmax_nt, pin + nt_bytes, nt_bytes);
+    if (label_len_n) memcpy(label_len_n, pin + 2 * nt_bytes, (size_t)n * sizeof(int32_t));
+    if (e->profiling) {
+        for (int i = 0; i < POCR_NUM_STAGES; ++i) e->stage_ms[i] = 0.f;
+        const int order[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, POCR_STAGE_AGG, POCR_STAGE_LSTM, POCR_STAGE_HEAD, POCR_STAGE_CTC, POCR_NUM_STAGES};
+        for (int k = 0; k + 1 < (int)(sizeof(order) / sizeof(int)); ++k)
+            HIP_TRY(hipEventElapsedTime(&e->stage_ms[order[k]], e->ev[order[k]], e->ev[order[k + 1]]));
+        HIP_TRY(hipEventElapsedTime(&e->stage_ms[POCR_STAGE_TOTAL], e->ev[0], e->ev[POCR_NUM_STAGES]));
+        e->have_ms = true;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pocr_last_error(void) { return g_err.c_str(); }
+int pocr_abi_version(void) { return POCR_ABI_VERSION; }
+
+int pocr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t pocr_num_weight_floats(const pocr_config *c) {
+    if (check_cfg(c)) return 0;
+    size_t t = 0;
+    for (const ConvLayer &L : kConvPlan) t += (size_t)L.cout * L.cin * 9 + L.cout;
+    t += 4 * 512;
+    t += (size_t)c->conv_out * 512 * (c->height / 8) + c->conv_out;
+    const size_t Hh = c->lstm_hidden;
+    for (int l = 0; l < c->lstm_layers; ++l) {
+        const size_t din = l == 0 ? c->conv_out : 2 * Hh;
+        t += 2 * (4 * Hh * din + 4 * Hh * Hh + 8 * Hh);
+    }
+    t += (size_t)c->num_classes * 2 * Hh + c->num_classes;
+    return t;
+}
+
+int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, int device_id, pocr_engine **out) {
+    if (!out) return fail("out is NULL");
+    *out = nullptr;
+    if (check_cfg(cfg)) return 1;
+    if (!weights) return fail("weights is NULL");
+    if (n_floats != pocr_num_weight_floats(cfg))
+        return fail("weight blob has %zu floats, config needs %zu", n_floats, pocr_num_weight_floats(cfg));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail("no HIP device available: this library has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail("device_id %d out of range (%d devices)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+
+    pocr_engine *e = new pocr_engine();
+    e->cfg = *cfg;
+    e->device = device_id;
+    auto bail = [&](int rc) { pocr_destroy(e); return rc; };
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
+    for (auto &ev : e->ev)
+        if (hipEventCreate(&ev) != hipSuccess) return bail(fail("hipEventCreate failed"));
+    hipStream_t st = e->stream;
+
+    WeightCursor cur{weights};
+    // conv1..9
+    for (int i = 0; i < 9; ++i) {
+        const ConvLayer &L = kConvPlan[i];
+        const float *w = cur.take((size_t)L.cout * L.cin * 9);
+        const float *b = cur.take(L.cout);
+        const int cout16 = round_up(L.cout, kConvNT[i]) / 16;
+        e->conv_cout16[i] = cout16;
+        std::vector<float> frag;
+        if (i == 0) {   // im2col form: one tap, "cin" k = (ky*3+kx)*3 + c, padded 27 -> 32
+            frag = build_wfrag(1, 32, cout16, [&](int co, int k, int) { const int tap = k / 3, c = k % 3; return w[((size_t)co * 3 + c) * 9 + tap]; }, 27, L.cout);
+        } else {
+            frag = build_wfrag(9, L.cin, cout16, [&](int co, int ci, int tap) { return w[((size_t)co * L.cin + ci) * 9 + tap]; }, L.cin, L.cout);
+        }
+        std::vector<float> bias(cout16 * 16, 0.f);
+        for (int k = 0; k < L.cout; ++k) bias[k] = b[k];
+        if (upload(e->conv_w[i], frag, st) || upload(e->conv_b[i], bias, st)) return bail(1);
+    }
+    {   // BatchNorm2d(512) eval: y = (x - mean) / sqrt(var + eps) * gamma + beta = x * scale + shift
+        const float *gamma = cur.take(512), *beta = cur.take(512), *mean = cur.take(512), *var = cur.take(512);
+        std::vector<float> sc(512), sh(512);
+        for (int k = 0; k < 512; ++k) {
+            const float inv = 1.0f / std::sqrt(var[k] + kBnEps);
+            sc[k] = gamma[k] * inv;
+            sh[k] = beta[k] - mean[k] * sc[k];
+        }
+        if (upload(e->bn_scale, sc, st) || upload(e->bn_shift, sh, st)) return bail(1);
+    }
+    {   // aggregation conv (AH x 1)
+        const int AH = cfg->height / 8, E = cfg->conv_out;
+        const float *w = cur.take((size_t)E * 512 * AH);
+        const float *b = cur.take(E);
+        e->agg_cout16 = round_up(E, kAggNT) / 16;
+        auto frag = build_wfrag(AH, 512, e->agg_cout16, [&](int co, int ci, int tap) { return w[((size_t)co * 512 + ci) * AH + tap]; }, 512, E);
+        std::vector<float> bias(e->agg_cout16 * 16, 0.f);
+        for (int k = 0; k < E; ++k) bias[k] = b[k];
+        if (upload(e->agg_w, frag, st) || upload(e->agg_b, bias, st)) return bail(1);
+    }
+    {   // BiLSTM layers
+        const int Hh = cfg->lstm_hidden, KGT = Hh / 16;
+        e->proj_cout16 = round_up(8 * Hh, kProjNT) / 16;
+        e->proj_w.resize(cfg->lstm_layers); e->proj_b.resize(cfg->lstm_layers);
+        e->whh.resize(cfg->lstm_layers); e->lstm_y.resize(cfg->lstm_layers);
+        for (int l = 0; l < cfg->lstm_layers; ++l) {
+            const int din = l == 0 ? cfg->conv_out : 2 * Hh;
+            const float *wih[2], *whh[2], *bih[2], *bhh[2];
+            for (int d = 0; d < 2; ++d) {
+                wih[d] = cur.take((size_t)4 * Hh * din); whh[d] = cur.take((size_t)4 * Hh * Hh);
+                bih[d] = cur.take(4 * Hh); bhh[d] = cur.take(4 * Hh);
+            }
+            auto frag = build_wfrag(1, din, e->proj_cout16, [&](int co, int ci, int) { const int d = co / (4 * Hh), r = co % (4 * Hh); return wih[d][(size_t)r * din + ci]; }, din, 8 * Hh);
+            std::vector<float> bias(e->proj_cout16 * 16, 0.f);
+            for (int d = 0; d < 2; ++d)
+                for (int r = 0; r < 4 * Hh; ++r) bias[d * 4 * Hh + r] = bih[d][r] + bhh[d][r];
+            // whh_frag[dir][ug][kg][gate][lane][j] = W_hh[gate*H + 16*ug + (lane&15)][16*kg + 4*(lane>>4) + j]
+            std::vector<float> wf((size_t)2 * KGT * KGT * 4 * 256);
+            size_t o = 0;
+            for (int d = 0; d < 2; ++d)
+                for (int ug = 0; ug < KGT; ++ug)
+                    for (int kg = 0; kg < KGT; ++kg)
+                        for (int g = 0; g < 4; ++g)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 4; ++j)
+                                    wf[o++] = whh[d][(size_t)(g * Hh + 16 * ug + (lane & 15)) * Hh + 16 * kg + 4 * (lane >> 4) + j];
+            if (upload(e->proj_w[l], frag, st) || upload(e->proj_b[l], bias, st) || upload(e->whh[l], wf, st)) return bail(1);
+        }
+    }
+    {   // head
+        const int Hh = cfg->lstm_hidden, C = cfg->num_classes;
+        const float *w = cur.take((size_t)C * 2 * Hh);
+        const float *b = cur.take(C);
+        e->head_cout16 = round_up(C, kHeadNT) / 16;
+        auto frag = build_wfrag(1, 2 * Hh, e->head_cout16, [&](int co, int ci, int) { return w[(size_t)co * 2 * Hh + ci]; }, 2 * Hh, C);
+        std::vector<float> bias(e->head_cout16 * 16, 0.f);
+        for (int k = 0; k < C; ++k) bias[k] = b[k];
+        if (upload(e->head_w, frag, st) || upload(e->head_b, bias, st)) return bail(1);
+    }
+    {   // u8 -> f32 table, bit-exact with torch's .float() / 255.0 (true division, pytorch_ocr_engine.py:61)
+        std::vector<float> lut(256);
+        for (int i = 0; i < 256; ++i) lut[i] = (float)i / 255.0f;
+        if (upload(e->lut, lut, st)) return bail(1);
+    }
+    *out = e;
+    return 0;
+}
+
+void pocr_destroy(pocr_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &b : e->conv_w) b.release();
+    for (auto &b : e->conv_b) b.release();
+    for (auto &b : e->act) b.release();
+    for (auto &v : {&e->proj_w, &e->proj_b, &e->whh, &e->lstm_y})
+        for (auto &b : *v) b.release();
+    for (DevBuf *b : {&e->bn_scale, &e->bn_shift, &e->agg_w, &e->agg_b, &e->head_w, &e->head_b, &e->lut, &e->crops,
+                      &e->lines, &e->feat, &e->xproj, &e->hbuf, &e->cbuf, &e->logits, &e->best, &e->labels, &e->lens})
+        b->release();
+    if (e->pinned) (void)hipHostFree(e->pinned);
+    for (auto &ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int pocr_stage_lines(pocr_engine *e, const uint8_t *crops, const int64_t *crop_offsets, const int32_t *widths,
+                     int32_t n, int32_t w_pad, int32_t pad_left) {
+    if (!e) return fail("engine is NULL");
+    e->staged = false;
+    if (n <= 0) return fail("n must be positive (got %d)", n);
+    if (w_pad < 4) return fail("w_pad must be >= 4 (got %d)", w_pad);
+    if (pad_left < 0) return fail("pad_left must be >= 0");
+    if (!crops || !crop_offsets || !widths) return fail("NULL input pointer");
+    HIP_TRY(hipSetDevice(e->device));
+    const int H = e->cfg.height;
+    std::vector<LineDesc> desc(n);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (widths[i] < 0) return fail("line %d has negative width", i);
+        if (crop_offsets[i] < 0) return fail("line %d has negative offset", i);
+        desc[i].offset = crop_offsets[i];
+        desc[i].width = widths[i];
+        desc[i].pad_left = pad_left;
+        const size_t end = (size_t)crop_offsets[i] + (size_t)H * widths[i] * 3;
+        if (end > total) total = end;
+    }
+    if (e->crops.reserve(total ? total : 1)) return 1;
+    if (e->lines.reserve((size_t)n * sizeof(LineDesc))) return 1;
+    if (total) HIP_TRY(hipMemcpyAsync(e->crops.p, crops, total, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->lines.p, desc.data(), (size_t)n * sizeof(LineDesc), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->n = n; e->w_pad = w_pad; e->staged = true;
+    return 0;
+}
+
+int pocr_run_staged(pocr_engine *e, float *logits_ntc, int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n) {
+    if (!e) return fail("engine is NULL");
+    if (!e->staged) return fail("no chunk staged: call pocr_stage_lines first");
+    HIP_TRY(hipSetDevice(e->device));
+    if (run_network(e)) return 1;
+    return fetch_outputs(e, logits_ntc, frame_argmax_nt, labels_nt, label_len_n);
+}
+
+int pocr_run_batch(pocr_engine *e, const uint8_t *batch_nhwc, int32_t n, int32_t w_pad, float *logits_ntc,
+                   int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n) {
+    if (!e) return fail("engine is NULL");
+    if (n <= 0) return fail("n must be positive (got %d)", n);
+    if (w_pad < 4) return fail("w_pad must be >= 4 (got %d)", w_pad);
+    std::vector<int64_t> off(n);
+    std::vector<int32_t> wd(n, w_pad);
+    const int64_t per = (int64_t)e->cfg.height * w_pad * 3;
+    for (int i = 0; i < n; ++i) off[i] = per * i;
+    if (pocr_stage_lines(e, batch_nhwc, off.data(), wd.data(), n, w_pad, 0)) return 1;
+    return pocr_run_staged(e, logits_ntc, frame_argmax_nt, labels_nt, label_len_n);
+}
+
+int pocr_set_profiling(pocr_engine *e, int32_t enabled) {
+    if (!e) return fail("engine is NULL");
+    e->profiling = enabled != 0;
+    e->have_ms = false;
+    return 0;
+}
+
+int pocr_last_stage_ms(pocr_engine *e, float *ms, int32_t cap) {
+    if (!e || !ms) return 0;
+    if (!e->have_ms) return 0;
+    int k = cap < POCR_NUM_STAGES ? cap : POCR_NUM_STAGES;
+    for (int i = 0; i < k; ++i) ms[i] = e->stage_ms[i];
+    return k;
+}
+
+int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t *n_floats) {
+    if (!e) return fail("engine is NULL");
+    if (!e->staged) return fail("nothing has been run");
+    HIP_TRY(hipSetDevice(e->device));
+    const int n = e->n, T = (e->w_pad / 2) / 2;
+    const float *src = nullptr;
+    size_t sz = 0;
+    if (what >= 0 && what < 9) { src = e->act[what].as<float>(); sz = (size_t)n * e->act_h[what] * e->act_w[what] * e->act_c[what]; }
+    else if (what == 9) { src = e->feat.as<float>(); sz = (size_t)n * T * e->cfg.conv_out; }
+    else if (what >= 10 && what < 10 + e->cfg.lstm_layers) { src = e->lstm_y[what - 10].as<float>(); sz = (size_t)n * T * 2 * e->cfg.lstm_hidden; }
+    else return fail("unknown activation id %d", what);
+    if (n_floats) *n_floats = sz;
+    const size_t k = cap < sz ? cap : sz;
+    if (out && k) {
+        HIP_TRY(hipMemcpyAsync(out, src, k * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+"""Caller-side adapter of the hot path: counterpart of the reference's PageOCR
+(pero_ocr/document_ocr/page_parser.py:406-434).  It gathers the crops of a page's
+text lines, calls `engine.process_lines` once for the whole page and writes the
+four result fields back on each line object (transcription, logits, characters,
+logit_coords - the TextLine contract of pero_ocr/core/layout.py:41-72).
+
+The page/line classes are duck-typed: anything with `lines_iterator()` yielding
+objects that carry `.crop` and `.id` works, so an unmodified pero-ocr PageLayout
+can be passed in (INTEGRATION.md shows the one-line swap inside pero-ocr itself).
+"""
+from __future__ import annotations
+
+from .. ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+
+
+class PageOCR:
+    def __init__(self, config, device, config_path=""):
+        """config: mapping with OCR_JSON (and optional USE_CPU / METHOD) like the [OCR] INI section."""
+        import os
+        json_file = config["OCR_JSON"]
+        if not os.path.isabs(json_file):
+            json_file = os.path.join(config_path, json_file)
+        use_cpu = str(config.get("USE_CPU", "no")).lower() in ("1", "yes", "true", "on")
+        if use_cpu:
+            raise RuntimeError("USE_CPU is set: pero_ocr_amd has no CPU path")
+        if config.get("METHOD", "") == "pytorch_ocr-transformer":
+            raise NotImplementedError("the seq2seq transformer engine is not part of this build (SURVEY.md 8f-3)")
+        self.device = device
+        self.ocr_engine = PytorchEngineLineOCR(json_file, self.device)
+
+    def process_page(self, img, page_layout):
+        lines = list(page_layout.lines_iterator())
+        for line in lines:
+            if line.crop is None:
+                raise Exception(f"Missing crop in line {line.id}.")
+        texts, logits, coords = self.ocr_engine.process_lines([line.crop for line in lines])
+        for line, text, line_logits, line_coords in zip(lines, texts, logits, coords):
+            line.transcription = text
+            line.logits = line_logits
+            line.characters = self.ocr_engine.characters
+            line.logit_coords = line_coords
+        return page_layout
+
+    @property
+    def provides_ctc_logits(self):
+        return isinstance(self.ocr_engine, PytorchEngineLineOCR)

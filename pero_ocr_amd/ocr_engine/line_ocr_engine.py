@@ -1,0 +1,145 @@
+"""Host side of the line recogniser: engine-JSON parsing, the reference's
+width-sorted chunking, scatter of results back to input order, logit_coords and
+logit sparsification.
+
+Mirrors the public surface of the reference's BaseEngineLineOCR
+(pero_ocr/ocr_engine/line_ocr_engine.py:16-177): same constructor arguments,
+same attributes (`characters`, `batch_size`, `max_input_horizontal_pixels`,
+`line_px_height`, `line_padding_px`, `embed_id`, `embed_num`, `config`, ...),
+same `process_lines` signature, defaults and return contract.  Only the CTC
+branch is implemented (the transformer split/merge branch :95-119,131-142 is a
+SURVEY.md section 8 "next" row).
+
+Chunking is part of the numerical contract: a line's logits
+depend on the padded width of its chunk, so `plan_chunks` reproduces
+line_ocr_engine.py:79-90 exactly - descending stable width sort, chunk size
+max(1, max_input_horizontal_pixels // ceil32(widest remaining)).
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+from scipy import sparse
+
+from .softmax import softmax
+
+SPARSE_PROB_THRESHOLD = 0.0001     # line_ocr_engine.py:170
+
+
+@dataclass
+class Chunk:
+    """One device batch: which input lines, and the geometry they are padded to."""
+    line_ids: List[int]
+    max_width: int          # ceil32 of the widest line in the chunk
+    w_pad: int              # columns actually fed to the network
+
+    @property
+    def frames(self) -> int:
+        return (self.w_pad // 2) // 2
+
+
+def ceil32(v: int) -> int:
+    return -(-int(v) // 32) * 32
+
+
+def plan_chunks(widths: Sequence[int], max_input_horizontal_pixels: int, line_padding_px: int = 32) -> List[Chunk]:
+    order = sorted(range(len(widths)), key=lambda i: -int(widths[i]))      # stable, like the reference's sorted()
+    chunks, pos = [], 0
+    while pos < len(order):
+        max_width = ceil32(widths[order[pos]])
+        if max_width == 0:       # the reference divides by ceil32(0) here (line_ocr_engine.py:87)
+            raise ZeroDivisionError("zero-width line crop")
+        take = max(1, int(max_input_horizontal_pixels) // max_width)
+        w_pad = min(max_width + 2 * line_padding_px, int(max_input_horizontal_pixels))   # :121 then crop :125-127
+        chunks.append(Chunk(order[pos:pos + take], max_width, w_pad))
+        pos += take
+    return chunks
+
+
+class BaseEngineLineOCR:
+    def __init__(self, json_def, device, batch_size=8, model_type="ctc"):
+        with open(json_def, "r", encoding="utf8") as f:
+            self.config = json.load(f)
+        cfg = self.config
+        self.line_px_height = cfg["line_px_height"]
+        self.line_vertical_scale = cfg["line_vertical_scale"]
+        ckpt = cfg["checkpoint"]
+        self.checkpoint = ckpt if os.path.isabs(ckpt) else os.path.realpath(
+            os.path.join(os.path.dirname(json_def), ckpt))
+        self.characters = tuple(cfg["characters"])
+        self.net_name = cfg["net_name"]
+        self.embed_num = int(cfg["embed_num"]) if "embed_num" in cfg else None
+        self.embed_id = None
+        if "embed_id" in cfg:
+            self.embed_id = "mean" if cfg["embed_id"] == "mean" else int(cfg["embed_id"])
+        self.max_line_width = int(cfg["max_line_width"]) if "max_line_width" in cfg else 1e10
+        if model_type != "ctc":
+            raise NotImplementedError("only the CTC engine is implemented on MI355X (model_type='ctc')")
+        self.model_type = model_type
+        self.device = device
+        self.batch_size = batch_size
+        self.line_padding_px = 32
+        self.max_input_horizontal_pixels = 480 * batch_size      # live-writable: drives the chunk plan
+
+    # -- to be provided by the engine subclass -------------------------------------------
+    def run_ocr(self, batch_data):
+        raise NotImplementedError
+
+    def _recognise_chunk(self, lines, chunk: Chunk, want_logits: bool):
+        """-> (transcriptions, logits [n,T,C] or None).  Default: assemble the padded batch on
+        the host and go through run_ocr (the reference's seam)."""
+        batch = np.zeros([len(chunk.line_ids), self.line_px_height, chunk.max_width + 2 * self.line_padding_px, 3],
+                         dtype=np.uint8)
+        for row, i in zip(batch, chunk.line_ids):
+            row[:, self.line_padding_px:self.line_padding_px + lines[i].shape[1], :] = lines[i]
+        return self.run_ocr(batch[:, :, :chunk.w_pad])
+
+    # -- public API -----------------------------------------------------------------------
+    def process_lines(self, lines, sparse_logits=True, tight_crop_logits=False, no_logits=False):
+        """Recognise a list of `uint8 [line_px_height, w_i, 3]` crops.
+
+        Returns three lists in input order: transcriptions (str), logits
+        (scipy.sparse.csc_matrix float32 [T_i, C]; dense ndarray if sparse_logits=False;
+        None if no_logits) and logit_coords ([start, end] frame span of the un-padded
+        line; [None, None] with tight_crop_logits; None if no_logits)."""
+        n = len(lines)
+        transcriptions: List[Optional[str]] = [None] * n
+        logits_out: List[object] = [None] * n
+        coords_out: List[Optional[list]] = [None] * n
+        for i, line in enumerate(lines):
+            if line.ndim != 3 or line.shape[0] != self.line_px_height or line.shape[2] != 3:
+                raise ValueError(f"line {i}: expected a [{self.line_px_height}, w, 3] crop, got {line.shape}")
+
+        sub = int(self.net_subsampling)
+        pad = int(self.line_padding_px)
+        for chunk in plan_chunks([l.shape[1] for l in lines], self.max_input_horizontal_pixels, pad):
+            if chunk.max_width + 2 * pad > chunk.w_pad:
+                print(f"WARNING: Line too long for OCR engine. Cropping from {chunk.max_width + 2 * pad} px "
+                      f"down to {chunk.w_pad}.")
+            texts, chunk_logits = self._recognise_chunk(lines, chunk, want_logits=not no_logits)
+            for k, i in enumerate(chunk.line_ids):
+                transcriptions[i] = texts[k]
+            if no_logits:
+                continue
+            probs = None
+            if sparse_logits:
+                probs = softmax(chunk_logits, axis=2)       # one vectorised pass per chunk; rows are independent
+            for k, i in enumerate(chunk.line_ids):
+                w = lines[i].shape[1]
+                first, last = pad // sub, (pad + w) // sub
+                ll = chunk_logits[k]
+                if tight_crop_logits:
+                    ll = ll[first:last]
+                    coords_out[i] = [None, None]
+                else:
+                    coords_out[i] = [first, last]
+                if sparse_logits:
+                    pp = probs[k][first:last] if tight_crop_logits else probs[k]
+                    ll = np.where(pp < SPARSE_PROB_THRESHOLD, np.float32(0), ll)
+                    ll = sparse.csc_matrix(ll)
+                logits_out[i] = ll
+        return transcriptions, logits_out, coords_out

@@ -1,0 +1,105 @@
+"""MI355X-native CTC line-recognition engine with the reference's engine surface.
+
+Drop-in for pero_ocr/ocr_engine/pytorch_ocr_engine.py: class name, constructor
+`(json_def, device, batch_size=8)`, attributes and `run_ocr(batch_data) ->
+(decoded strings, float32 [n, T, C] logits)` follow PytorchEngineLineOCR (:37-74);
+`process_lines` comes from BaseEngineLineOCR.  Where the reference does
+`torch.jit.load(checkpoint)` + `model(x)` + `greedy_decode_ctc` (:52-57, :59-74,
+:13-34) this engine hands the uint8 crops to hand-written HIP kernels through the
+C ABI in include/pocr.h (ctypes).  There is no CPU fallback: constructing the
+engine without a usable gfx950 device raises.
+
+Engine JSON: the reference's keys (line_px_height, line_vertical_scale, checkpoint,
+characters, net_name, optional embed_*/max_line_width) plus the build-specific key
+  "net": {"arch": "vgg_blstm_ctc", "conv_out": 512, "lstm_hidden": 256, "lstm_layers": 2,
+          "weight_seed": <int, optional>}
+`checkpoint` names a POCRW001 weight blob (pero_ocr_amd/netspec.py); if the file does
+not exist and "weight_seed" is given, seeded synthetic weights are generated instead
+(there is no network access to fetch real pero checkpoints).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Tuple
+
+import numpy as np
+
+from .. import _native, netspec
+from .line_ocr_engine import BaseEngineLineOCR, Chunk
+
+BLANK_PLACEHOLDER = "\u200B"      # pytorch_ocr_engine.py:42
+
+
+def _device_index(device) -> int:
+    if isinstance(device, int):
+        return device
+    dtype = getattr(device, "type", None)
+    if dtype is None:
+        s = str(device)
+        dtype, _, idx = s.partition(":")
+        index = int(idx) if idx else 0
+    else:
+        index = getattr(device, "index", None)
+        index = 0 if index is None else int(index)
+    if dtype == "cpu":
+        raise RuntimeError("pero_ocr_amd has no CPU path: the engine runs on an MI355X (device 'cuda:<i>'). "
+                           "Use the reference engine for CPU inference.")
+    return index
+
+
+def labels_to_strings(labels: np.ndarray, lens: np.ndarray, characters) -> List[str]:
+    return ["".join(characters[c] for c in labels[i, :lens[i]]) for i in range(labels.shape[0])]
+
+
+class PytorchEngineLineOCR(BaseEngineLineOCR):
+    def __init__(self, json_def, device, batch_size=8):
+        super().__init__(json_def, device, batch_size=batch_size)
+        self.net_subsampling = 4
+        self.characters = list(self.characters) + [BLANK_PLACEHOLDER]
+        if self.embed_id is not None:
+            raise NotImplementedError("style-embedding models (embed_id) are not supported by this engine")
+        self._load_exported_model()
+
+    # reference name kept (pytorch_ocr_engine.py:52)
+    def _load_exported_model(self):
+        net_cfg = dict(self.config.get("net", {}))
+        if os.path.exists(self.checkpoint):
+            spec, weights = netspec.load_blob(self.checkpoint)
+        elif "weight_seed" in net_cfg:
+            spec = netspec.NetSpec(num_classes=len(self.characters), height=int(self.line_px_height),
+                                   conv_out=int(net_cfg.get("conv_out", 512)),
+                                   lstm_hidden=int(net_cfg.get("lstm_hidden", 256)),
+                                   lstm_layers=int(net_cfg.get("lstm_layers", 2)),
+                                   arch=net_cfg.get("arch", netspec.ARCH))
+            weights = netspec.generate_weights(spec, int(net_cfg["weight_seed"]))
+        else:
+            raise FileNotFoundError(f"weight blob {self.checkpoint} not found and no net.weight_seed in the engine JSON")
+        if spec.num_classes != len(self.characters):
+            raise ValueError(f"model has {spec.num_classes} classes, engine JSON implies {len(self.characters)} "
+                             "(characters + blank)")
+        if spec.height != int(self.line_px_height):
+            raise ValueError(f"model height {spec.height} != line_px_height {self.line_px_height}")
+        self.net_spec = spec
+        self.model = _native.NativeEngine(spec, netspec.pack_weights(spec, weights), _device_index(self.device))
+
+    def run_ocr(self, batch_data) -> Tuple[List[str], np.ndarray]:
+        """uint8 [n, H, W_pad, 3] -> (decoded strings, float32 logits [n, T, C])."""
+        logits, _amax, labels, lens = self.model.run_batch(batch_data, want_logits=True, want_argmax=False)
+        return labels_to_strings(labels, lens, self.characters), logits
+
+    def _recognise_chunk(self, lines, chunk: Chunk, want_logits: bool):
+        """Ragged path: the crops go to the GPU un-padded; the zero padding of
+        line_ocr_engine.py:121-123 happens inside the first kernel's staging."""
+        flat = [np.ascontiguousarray(lines[i], dtype=np.uint8).reshape(-1) for i in chunk.line_ids]
+        widths = np.array([lines[i].shape[1] for i in chunk.line_ids], dtype=np.int32)
+        sizes = np.array([f.size for f in flat], dtype=np.int64)
+        offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        pool = np.concatenate(flat) if flat else np.zeros(0, np.uint8)
+        self.model.stage_lines(pool, offsets, widths, chunk.w_pad, self.line_padding_px)
+        logits, _amax, labels, lens = self.model.run_staged(want_logits=want_logits, want_argmax=False)
+        return labels_to_strings(labels, lens, self.characters), logits
+
+    def frame_argmax(self, batch_data) -> np.ndarray:
+        """Per-frame class ids [n, T] (what greedy_decode_ctc's torch.argmax sees)."""
+        _l, amax, _lab, _len = self.model.run_batch(batch_data, want_logits=False, want_argmax=True)
+        return amax

@@ -1,0 +1,218 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(libpocr_hip.so via pero_ocr_amd._native / the engine class); the oracle is only the checker.
+
+Bars (BASELINE.json north_star): decoded strings and per-frame argmax identical to the
+reference PyTorch-CPU path, logits within 1e-3 (fp32).
+"""
+import numpy as np
+import pytest
+
+from conftest import gpu_available
+from oracle import engine_oracle, model_oracle
+from pero_ocr_amd import _native, netspec, synth
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3        # the tolerance north_star states for fp32 logits
+
+
+class Dev:
+    type, index = "cuda", 0
+
+
+@pytest.fixture(scope="module")
+def small():
+    """A small engine + oracle pair shared by the layer-level tests."""
+    chars = synth.make_charset(99)
+    spec = netspec.NetSpec(num_classes=len(chars) + 1)
+    weights = netspec.generate_weights(spec, 20260928)
+    eng = _native.NativeEngine(spec, netspec.pack_weights(spec, weights), 0)
+    net = model_oracle.OracleNet(spec, weights)
+    return spec, weights, eng, net
+
+
+def _oracle_activations(net, batch_u8):
+    """Per-layer oracle outputs in the library's layouts (NHWC / [n,T,C])."""
+    import torch
+    outs = []
+    with torch.no_grad():
+        x = (torch.from_numpy(batch_u8).float() / 255.0).permute(0, 3, 1, 2)
+        mods = list(net.backbone)
+        i = 0
+        while i < len(mods):
+            x = mods[i](x)                      # conv
+            i += 1
+            while i < len(mods) and not isinstance(mods[i], torch.nn.Conv2d):
+                x = mods[i](x)                  # act / pool / bn
+                i += 1
+            outs.append(x.permute(0, 2, 3, 1).contiguous().numpy())
+        f = net.agg_act(net.agg(x)).squeeze(2)                  # [n,E,T]
+        outs.append(f.permute(0, 2, 1).contiguous().numpy())
+        inp = f.permute(0, 2, 1)
+        hh = net.spec.lstm_hidden
+        for l in range(net.spec.lstm_layers):
+            sub = torch.nn.LSTM(inp.shape[2], hh, num_layers=1, bidirectional=True, batch_first=True)
+            for sfx in ("", "_reverse"):
+                for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                    getattr(sub, f"{nm}_l0{sfx}").data = getattr(net.lstm, f"{nm}_l{l}{sfx}").data
+            inp, _ = sub(inp)
+            outs.append(inp.contiguous().numpy())
+        logits = net.head(inp)
+    return outs, logits.numpy()
+
+
+def test_layerwise_parity(small):
+    """Every stage of the network against the oracle, so a failure names the kernel."""
+    spec, weights, eng, net = small
+    crops = synth.make_crops(7, [96, 61, 128])
+    batch = engine_oracle.assemble_batch(crops, [0, 1, 2], spec.height, 128, 3840)      # W_pad 192
+    logits, amax, labels, lens = eng.run_batch(batch)
+    ref_acts, ref_logits = _oracle_activations(net, batch)
+    names = [f"conv{i}" for i in range(1, 10)] + ["agg"] + [f"lstm{l}" for l in range(spec.lstm_layers)]
+    for k, (name, ref) in enumerate(zip(names, ref_acts)):
+        got = eng.debug_read(k).reshape(ref.shape)
+        err = float(np.max(np.abs(got - ref)))
+        scale = float(np.max(np.abs(ref)))
+        assert err <= 2e-5 * max(1.0, scale), f"{name}: max err {err:.3e} (scale {scale:.2f})"
+    assert float(np.max(np.abs(logits - ref_logits))) < 1e-4
+    assert np.array_equal(amax, np.argmax(ref_logits, axis=2))
+
+
+def test_conv1_normalise_is_bit_exact(small):
+    """u8 -> f32 goes through the i/255.0f table, so conv1's INPUT is bit-identical to the
+    reference's `.float() / 255.0`; with an all-equal image conv1 must be bit-stable across pixels."""
+    spec, weights, eng, net = small
+    batch = np.full((1, spec.height, 64, 3), 173, dtype=np.uint8)
+    eng.run_batch(batch)
+    got = eng.debug_read(0).reshape(1, spec.height, 64, 64)
+    inner = got[0, 1:-1, 1:-1, :]
+    assert np.all(inner == inner[0, 0]), "interior pixels of a constant image must be identical"
+    ref_acts, _ = _oracle_activations(net, batch)
+    assert np.max(np.abs(got - ref_acts[0])) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["c1", "ragged"])
+def test_engine_matches_reference_golden(golden, tmp_path, name):
+    """PytorchEngineLineOCR.process_lines (ragged GPU path) vs the imported-reference fixtures."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    g = golden(name)
+    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=g.batch_size)
+    assert eng.characters == g.characters
+    crops = g.crops()
+    keep = [c.copy() for c in crops]
+    texts, logits, coords = eng.process_lines(crops, sparse_logits=False)
+    assert all(np.array_equal(a, b) for a, b in zip(crops, keep)), "crops must not be mutated"
+    assert texts == g.transcriptions
+    assert coords == g.logit_coords
+    worst = 0.0
+    for i in range(g.n):
+        li = np.asarray(logits[i])
+        assert li.dtype == np.float32 and list(li.shape) == g.arrays["shapes"][i].tolist()
+        assert np.array_equal(np.argmax(li, axis=1), g.argmax(i)), f"line {i}: per-frame argmax differs"
+        worst = max(worst, float(np.max(np.abs(li[g.sample_rows[i]] - g.arrays[f"rows_{i}"]))))
+        l2 = float(np.sqrt(np.sum(li.astype(np.float64) ** 2)))
+        assert abs(l2 - float(g.arrays[f"l2_{i}"][0])) < 1e-3 * max(1.0, l2)
+        if f"dense_{i}" in g.arrays:
+            worst = max(worst, float(np.max(np.abs(li - g.arrays[f"dense_{i}"]))))
+    assert worst < LOGIT_TOL, worst
+
+    # the other output modes of the contract
+    t2, l2s, c2 = eng.process_lines(crops)                                  # sparse (default)
+    assert t2 == texts and c2 == coords
+    for i in range(g.n):
+        assert l2s[i].format == "csc" and l2s[i].dtype == np.float32
+        assert abs(int(l2s[i].nnz) - g.nnz_sparse[i]) <= max(2, g.nnz_sparse[i] // 200)
+    t3, l3, c3 = eng.process_lines(crops, sparse_logits=False, tight_crop_logits=True)
+    assert t3 == texts and all(c == [None, None] for c in c3)
+    assert [list(np.asarray(x).shape) for x in l3] == g.tight_shapes
+    t4, l4, c4 = eng.process_lines(crops, no_logits=True)
+    assert t4 == texts and all(x is None for x in l4) and all(x is None for x in c4)
+
+
+def test_c2_full_batch_matches_reference_golden(golden, tmp_path):
+    """BASELINE config 2: 256 lines @40x512 in ONE chunk (batch_size 274), W_pad 576, T 144."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    g = golden("c2")
+    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=g.batch_size)
+    texts, logits, coords = eng.process_lines(g.crops(), sparse_logits=False)
+    assert texts == g.transcriptions
+    assert coords == g.logit_coords
+    bad, worst = [], 0.0
+    for i in range(g.n):
+        li = np.asarray(logits[i])
+        if not np.array_equal(np.argmax(li, axis=1), g.argmax(i)):
+            bad.append(i)
+        worst = max(worst, float(np.max(np.abs(li[g.sample_rows[i]] - g.arrays[f"rows_{i}"]))))
+    assert not bad, f"argmax differs on lines {bad} (reference min top-2 margin {g.min_top2_margin:.2e})"
+    assert worst < LOGIT_TOL, worst
+
+
+def test_run_ocr_padded_path_equals_ragged_path(golden, tmp_path):
+    """run_ocr(batch_data) (host-assembled padded batch) and the fused ragged staging must agree bit for bit."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    from pero_ocr_amd.ocr_engine import line_ocr_engine
+    g = golden("ragged")
+    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=g.batch_size)
+    crops = g.crops()
+    texts, logits, _ = eng.process_lines(crops, sparse_logits=False)
+    for chunk in line_ocr_engine.plan_chunks(g.widths, eng.max_input_horizontal_pixels):
+        t_pad, l_pad = line_ocr_engine.BaseEngineLineOCR._recognise_chunk(eng, crops, chunk, True)
+        for k, i in enumerate(chunk.line_ids):
+            assert t_pad[k] == texts[i]
+            assert np.array_equal(l_pad[k], np.asarray(logits[i]))
+
+
+def test_odd_and_tiny_widths_against_oracle(small):
+    """w_pad not a multiple of 4 (floor-mode pools), the minimum width, a batch of one."""
+    spec, weights, eng, net = small
+    for n, w_pad in ((1, 4), (2, 70), (1, 322), (3, 101)):
+        batch = synth.random_u8_batch(11 + w_pad, n, spec.height, w_pad)
+        logits, amax, labels, lens = eng.run_batch(batch)
+        ref = model_oracle.forward_logits(net, batch)               # [n,C,T]
+        assert logits.shape == (n, ref.shape[2], ref.shape[1])
+        assert float(np.max(np.abs(logits - ref.transpose(0, 2, 1)))) < LOGIT_TOL
+        ref_best, ref_labels = engine_oracle.greedy_ctc(ref)
+        margins = np.sort(ref, axis=1)
+        safe = (margins[:, -1] - margins[:, -2]) > 1e-3
+        assert np.array_equal(amax[safe], ref_best[safe])
+        if safe.all():
+            for i in range(n):
+                assert np.array_equal(labels[i, :lens[i]], ref_labels[i])
+
+
+def test_empty_line_inside_a_chunk(small):
+    """A zero-width crop that does not open a chunk is legal in the reference (all padding)."""
+    spec, weights, eng, net = small
+    crops = synth.make_crops(5, [64, 0, 40])
+    crops[1] = np.zeros((spec.height, 0, 3), np.uint8)
+    pool = np.concatenate([c.reshape(-1) for c in crops])
+    sizes = [c.size for c in crops]
+    eng.stage_lines(pool, np.array([0, sizes[0], sizes[0] + sizes[1]]), np.array([64, 0, 40]), 128, 32)
+    logits, amax, labels, lens = eng.run_staged()
+    batch = engine_oracle.assemble_batch(crops, [0, 1, 2], spec.height, 64, 3840)
+    ref = model_oracle.forward_logits(net, batch)
+    assert float(np.max(np.abs(logits - ref.transpose(0, 2, 1)))) < LOGIT_TOL
+    assert np.array_equal(amax, engine_oracle.greedy_ctc(ref)[0])
+
+
+def test_determinism_and_line_independence_at_full_size(golden):
+    """Size-independent properties at BASELINE's full batch: (1) two runs are bit-identical,
+    (2) permuting the lines of a chunk permutes the outputs bit-exactly (lines are independent
+    units - the property the multi-GPU sharding relies on), (3) labels == collapse(argmax)."""
+    g = golden("c2")
+    spec, weights = g.spec(), g.weights()
+    eng = _native.NativeEngine(spec, netspec.pack_weights(spec, weights), 0)
+    crops = g.crops()
+    batch = engine_oracle.assemble_batch(crops, list(range(g.n)), spec.height, 512, 480 * g.batch_size)
+    l1, a1, lab1, len1 = eng.run_batch(batch)
+    l2, a2, lab2, len2 = eng.run_batch(batch)
+    assert np.array_equal(l1, l2) and np.array_equal(a1, a2) and np.array_equal(lab1, lab2)
+    perm = np.random.RandomState(1).permutation(g.n)
+    l3, a3, lab3, len3 = eng.run_batch(batch[perm])
+    assert np.array_equal(l3, l1[perm]) and np.array_equal(a3, a1[perm]) and np.array_equal(len3, len1[perm])
+    blank = spec.num_classes - 1
+    for i in range(g.n):
+        prev = np.concatenate([[blank], a1[i, :-1]])
+        keep = (a1[i] != prev) & (a1[i] != blank)
+        assert np.array_equal(lab1[i, :len1[i]], a1[i][keep])
+        assert np.array_equal(a1[i], g.argmax(i))

@@ -1,0 +1,121 @@
+"""CPU tests of the product's host logic and of the C-ABI library surface
+(no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, gpu_available
+from oracle import engine_oracle
+from pero_ocr_amd import _native, netspec
+from pero_ocr_amd.ocr_engine import line_ocr_engine
+from pero_ocr_amd.ocr_engine.softmax import softmax
+
+
+def test_plan_chunks_matches_oracle_random():
+    rng = np.random.RandomState(3)
+    for trial in range(200):
+        n = rng.randint(1, 60)
+        widths = rng.randint(1, 2500, size=n).tolist()
+        if trial % 5 == 0:
+            widths = [widths[0]] * n                      # all ties
+        bs = int(rng.choice([1, 2, 8, 16, 32, 274]))
+        got = line_ocr_engine.plan_chunks(widths, 480 * bs)
+        ref = engine_oracle.chunk_plan(widths, 480 * bs)
+        assert [(c.line_ids, c.max_width) for c in got] == [(ids, mw) for ids, mw in ref]
+        for c in got:
+            assert c.w_pad == min(c.max_width + 64, 480 * bs)
+
+
+def test_plan_chunks_golden(golden):
+    for name in ("c1", "ragged", "c2"):
+        g = golden(name)
+        got = line_ocr_engine.plan_chunks(g.widths, 480 * g.batch_size)
+        assert [[c.line_ids, c.max_width] for c in got] == g.plan
+
+
+def test_zero_width_line_raises_like_reference():
+    # only when the empty line opens a chunk (the reference divides by ceil32(0), line_ocr_engine.py:81-87)
+    with pytest.raises(ZeroDivisionError):
+        line_ocr_engine.plan_chunks([0], 3840)
+    with pytest.raises(ZeroDivisionError):
+        engine_oracle.chunk_plan([0], 3840)
+    assert [c.line_ids for c in line_ocr_engine.plan_chunks([100, 0], 3840)] == [[0, 1]]
+
+
+def test_softmax_matches_oracle():
+    x = np.random.RandomState(0).randn(7, 13, 50).astype(np.float32) * 8
+    assert np.array_equal(softmax(x, axis=2), engine_oracle.softmax(x.reshape(-1, 50), axis=1).reshape(x.shape))
+    assert softmax(x[0, 0]).shape == (50,)
+
+
+def test_library_exports_every_header_symbol():
+    """include/pocr.h is the contract: every function it declares must be exported."""
+    hdr = open(os.path.join(REPO, "include", "pocr.h")).read()
+    declared = set(re.findall(r"\b(pocr_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
+    lib = ctypes.CDLL(_native.lib_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _native.load().pocr_abi_version() == _native.ABI_VERSION
+
+
+def test_weight_count_agrees_with_library():
+    lib = _native.load()
+    for spec in (netspec.NetSpec(num_classes=100), netspec.NetSpec(num_classes=232, height=48, conv_out=256,
+                                                                    lstm_hidden=128, lstm_layers=3)):
+        cfg = _native.PocrConfig(_native.ABI_VERSION, spec.height, spec.num_classes, spec.conv_out,
+                                 spec.lstm_hidden, spec.lstm_layers)
+        assert lib.pocr_num_weight_floats(ctypes.byref(cfg)) == netspec.num_weight_floats(spec)
+
+
+def test_create_rejects_bad_config_and_wrong_blob_size():
+    lib = _native.load()
+    h = ctypes.c_void_p()
+    w = np.zeros(10, np.float32)
+    bad = _native.PocrConfig(_native.ABI_VERSION, 41, 100, 512, 256, 2)
+    assert lib.pocr_create(ctypes.byref(bad), w.ctypes.data_as(_native._f32p), w.size, 0, ctypes.byref(h)) != 0
+    assert b"height" in lib.pocr_last_error()
+    ok = _native.PocrConfig(_native.ABI_VERSION, 40, 100, 512, 256, 2)
+    assert lib.pocr_create(ctypes.byref(ok), w.ctypes.data_as(_native._f32p), w.size, 0, ctypes.byref(h)) != 0
+    assert b"floats" in lib.pocr_last_error()
+    old = _native.PocrConfig(99, 40, 100, 512, 256, 2)
+    assert lib.pocr_create(ctypes.byref(old), w.ctypes.data_as(_native._f32p), w.size, 0, ctypes.byref(h)) != 0
+    assert b"ABI" in lib.pocr_last_error()
+
+
+@pytest.mark.skipif(gpu_available(), reason="checks the no-GPU failure mode")
+def test_no_silent_cpu_fallback(golden, tmp_path):
+    """Without a GPU the product path must fail loudly, never compute on the CPU."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    g = golden("c1")
+    path = g.write_engine_json(tmp_path)
+
+    class Dev:
+        type, index = "cuda", 0
+    with pytest.raises(RuntimeError, match="no HIP device|CPU fallback"):
+        PytorchEngineLineOCR(path, Dev())
+
+
+def test_cpu_device_is_refused(golden, tmp_path):
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    g = golden("c1")
+    path = g.write_engine_json(tmp_path)
+
+    class Cpu:
+        type, index = "cpu", None
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        PytorchEngineLineOCR(path, Cpu())
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under pero_ocr_amd/ may reference it."""
+    pkg = os.path.join(REPO, "pero_ocr_amd")
+    for root, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(root, f), encoding="utf8").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(root, f)
+                assert "/root/reference" not in src, os.path.join(root, f)

@@ -1,0 +1,79 @@
+"""Multi-process CPU tests (gloo, world_size 2) of the N>1 path: chunk assignment and the
+all-gather of decoded labels.  The per-chunk device call is replaced by a stand-in that
+derives labels from the crop bytes, so the sharding / gather logic is what is tested."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from pero_ocr_amd import sharding, synth
+from pero_ocr_amd.ocr_engine.line_ocr_engine import plan_chunks
+
+
+def test_assign_chunks_covers_everything_and_balances():
+    widths = synth.make_widths(9, 2048)
+    chunks = plan_chunks(widths, 480 * 8)
+    for world in (1, 2, 4, 8):
+        parts = sharding.assign_chunks(chunks, world)
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(len(chunks)))
+        cost = [sum(len(chunks[i].line_ids) * chunks[i].w_pad for i in p) for p in parts]
+        assert max(cost) <= 1.05 * (sum(cost) / world) + max(len(c.line_ids) * c.w_pad for c in chunks)
+    # chunks are never split or re-bucketed: the set of (ids, w_pad) is the reference plan
+    assert sum(len(c.line_ids) for c in chunks) == len(widths)
+
+
+def _fake_recognise(lines, chunk):
+    """Deterministic stand-in for the GPU call: label t of line i = crop byte hash."""
+    T = chunk.frames
+    labs = np.zeros((len(chunk.line_ids), T), np.int32)
+    lens = np.zeros(len(chunk.line_ids), np.int32)
+    for k, i in enumerate(chunk.line_ids):
+        w = lines[i].shape[1]
+        n = min(T, 1 + w // 16)
+        labs[k, :n] = (np.arange(n) * 7 + int(lines[i][5, :, 0].sum()) + chunk.w_pad) % 50
+        lens[k] = n
+    return labs, lens
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        widths = [300, 17, 641, 640, 300, 1, 1290, 96, 33, 512, 300, 3900, 1000, 64, 257, 2000] * 3
+        lines = synth.make_crops(4, widths)
+        chars = synth.make_charset(50)
+        eng = sharding.ShardedLineOCR(_fake_recognise, chars, 480 * 8)
+        texts = eng.process_lines(lines)
+        # a rank with no chunks at all (more ranks than chunks) must still take part
+        few = sharding.ShardedLineOCR(_fake_recognise, chars, 480 * 64).process_lines(lines[:3])
+        np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array(texts + few, dtype=object), allow_pickle=True)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_allgather_labels(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "r0.npy", allow_pickle=True).tolist()
+    r1 = np.load(tmp_path / "r1.npy", allow_pickle=True).tolist()
+    assert r0 == r1 and all(t is not None for t in r0)
+    # single-process expectation
+    widths = [300, 17, 641, 640, 300, 1, 1290, 96, 33, 512, 300, 3900, 1000, 64, 257, 2000] * 3
+    lines = synth.make_crops(4, widths)
+    chars = synth.make_charset(50)
+    expect = [None] * len(lines)
+    for ch in plan_chunks(widths, 480 * 8):
+        labs, lens = _fake_recognise(lines, ch)
+        for k, i in enumerate(ch.line_ids):
+            expect[i] = "".join(chars[c] for c in labs[k, :lens[k]])
+    assert r0[:len(lines)] == expect
