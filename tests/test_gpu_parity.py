@@ -73,7 +73,10 @@ def test_layerwise_parity(small):
         got = eng.debug_read(k).reshape(ref.shape)
         err = float(np.max(np.abs(got - ref)))
         scale = float(np.max(np.abs(ref)))
-        assert err <= 2e-5 * max(1.0, scale), f"{name}: max err {err:.3e} (scale {scale:.2f})"
+        # conv stages: fp32 re-association only.  LSTM stages: + expf/tanhf vs oneDNN's vectorised
+        # exp/tanh through 48 recurrent steps (outputs are in (-1, 1)).
+        tol = 2e-4 if name.startswith("lstm") else 2e-5 * max(1.0, scale)
+        assert err <= tol, f"{name}: max err {err:.3e} (scale {scale:.2f})"
     assert float(np.max(np.abs(logits - ref_logits))) < 1e-4
     assert np.array_equal(amax, np.argmax(ref_logits, axis=2))
 
