@@ -13,6 +13,9 @@
 // then thread (line, unit) applies the gate non-linearities.  h ping-pongs between two
 // HBM buffers (kernel boundary = the step barrier); W_hh is read from L2 in fragment order
 //   whh_frag[dir][unit_group][k/16][gate][lane][j] = W_hh[gate*H + 16*ug + (lane&15)][16*kg + 4*(lane>>4) + j].
+// The step is latency-bound (a chain of L2 round trips), so every global load of the step -
+// h fragments, W_hh fragments, the xproj gate pre-activations and c - is issued up front
+// (KPW = k-groups per wave is a template parameter so the loop unrolls).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_igemm.hpp"
@@ -31,31 +34,62 @@ struct LstmStepArgs {
 
 __device__ __forceinline__ float sigmoid_f32(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// KPW > 0: H == 64 * KPW, fully unrolled.  KPW == 0: generic H (multiple of 16).
+template <int KPW>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
     __shared__ float part[4 * 4 * 64 * 4];      // [wave][gate][lane][reg]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int ug = blockIdx.x, slice = blockIdx.y, dir = blockIdx.z;
-    const int H = a.H, KGT = H / 16;
+    const int H = KPW > 0 ? 64 * KPW : a.H, KGT = H / 16;
     const int t = dir == 0 ? a.step : a.T - 1 - a.step;
+
+    // epilogue operands first: they come from HBM (xproj is streamed, never cached)
+    const int u = tid & 15, i = tid >> 4;
+    const int line = slice * 16 + i;
+    const int unit = ug * 16 + u;
+    const size_t sidx = ((size_t)dir * a.npad + line) * H + unit;
+    float xg[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (line < a.n) {
+        const float *xp = a.xproj + ((size_t)line * a.T + t) * (8 * H) + (size_t)dir * 4 * H + unit;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xg[g] = xp[(size_t)g * H];
+        cprev = a.c[sidx];
+    }
 
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     const float *hrow = a.h_in + ((size_t)dir * a.npad + slice * 16 + li) * H;
     const f32x4 *wf = reinterpret_cast<const f32x4 *>(a.whh_frag) + ((size_t)(dir * KGT + ug) * KGT) * 4 * 64 + lane;
-    // this wave's share of K: 16-wide groups kg = wave, wave+4, ...
-    for (int kg = wave; kg < KGT; kg += 4) {
-        const f32x4 av = *reinterpret_cast<const f32x4 *>(hrow + kg * 16 + kq * 4);
-        f32x4 bv[4];
+    if constexpr (KPW > 0) {
+        f32x4 av[KPW], bv[KPW][4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bv[g] = wf[((size_t)kg * 4 + g) * 64];
+        for (int q = 0; q < KPW; ++q) {
+            const int kg = wave + 4 * q;
+            av[q] = *reinterpret_cast<const f32x4 *>(hrow + kg * 16 + kq * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int g = 0; g < 4; ++g) bv[q][g] = wf[((size_t)kg * 4 + g) * 64];
+        }
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[g][j], acc[g], 0, 0, 0);
+        for (int q = 0; q < KPW; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][j], bv[q][g][j], acc[g], 0, 0, 0);
+    } else {
+        for (int kg = wave; kg < KGT; kg += 4) {
+            const f32x4 av = *reinterpret_cast<const f32x4 *>(hrow + kg * 16 + kq * 4);
+            f32x4 bv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[g] = wf[((size_t)kg * 4 + g) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[g][j], acc[g], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -63,8 +97,6 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
     __syncthreads();
 
     // thread -> (line i, unit u); D layout: lane = (i/4)*16 + u, reg = i%4
-    const int u = tid & 15, i = tid >> 4;
-    const int line = slice * 16 + i;
     const int src = (((i >> 2) * 16 + u) * 4) + (i & 3);
     float gate[4];
 #pragma unroll
@@ -75,15 +107,12 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
         s += part[(3 * 4 + g) * 256 + src];
         gate[g] = s;
     }
-    const int unit = ug * 16 + u;
-    const size_t sidx = ((size_t)dir * a.npad + line) * H + unit;
     if (line < a.n) {
-        const float *xp = a.xproj + ((size_t)line * a.T + t) * (8 * H) + (size_t)dir * 4 * H + unit;
-        const float gi = sigmoid_f32(gate[0] + xp[0]);
-        const float gf = sigmoid_f32(gate[1] + xp[H]);
-        const float gg = tanhf(gate[2] + xp[2 * H]);
-        const float go = sigmoid_f32(gate[3] + xp[3 * H]);
-        const float cn = gf * a.c[sidx] + gi * gg;
+        const float gi = sigmoid_f32(gate[0] + xg[0]);
+        const float gf = sigmoid_f32(gate[1] + xg[1]);
+        const float gg = tanhf(gate[2] + xg[2]);
+        const float go = sigmoid_f32(gate[3] + xg[3]);
+        const float cn = gf * cprev + gi * gg;
         const float hn = go * tanhf(cn);
         a.c[sidx] = cn;
         a.h_out[sidx] = hn;

@@ -252,7 +252,14 @@ int run_network(pocr_engine *e) {
             la.h_out = e->hbuf.as<float>() + (size_t)((s + 1) & 1) * hsz;
             la.c = e->cbuf.as<float>(); la.y = e->lstm_y[l].as<float>();
             la.n = n; la.npad = npad; la.T = T; la.H = Hh; la.step = s;
-            hipLaunchKernelGGL(lstm_step_kernel, dim3(Hh / 16, npad / 16, 2), dim3(256), 0, st, la);
+            const dim3 grid(Hh / 16, npad / 16, 2);
+            switch (Hh) {
+                case 64: hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, st, la); break;
+                case 128: hipLaunchKernelGGL(lstm_step_kernel<2>, grid, dim3(256), 0, st, la); break;
+                case 256: hipLaunchKernelGGL(lstm_step_kernel<4>, grid, dim3(256), 0, st, la); break;
+                case 512: hipLaunchKernelGGL(lstm_step_kernel<8>, grid, dim3(256), 0, st, la); break;
+                default: hipLaunchKernelGGL(lstm_step_kernel<0>, grid, dim3(256), 0, st, la); break;
+            }
         }
         HIP_TRY(hipGetLastError());
         layer_in = e->lstm_y[l].as<float>();
