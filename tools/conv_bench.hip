@@ -32,6 +32,35 @@ struct Variant { const char *name; void (*fn)(ConvArgs, hipStream_t); int nt; };
                NS * NW * 16, NW * 64, a, st);                                                                      \
     }
 
+#define VARP(NAME, TH, MW, NS, NW, KC, PH, PW, ACT, BN, PIPE)                                                      \
+    static void NAME(ConvArgs a, hipStream_t st) {                                                                 \
+        launch(conv_igemm_kernel<3, 3, 1, 1, TH, MW, NS, NW, KC, PH, PW, ACT, BN, STAGE_F32_NHWC, PIPE>, TH,        \
+               16 * MW, NS * NW * 16, NW * 64, a, st);                                                             \
+    }
+VARP(h5_pipe1,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 1)
+VARP(h5_pipe1_nt128, 5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, 1)
+VARP(h10_pipe1,    10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, 1)
+VARP(h10_pipe1_th5, 5, 1, 4, 4, 16, 1, 1, ACT_RELU, false, 1)
+VARP(h20_pipe1,    4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, 1)
+VARP(p22_pipe1,    4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, 1)
+VARP(p22_pipe1_nt64, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, 1)
+VARP(h5_pipe2,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 2)
+VARP(h10_pipe2,    10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, 2)
+VARP(p22_pipe2,    4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, 2)
+VARP(p22_pipe2_nt64, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, 2)
+VARP(h5_abl1,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 9)
+VARP(h5_abl2,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 10)
+VARP(h5_abl3,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 11)
+VARP(h5_abl4,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 12)
+VARP(h5_abl5,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 13)
+VARP(h5_abl16,    5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 24)
+VARP(h5_abl32,    5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 40)
+VARP(h5_abl7,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 15)
+VARP(h5_pipe3,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 3)
+VARP(h10_pipe3,    10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, 3)
+VARP(h20_pipe3,    4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, 3)
+VARP(p22_pipe3,    4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, 3)
+VARP(p22_pipe3_nt64, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, 3)
 // conv8/9-shaped (H=5): pool none
 VAR(h5_base,      5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true)
 VAR(h5_kc32_nt128,5, 1, 2, 4, 32, 1, 1, ACT_LEAKY, true)
@@ -66,19 +95,31 @@ int main(int argc, char **argv) {
                         {256, 256, 10, wpad / 4, 1, 1, ACT_RELU, false}, {256, 256, 10, wpad / 4, 2, 1, ACT_RELU, false},
                         {256, 512, 5, wpad / 4, 1, 1, ACT_LEAKY, false}, {512, 512, 5, wpad / 4, 1, 1, ACT_LEAKY, true}};
     Shape s = shapes[layer];
+    if (argc > 4) s.cin = atoi(argv[4]);     // experiment: longer K loop per workgroup
     std::vector<Variant> vars;
     if (layer >= 8) vars = {{"TH5 MW1 NS4 NW4 KC16 (base)", h5_base, 256}, {"TH5 MW1 NS2 NW4 KC32 NT128", h5_kc32_nt128, 128},
                             {"TH5 MW1 NS2 NW8 KC16", h5_nw8, 256}, {"TH5 MW1 NS2 NW8 KC32", h5_nw8_kc32, 256},
                             {"TH5 MW1 NS2 NW4 KC16 NT128", h5_nt128, 128}, {"TH5 MW2 NS2 NW4 KC16 NT128", h5_mw2_nt128, 128},
-                            {"TH5 MW1 NS4 NW4 KC32", h5_kc32, 256}};
+                            {"TH5 MW1 NS4 NW4 KC32", h5_kc32, 256},
+                            {"PIPE1 TH5 MW1 NS4 NW4 KC16", h5_pipe1, 256}, {"PIPE1 TH5 MW1 NS2 NW4 NT128", h5_pipe1_nt128, 128},
+                            {"PIPE2 TH5 MW1 NS4 NW4", h5_pipe2, 256}, {"PIPE3 TH5 MW1 NS4 NW4", h5_pipe3, 256},
+                            {"ABL no-loads/stores", h5_abl1, 256}, {"ABL no-barrier", h5_abl2, 256}, {"ABL no-loads no-barrier", h5_abl3, 256},
+                            {"ABL no-ds_read", h5_abl4, 256}, {"ABL no-loads no-ds_read", h5_abl5, 256}, {"ABL mfma only", h5_abl7, 256},
+                            {"ABL stores-no-loads", h5_abl16, 256}, {"ABL loads-no-stores", h5_abl32, 256}};
     else if (layer == 5 || layer == 6) vars = {{"TH10 MW1 NS2 NW4 KC16 (base)", h10_base, 128}, {"TH5 MW1 NS4 NW4 KC16", h10_th5_ns4, 256},
                             {"TH10 MW1 NS1 NW8 KC16", h10_nw8, 128}, {"TH10 MW1 NS2 NW4 KC32", h10_kc32, 128},
-                            {"TH5 MW2 NS2 NW4 KC16", h10_th5_mw2, 128}};
+                            {"TH5 MW2 NS2 NW4 KC16", h10_th5_mw2, 128},
+                            {"PIPE1 TH10 MW1 NS2 NW4", h10_pipe1, 128}, {"PIPE1 TH5 MW1 NS4 NW4", h10_pipe1_th5, 256},
+                            {"PIPE2 TH10 MW1 NS2 NW4", h10_pipe2, 128}, {"PIPE3 TH10 MW1 NS2 NW4", h10_pipe3, 128}};
     else if (layer == 3) vars = {{"TH4 MW2 NS2 NW4 KC16 (base)", h20_base, 128}, {"TH10 MW1 NS2 NW4", h20_th10, 128},
-                            {"TH5 MW1 NS4 NW4 (NT256: cout pad)", h20_th5_ns4, 256}, {"TH4 MW4 NS1 NW4 NT64", h20_th4mw4ns1, 64}};
+                            {"TH5 MW1 NS4 NW4 (NT256: cout pad)", h20_th5_ns4, 256}, {"TH4 MW4 NS1 NW4 NT64", h20_th4mw4ns1, 64},
+                            {"PIPE1 TH4 MW2 NS2 NW4", h20_pipe1, 128}, {"PIPE3 TH4 MW2 NS2 NW4", h20_pipe3, 128}};
     else if (layer == 2 || layer == 4) vars = {{"TH4 MW2 NS2 NW4 KC16 NT128", p22_base, 128}, {"TH10 MW1 NS2 NW4", p22_th10, 128},
                             {"TH4 MW4 NS1 NW4 NT64", p22_th4mw4, 64}, {"TH2 MW4 NS2 NW4 NT128", p22_th2mw4ns2, 128},
-                            {"TH4 MW2 NS2 NW4 KC32", p22_kc32, 128}};
+                            {"TH4 MW2 NS2 NW4 KC32", p22_kc32, 128},
+                            {"PIPE1 TH4 MW2 NS2 NW4 NT128", p22_pipe1, 128}, {"PIPE1 TH4 MW4 NS1 NW4 NT64", p22_pipe1_nt64, 64},
+                            {"PIPE2 TH4 MW2 NS2 NW4 NT128", p22_pipe2, 128}, {"PIPE2 TH4 MW4 NS1 NW4 NT64", p22_pipe2_nt64, 64},
+                            {"PIPE3 TH4 MW2 NS2 NW4 NT128", p22_pipe3, 128}, {"PIPE3 TH4 MW4 NS1 NW4 NT64", p22_pipe3_nt64, 64}};
     else { printf("layer %d not covered\n", layer); return 1; }
 
     const size_t xin = (size_t)n * s.H * s.W * s.cin;
