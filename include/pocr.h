@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define POCR_ABI_VERSION 1
+#define POCR_ABI_VERSION 2
 
 typedef struct pocr_engine pocr_engine;
 
@@ -35,9 +35,17 @@ typedef struct pocr_config {
     int32_t height;        /* line_px_height, multiple of 8 (line_ocr_engine.py:22) */
     int32_t num_classes;   /* C, blank = C-1 (pytorch_ocr_engine.py:12) */
     int32_t conv_out;      /* E: aggregation conv output channels, multiple of 16 */
-    int32_t lstm_hidden;   /* multiple of 16 */
-    int32_t lstm_layers;   /* >= 1 */
+    int32_t lstm_hidden;   /* multiple of 16 (POCR_ARCH_BLSTM) */
+    int32_t lstm_layers;   /* >= 1          (POCR_ARCH_BLSTM) */
+    int32_t arch;          /* POCR_ARCH_BLSTM or POCR_ARCH_SA */
+    int32_t sa_layers;     /* POCR_ARCH_SA: encoder layers      (transformer.py:366-376, JSON encoder_layers) */
+    int32_t sa_heads;      /* POCR_ARCH_SA: heads, conv_out/heads in {32, 64, 128} */
+    int32_t sa_ff;         /* POCR_ARCH_SA: feed-forward width, multiple of 16 */
 } pocr_config;
+
+/* Sequence model after the conv backbone: BiLSTM stack, or the self-attention encoder
+ * (LineSelfAttentionEncoder, pero_ocr/ocr_engine/transformer.py:366-385 = BASELINE config 4). */
+enum { POCR_ARCH_BLSTM = 0, POCR_ARCH_SA = 1 };
 
 /* Number of float32 values pocr_create() expects (tensor order = netspec.tensor_table). */
 size_t pocr_num_weight_floats(const pocr_config *cfg);
@@ -89,7 +97,7 @@ enum {
     POCR_STAGE_CONV2, POCR_STAGE_CONV3, POCR_STAGE_CONV4, POCR_STAGE_CONV5,
     POCR_STAGE_CONV6, POCR_STAGE_CONV7, POCR_STAGE_CONV8, POCR_STAGE_CONV9,
     POCR_STAGE_AGG,         /* aggregation conv */
-    POCR_STAGE_LSTM,        /* all BiLSTM layers: input projections + recurrence */
+    POCR_STAGE_LSTM,        /* sequence model: BiLSTM layers (projections + recurrence) or the self-attention encoder */
     POCR_STAGE_HEAD,        /* projection to C classes */
     POCR_STAGE_CTC,         /* argmax + collapse */
     POCR_STAGE_TOTAL,       /* first kernel start -> last kernel end */
@@ -101,7 +109,9 @@ int pocr_set_profiling(pocr_engine *e, int32_t enabled);
 
 /* Copy an intermediate activation of the last run to the host (tests only).
  * what: 0..8 = output of conv1..conv9 (NHWC, after activation/pool/BN),
- *       9 = aggregation features [n, T, E], 10+l = BiLSTM layer l output [n, T, 2*hidden].
+ *       9 = aggregation features [n, T, E];
+ *       BLSTM: 10+l = BiLSTM layer l output [n, T, 2*hidden];
+ *       SA:    10 = LayerNorm + positional encoding [n, T, E], 11+l = encoder layer l output [n, T, E].
  * Writes min(cap, size) floats, stores the full size in *n_floats. */
 int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t *n_floats);
 

@@ -81,6 +81,17 @@ def build_reference_model(transformer, spec: netspec.NetSpec, weights):
     with contextlib.redirect_stdout(io.StringIO()):
         enc = transformer.ConvolutionalEncoder(in_height=spec.height, in_channels=3,
                                                out_channels=spec.conv_out, conv_subsampling=(8, 4))
+    fill_conv(enc, weights)
+    lstm = nn.LSTM(spec.conv_out, spec.lstm_hidden, num_layers=spec.lstm_layers,
+                   bidirectional=True, batch_first=True)
+    model_oracle.load_lstm_weights(lstm, spec, weights)
+    head = nn.Linear(2 * spec.lstm_hidden, spec.num_classes)
+    head.weight.data = torch.from_numpy(weights["head.weight"].copy())
+    head.bias.data = torch.from_numpy(weights["head.bias"].copy())
+    return RefTopologyNet(enc.blocks_2d, enc.aggregation_conv, lstm, head).eval()
+
+
+def fill_conv(enc, weights):
     convs = [m for m in enc.blocks_2d.modules() if isinstance(m, nn.Conv2d)]
     bns = [m for m in enc.blocks_2d.modules() if isinstance(m, nn.BatchNorm2d)]
     assert len(convs) == 9 and len(bns) == 1, (len(convs), len(bns))
@@ -96,13 +107,46 @@ def build_reference_model(transformer, spec: netspec.NetSpec, weights):
     agg = enc.aggregation_conv
     agg[0].weight.data = torch.from_numpy(weights["agg.weight"].copy())
     agg[0].bias.data = torch.from_numpy(weights["agg.bias"].copy())
-    lstm = nn.LSTM(spec.conv_out, spec.lstm_hidden, num_layers=spec.lstm_layers,
-                   bidirectional=True, batch_first=True)
-    model_oracle.load_lstm_weights(lstm, spec, weights)
-    head = nn.Linear(2 * spec.lstm_hidden, spec.num_classes)
-    head.weight.data = torch.from_numpy(weights["head.weight"].copy())
-    head.bias.data = torch.from_numpy(weights["head.bias"].copy())
-    return RefTopologyNet(enc.blocks_2d, agg, lstm, head).eval()
+
+
+class RefTopologyNetSA(nn.Module):
+    """conv part + self-attention encoder = the reference's module instances
+    (ConvolutionalEncoder, LineSelfAttentionEncoder transformer.py:366-385); head = torch.nn.Linear."""
+
+    def __init__(self, blocks_2d, aggregation_conv, encoder, head):
+        super().__init__()
+        self.blocks_2d = blocks_2d
+        self.aggregation_conv = aggregation_conv
+        self.encoder = encoder
+        self.head = head
+
+    def forward(self, x):
+        f = self.aggregation_conv(self.blocks_2d(x)).squeeze(2)   # [N,E,T]
+        enc = self.encoder(f)                                      # [T,N,E]
+        return self.head(enc).permute(1, 2, 0)                     # [N,C,T]
+
+
+def build_reference_model_sa(transformer, spec: netspec.NetSpec, weights):
+    with contextlib.redirect_stdout(io.StringIO()):
+        enc = transformer.ConvolutionalEncoder(in_height=spec.height, in_channels=3,
+                                               out_channels=spec.conv_out, conv_subsampling=(8, 4))
+    fill_conv(enc, weights)
+    sa = transformer.LineSelfAttentionEncoder(dropout=0.0, max_seq_len=1000, dim_model=spec.conv_out,
+                                              dim_ff=spec.sa_ff, nb_heads=spec.sa_heads, nb_layers=spec.sa_layers)
+    t = lambda k: torch.from_numpy(weights[k].copy())
+    sa.input_norm.weight.data, sa.input_norm.bias.data = t("sa.norm.weight"), t("sa.norm.bias")
+    for l, layer in enumerate(sa.trans_encoder.layers):
+        layer.self_attn.in_proj_weight.data = t(f"sa{l}.in_proj.weight")
+        layer.self_attn.in_proj_bias.data = t(f"sa{l}.in_proj.bias")
+        layer.self_attn.out_proj.weight.data = t(f"sa{l}.out_proj.weight")
+        layer.self_attn.out_proj.bias.data = t(f"sa{l}.out_proj.bias")
+        layer.linear1.weight.data, layer.linear1.bias.data = t(f"sa{l}.lin1.weight"), t(f"sa{l}.lin1.bias")
+        layer.linear2.weight.data, layer.linear2.bias.data = t(f"sa{l}.lin2.weight"), t(f"sa{l}.lin2.bias")
+        layer.norm1.weight.data, layer.norm1.bias.data = t(f"sa{l}.norm1.weight"), t(f"sa{l}.norm1.bias")
+        layer.norm2.weight.data, layer.norm2.bias.data = t(f"sa{l}.norm2.weight"), t(f"sa{l}.norm2.bias")
+    head = nn.Linear(spec.conv_out, spec.num_classes)
+    head.weight.data, head.bias.data = t("head.weight"), t("head.bias")
+    return RefTopologyNetSA(enc.blocks_2d, enc.aggregation_conv, sa, head).eval()
 
 
 CONFIGS = {
@@ -116,6 +160,13 @@ CONFIGS = {
     # BASELINE.json configs[1]: 256 x 40x512 in ONE chunk (batch_size 274 -> 480*274//512 = 256), W_pad 576, T 144
     "c2": dict(n_symbols=231, weight_seed=20260929, crop_seed=305, widths=[512] * 256, batch_size=274,
                store_dense=False),
+    # self-attention encoder variant (BASELINE.json configs[3] topology) on ragged widths
+    "sa_ragged": dict(n_symbols=99, weight_seed=20260930, crop_seed=401, arch="vgg_sa_ctc",
+                      widths=[300, 17, 641, 640, 300, 1, 1290, 96, 33, 512, 300, 1000, 64, 257], batch_size=8,
+                      store_dense=False),
+    # BASELINE.json configs[3]: 256 x 40x768 in ONE chunk (batch_size 410 -> 480*410//768 = 256), W_pad 832, T 208
+    "c4": dict(n_symbols=231, weight_seed=20260931, crop_seed=501, arch="vgg_sa_ctc", widths=[768] * 256,
+               batch_size=410, store_dense=False),
 }
 
 
@@ -123,14 +174,14 @@ def run_config(name: str, out_dir: str):
     cfg = CONFIGS[name]
     engine_mod, transformer = import_reference()
     chars = synth.make_charset(cfg["n_symbols"])
-    spec = netspec.NetSpec(num_classes=len(chars) + 1)
+    spec = netspec.NetSpec(num_classes=len(chars) + 1, arch=cfg.get("arch", netspec.ARCH))
     weights = netspec.generate_weights(spec, cfg["weight_seed"])
     crops = synth.make_crops(cfg["crop_seed"], cfg["widths"], spec.height)
 
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
     assert torch.get_float32_matmul_precision() == "highest"
-    model = build_reference_model(transformer, spec, weights)
+    model = (build_reference_model_sa if spec.arch == netspec.ARCH_SA else build_reference_model)(transformer, spec, weights)
 
     with tempfile.TemporaryDirectory() as td:
         scripted = torch.jit.script(model)
@@ -160,7 +211,7 @@ def run_config(name: str, out_dir: str):
     assert o_c == c_dense
     max_diff = max(float(np.max(np.abs(a - np.asarray(b)))) for a, b in zip(o_l, l_dense))
     print(f"[{name}] oracle-vs-reference max |dlogit| = {max_diff:.3e}")
-    assert max_diff < 1e-4
+    assert max_diff < (5e-4 if spec.arch == netspec.ARCH_SA else 1e-4)   # nn.TransformerEncoder's fused fast path re-associates
 
     n = len(crops)
     dense = [np.ascontiguousarray(np.asarray(x), dtype=np.float32) for x in l_dense]
@@ -194,6 +245,8 @@ def run_config(name: str, out_dir: str):
         arrays[f"argmax_{i}"] = argmax[i]
         arrays[f"rows_{i}"] = dense[i][sample_rows[i]]
         arrays[f"l2_{i}"] = np.array([np.sqrt(np.sum(dense[i].astype(np.float64) ** 2))])
+        srt = np.sort(dense[i], axis=1)
+        arrays[f"margin_{i}"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)     # reference top-2 margin per frame
     if cfg["store_dense"]:
         for i in range(n):
             arrays[f"dense_{i}"] = dense[i]

@@ -28,7 +28,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from pero_ocr_amd.netspec import BN_EPS, CONV_PLAN, LEAKY_SLOPE, NetSpec
+from pero_ocr_amd.netspec import ARCH_SA, BN_EPS, CONV_PLAN, LEAKY_SLOPE, LN_EPS, NetSpec
 
 
 class OracleNet(nn.Module):
@@ -56,10 +56,15 @@ class OracleNet(nn.Module):
         self.agg.weight.data = torch.from_numpy(weights["agg.weight"].copy())
         self.agg.bias.data = torch.from_numpy(weights["agg.bias"].copy())
         self.agg_act = nn.LeakyReLU(LEAKY_SLOPE)
-        self.lstm = nn.LSTM(spec.conv_out, spec.lstm_hidden, num_layers=spec.lstm_layers,
-                            bidirectional=True, batch_first=True)
-        load_lstm_weights(self.lstm, spec, weights)
-        self.head = nn.Linear(2 * spec.lstm_hidden, spec.num_classes)
+        self.sa = None
+        if spec.arch == ARCH_SA:
+            self.sa = {k: torch.from_numpy(v.copy()) for k, v in weights.items() if k.startswith("sa")}
+            self.head = nn.Linear(spec.conv_out, spec.num_classes)
+        else:
+            self.lstm = nn.LSTM(spec.conv_out, spec.lstm_hidden, num_layers=spec.lstm_layers,
+                                bidirectional=True, batch_first=True)
+            load_lstm_weights(self.lstm, spec, weights)
+            self.head = nn.Linear(2 * spec.lstm_hidden, spec.num_classes)
         self.head.weight.data = torch.from_numpy(weights["head.weight"].copy())
         self.head.bias.data = torch.from_numpy(weights["head.bias"].copy())
         self.eval()
@@ -69,8 +74,43 @@ class OracleNet(nn.Module):
         f = self.agg_act(self.agg(self.backbone(x)))
         return f.squeeze(2)
 
+    def encoder_stages(self, f: torch.Tensor):
+        """Self-attention encoder restated from the documented equations of
+        LineSelfAttentionEncoder (pero_ocr/ocr_engine/transformer.py:366-385): LayerNorm(E, 1e-5),
+        + sinusoidal PE (:316-332), then post-norm nn.TransformerEncoderLayer blocks (ReLU FFN,
+        dropout 0, no mask): x = LN1(x + MHA(x)); x = LN2(x + W2 relu(W1 x)).  f: [N,E,T].
+        Returns the list [after input norm+PE, after layer 0, ...] as [N,T,E] tensors."""
+        import math
+        import torch.nn.functional as F
+        sp, w = self.spec, self.sa
+        e, h = sp.conv_out, sp.sa_heads
+        d = e // h
+        x = f.permute(0, 2, 1)                                        # [N,T,E]; lines are independent
+        n, t, _ = x.shape
+        position = torch.arange(0, t, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, e, 2).float() * (-math.log(10000.0) / e))
+        pe = torch.zeros(t, e)
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        x = F.layer_norm(x, (e,), w["sa.norm.weight"], w["sa.norm.bias"], LN_EPS) + pe
+        outs = [x]
+        for l in range(sp.sa_layers):
+            g = lambda k: w[f"sa{l}.{k}"]
+            qkv = F.linear(x, g("in_proj.weight"), g("in_proj.bias")).view(n, t, 3, h, d)
+            q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))           # [N,h,T,d]
+            att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1) @ v   # [N,h,T,d]
+            att = att.permute(0, 2, 1, 3).reshape(n, t, e)
+            x = F.layer_norm(x + F.linear(att, g("out_proj.weight"), g("out_proj.bias")), (e,),
+                             g("norm1.weight"), g("norm1.bias"), LN_EPS)
+            ff = F.linear(F.relu(F.linear(x, g("lin1.weight"), g("lin1.bias"))), g("lin2.weight"), g("lin2.bias"))
+            x = F.layer_norm(x + ff, (e,), g("norm2.weight"), g("norm2.bias"), LN_EPS)
+            outs.append(x)
+        return outs
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         f = self.features(x)
+        if self.sa is not None:
+            return self.head(self.encoder_stages(f)[-1]).permute(0, 2, 1)
         y, _ = self.lstm(f.permute(0, 2, 1))
         return self.head(y).permute(0, 2, 1)
 

@@ -14,7 +14,7 @@ import numpy as np
 from .netspec import NetSpec
 
 LIB_NAME = "libpocr_hip.so"
-ABI_VERSION = 1
+ABI_VERSION = 2
 STAGE_NAMES = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv8", "conv9",
                "agg", "lstm", "head", "ctc", "total")
 
@@ -23,7 +23,16 @@ _lib: Optional[C.CDLL] = None
 
 class PocrConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("height", C.c_int32), ("num_classes", C.c_int32),
-                ("conv_out", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_layers", C.c_int32)]
+                ("conv_out", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_layers", C.c_int32),
+                ("arch", C.c_int32), ("sa_layers", C.c_int32), ("sa_heads", C.c_int32), ("sa_ff", C.c_int32)]
+
+
+ARCH_IDS = {"vgg_blstm_ctc": 0, "vgg_sa_ctc": 1}
+
+
+def make_config(spec: NetSpec) -> "PocrConfig":
+    return PocrConfig(ABI_VERSION, spec.height, spec.num_classes, spec.conv_out, spec.lstm_hidden,
+                      spec.lstm_layers, ARCH_IDS[spec.arch], spec.sa_layers, spec.sa_heads, spec.sa_ff)
 
 
 # every symbol include/pocr.h declares: name -> (restype, argtypes)
@@ -77,8 +86,7 @@ class NativeEngine:
         self._lib = load()
         self._h = C.c_void_p()
         self.spec = spec
-        cfg = PocrConfig(ABI_VERSION, spec.height, spec.num_classes, spec.conv_out, spec.lstm_hidden,
-                         spec.lstm_layers)
+        cfg = make_config(spec)
         w = np.ascontiguousarray(flat_weights, dtype=np.float32)
         rc = self._lib.pocr_create(C.byref(cfg), _ptr(w, _f32p), w.size, int(device_id), C.byref(self._h))
         if rc:

@@ -13,6 +13,7 @@
 #include "../../include/pocr.h"
 #include "conv_igemm.hpp"
 #include "ctc.hpp"
+#include "encoder.hpp"
 #include "lstm.hpp"
 
 using namespace pocr;
@@ -114,6 +115,7 @@ POCR_CONV(agg6_k,    6, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F
 POCR_CONV(agg8_k,    8, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, 0)
 POCR_CONV(gemm128_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC, 3)   // rows x 128 cols per WG
 POCR_CONV(gemm64_k,  1, 1, 0, 0, 1, 8, 1, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC, 3)   // rows x 64 cols per WG
+POCR_CONV(gemm128_relu_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, 3)   // FFN first linear
 const int kConvNT[9] = {64, 64, 128, 128, 128, 128, 128, 256, 256};
 const int kAggNT = 256, kProjNT = 128, kHeadNT = 64;
 
@@ -128,6 +130,13 @@ struct pocr_engine {
     // weights (device)
     DevBuf conv_w[9], conv_b[9], bn_scale, bn_shift, agg_w, agg_b, head_w, head_b, lut;
     std::vector<DevBuf> proj_w, proj_b, whh;       // per LSTM layer
+    // self-attention encoder (POCR_ARCH_SA): per layer in_proj, out_proj, lin1, lin2 (fragment order) + LN params
+    struct SaLayer { DevBuf w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b; };
+    std::vector<SaLayer> sa;
+    DevBuf sa_nw, sa_nb, pe;
+    int pe_rows = 0;
+    DevBuf sa_x, sa_x1, sa_qkv, sa_att, sa_tmp, sa_ff;
+    std::vector<DevBuf> sa_y;
     int conv_cout16[9]{};
     int agg_cout16 = 0, head_cout16 = 0, proj_cout16 = 0;
     // staged chunk
@@ -165,8 +174,19 @@ int check_cfg(const pocr_config *c) {
     if (ah != 4 && ah != 5 && ah != 6 && ah != 8) return fail("unsupported height %d (aggregation height %d; built for 32/40/48/64)", c->height, ah);
     if (c->num_classes < 2) return fail("num_classes must be >= 2");
     if (c->conv_out <= 0 || c->conv_out % 16) return fail("conv_out must be a positive multiple of 16");
-    if (c->lstm_hidden <= 0 || c->lstm_hidden % 16) return fail("lstm_hidden must be a positive multiple of 16");
-    if (c->lstm_layers < 1) return fail("lstm_layers must be >= 1");
+    if (c->arch == POCR_ARCH_SA) {
+        if (c->sa_layers < 1) return fail("sa_layers must be >= 1");
+        if (c->sa_heads < 1 || c->conv_out % c->sa_heads) return fail("conv_out must be divisible by sa_heads");
+        const int d = c->conv_out / c->sa_heads;
+        if (d != 32 && d != 64 && d != 128) return fail("head dim conv_out/sa_heads must be 32, 64 or 128 (got %d)", d);
+        if (c->sa_ff <= 0 || c->sa_ff % 16) return fail("sa_ff must be a positive multiple of 16");
+        if (c->conv_out > 1024) return fail("conv_out must be <= 1024 for the self-attention encoder");
+    } else if (c->arch == POCR_ARCH_BLSTM) {
+        if (c->lstm_hidden <= 0 || c->lstm_hidden % 16) return fail("lstm_hidden must be a positive multiple of 16");
+        if (c->lstm_layers < 1) return fail("lstm_layers must be >= 1");
+    } else {
+        return fail("unknown arch id %d", c->arch);
+    }
     return 0;
 }
 
@@ -228,14 +248,66 @@ int run_network(pocr_engine *e) {
         int rc = AH == 4 ? agg4_k(a, st) : AH == 5 ? agg5_k(a, st) : AH == 6 ? agg6_k(a, st) : agg8_k(a, st);
         if (rc) return rc;
     }
+    const float *layer_in = e->feat.as<float>();
+    int din = E;
+    mark(POCR_STAGE_LSTM);
+    if (c.arch == POCR_ARCH_SA) {
+    // ---- self-attention encoder (transformer.py:366-385)
+    const int rows = n * T, FF = c.sa_ff, heads = c.sa_heads, D = E / heads;
+    const size_t xe = (size_t)rows * E * sizeof(float);
+    if (e->sa_x.reserve(xe) || e->sa_x1.reserve(xe) || e->sa_att.reserve(xe) || e->sa_tmp.reserve(xe)) return 1;
+    if (e->sa_qkv.reserve(3 * xe) || e->sa_ff.reserve((size_t)rows * FF * sizeof(float))) return 1;
+    if (T > e->pe_rows) {      // sinusoidal table, float32 like PositionalEncoding (transformer.py:316-332)
+        const int rows_pe = round_up(T, 256);
+        std::vector<float> pe((size_t)rows_pe * E);
+        for (int k = 0; k < E; k += 2) {
+            const float div = expf((float)k * (-logf(10000.0f) / (float)E));
+            for (int t = 0; t < rows_pe; ++t) {
+                pe[(size_t)t * E + k] = sinf((float)t * div);
+                if (k + 1 < E) pe[(size_t)t * E + k + 1] = cosf((float)t * div);
+            }
+        }
+        if (upload(e->pe, pe, st)) return 1;
+        e->pe_rows = rows_pe;
+    }
+    auto ln = [&](const float *a_, const float *b_, const DevBuf &gw, const DevBuf &gb, const float *pe_, float *y_) {
+        hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a_, b_, gw.as<float>(), gb.as<float>(),
+                           pe_, y_, rows, E, T, 1e-5f);
+    };
+    auto gemm = [&](const float *x_, int cin_, const DevBuf &w_, const DevBuf &b_, int cout_, float *y_, bool relu) {
+        ConvArgs g{};
+        g.x = x_; g.n = 1; g.H = 1; g.W = rows; g.Ho = 1; g.Wo = rows; g.cin = cin_;
+        g.cout16 = round_up(cout_, kProjNT) / 16; g.cout_valid = cout_; g.out_stride = cout_;
+        g.wfrag = w_.as<float>(); g.bias = b_.as<float>(); g.y = y_;
+        return relu ? gemm128_relu_k(g, st) : gemm128_k(g, st);
+    };
+    ln(e->feat.as<float>(), nullptr, e->sa_nw, e->sa_nb, e->pe.as<float>(), e->sa_x.as<float>());
+    for (int l = 0; l < c.sa_layers; ++l) {
+        pocr_engine::SaLayer &L = e->sa[l];
+        if (e->sa_y[l].reserve(xe)) return 1;
+        if (gemm(e->sa_x.as<float>(), E, L.w_in, L.b_in, 3 * E, e->sa_qkv.as<float>(), false)) return 1;
+        const dim3 agrid((T + 15) / 16, heads, n);
+        const float scale = 1.0f / sqrtf((float)D);
+        if (D == 32) hipLaunchKernelGGL(attention_kernel<32>, agrid, dim3(64), 0, st, e->sa_qkv.as<float>(), e->sa_att.as<float>(), T, E, scale);
+        else if (D == 64) hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(64), 0, st, e->sa_qkv.as<float>(), e->sa_att.as<float>(), T, E, scale);
+        else hipLaunchKernelGGL(attention_kernel<128>, agrid, dim3(64), 0, st, e->sa_qkv.as<float>(), e->sa_att.as<float>(), T, E, scale);
+        if (gemm(e->sa_att.as<float>(), E, L.w_out, L.b_out, E, e->sa_tmp.as<float>(), false)) return 1;
+        ln(e->sa_x.as<float>(), e->sa_tmp.as<float>(), L.n1w, L.n1b, nullptr, e->sa_x1.as<float>());
+        if (gemm(e->sa_x1.as<float>(), E, L.w1, L.b1, FF, e->sa_ff.as<float>(), true)) return 1;
+        if (gemm(e->sa_ff.as<float>(), FF, L.w2, L.b2, E, e->sa_tmp.as<float>(), false)) return 1;
+        ln(e->sa_x1.as<float>(), e->sa_tmp.as<float>(), L.n2w, L.n2b, nullptr, e->sa_y[l].as<float>());
+        HIP_TRY(hipGetLastError());
+        // the next layer reads sa_x: keep per-layer outputs for the test taps, copy is avoided by swapping roles
+        if (l + 1 < c.sa_layers) HIP_TRY(hipMemcpyAsync(e->sa_x.p, e->sa_y[l].p, xe, hipMemcpyDeviceToDevice, st));
+    }
+    layer_in = e->sa_y[c.sa_layers - 1].as<float>();
+    din = E;
+    } else {
     // ---- BiLSTM stack
     const int Hh = c.lstm_hidden, npad = round_up(n, 16);
-    mark(POCR_STAGE_LSTM);
     if (e->xproj.reserve((size_t)n * T * 8 * Hh * sizeof(float))) return 1;
     if (e->hbuf.reserve((size_t)2 * 2 * npad * Hh * sizeof(float))) return 1;
     if (e->cbuf.reserve((size_t)2 * npad * Hh * sizeof(float))) return 1;
-    const float *layer_in = e->feat.as<float>();
-    int din = E;
     for (int l = 0; l < c.lstm_layers; ++l) {
         if (e->lstm_y[l].reserve((size_t)n * T * 2 * Hh * sizeof(float))) return 1;
         ConvArgs a{};
@@ -266,12 +338,13 @@ int run_network(pocr_engine *e) {
         layer_in = e->lstm_y[l].as<float>();
         din = 2 * Hh;
     }
-    // ---- head: [n*T][2H] -> logits [n][T][C]
+    }
+    // ---- head: [n*T][din] -> logits [n][T][C]
     const int C = c.num_classes;
     {
         if (e->logits.reserve((size_t)n * T * C * sizeof(float))) return 1;
         ConvArgs a{};
-        a.x = layer_in; a.n = 1; a.H = 1; a.W = n * T; a.Ho = 1; a.Wo = n * T; a.cin = 2 * Hh;
+        a.x = layer_in; a.n = 1; a.H = 1; a.W = n * T; a.Ho = 1; a.Wo = n * T; a.cin = din;
         a.cout16 = e->head_cout16; a.cout_valid = C; a.out_stride = C;
         a.wfrag = e->head_w.as<float>(); a.bias = e->head_b.as<float>(); a.y = e->logits.as<float>();
         mark(POCR_STAGE_HEAD);
@@ -344,6 +417,13 @@ size_t pocr_num_weight_floats(const pocr_config *c) {
     for (const ConvLayer &L : kConvPlan) t += (size_t)L.cout * L.cin * 9 + L.cout;
     t += 4 * 512;
     t += (size_t)c->conv_out * 512 * (c->height / 8) + c->conv_out;
+    if (c->arch == POCR_ARCH_SA) {
+        const size_t E = c->conv_out, FF = c->sa_ff;
+        t += 2 * E;
+        t += (size_t)c->sa_layers * (3 * E * E + 3 * E + E * E + E + FF * E + FF + E * FF + E + 4 * E);
+        t += (size_t)c->num_classes * E + c->num_classes;
+        return t;
+    }
     const size_t Hh = c->lstm_hidden;
     for (int l = 0; l < c->lstm_layers; ++l) {
         const size_t din = l == 0 ? c->conv_out : 2 * Hh;
@@ -417,7 +497,29 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         for (int k = 0; k < E; ++k) bias[k] = b[k];
         if (upload(e->agg_w, frag, st) || upload(e->agg_b, bias, st)) return bail(1);
     }
-    {   // BiLSTM layers
+    int head_in = 2 * cfg->lstm_hidden;
+    if (cfg->arch == POCR_ARCH_SA) {   // self-attention encoder weights
+        const int E = cfg->conv_out, FF = cfg->sa_ff;
+        head_in = E;
+        auto vec = [&](size_t n_) { const float *p_ = cur.take(n_); return std::vector<float>(p_, p_ + n_); };
+        auto lin = [&](DevBuf &wbuf, DevBuf &bbuf, int cout_, int cin_) {
+            const float *w = cur.take((size_t)cout_ * cin_);
+            const float *b = cur.take(cout_);
+            const int c16 = round_up(cout_, kProjNT) / 16;
+            auto frag = build_wfrag(1, cin_, c16, [&](int co, int ci, int) { return w[(size_t)co * cin_ + ci]; }, cin_, cout_);
+            std::vector<float> bias(c16 * 16, 0.f);
+            for (int k = 0; k < cout_; ++k) bias[k] = b[k];
+            return upload(wbuf, frag, st) || upload(bbuf, bias, st);
+        };
+        if (upload(e->sa_nw, vec(E), st) || upload(e->sa_nb, vec(E), st)) return bail(1);
+        e->sa.resize(cfg->sa_layers);
+        e->sa_y.resize(cfg->sa_layers);
+        for (int l = 0; l < cfg->sa_layers; ++l) {
+            pocr_engine::SaLayer &L = e->sa[l];
+            if (lin(L.w_in, L.b_in, 3 * E, E) || lin(L.w_out, L.b_out, E, E) || lin(L.w1, L.b1, FF, E) || lin(L.w2, L.b2, E, FF)) return bail(1);
+            if (upload(L.n1w, vec(E), st) || upload(L.n1b, vec(E), st) || upload(L.n2w, vec(E), st) || upload(L.n2b, vec(E), st)) return bail(1);
+        }
+    } else {   // BiLSTM layers
         const int Hh = cfg->lstm_hidden, KGT = Hh / 16;
         e->proj_cout16 = round_up(8 * Hh, kProjNT) / 16;
         e->proj_w.resize(cfg->lstm_layers); e->proj_b.resize(cfg->lstm_layers);
@@ -447,11 +549,11 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         }
     }
     {   // head
-        const int Hh = cfg->lstm_hidden, C = cfg->num_classes;
-        const float *w = cur.take((size_t)C * 2 * Hh);
+        const int C = cfg->num_classes;
+        const float *w = cur.take((size_t)C * head_in);
         const float *b = cur.take(C);
         e->head_cout16 = round_up(C, kHeadNT) / 16;
-        auto frag = build_wfrag(1, 2 * Hh, e->head_cout16, [&](int co, int ci, int) { return w[(size_t)co * 2 * Hh + ci]; }, 2 * Hh, C);
+        auto frag = build_wfrag(1, head_in, e->head_cout16, [&](int co, int ci, int) { return w[(size_t)co * head_in + ci]; }, head_in, C);
         std::vector<float> bias(e->head_cout16 * 16, 0.f);
         for (int k = 0; k < C; ++k) bias[k] = b[k];
         if (upload(e->head_w, frag, st) || upload(e->head_b, bias, st)) return bail(1);
@@ -472,8 +574,11 @@ void pocr_destroy(pocr_engine *e) {
     for (auto &b : e->conv_w) b.release();
     for (auto &b : e->conv_b) b.release();
     for (auto &b : e->act) b.release();
-    for (auto &v : {&e->proj_w, &e->proj_b, &e->whh, &e->lstm_y})
+    for (auto &v : {&e->proj_w, &e->proj_b, &e->whh, &e->lstm_y, &e->sa_y})
         for (auto &b : *v) b.release();
+    for (auto &L : e->sa)
+        for (DevBuf *b : {&L.w_in, &L.b_in, &L.w_out, &L.b_out, &L.w1, &L.b1, &L.w2, &L.b2, &L.n1w, &L.n1b, &L.n2w, &L.n2b}) b->release();
+    for (DevBuf *b : {&e->sa_nw, &e->sa_nb, &e->pe, &e->sa_x, &e->sa_x1, &e->sa_qkv, &e->sa_att, &e->sa_tmp, &e->sa_ff}) b->release();
     for (DevBuf *b : {&e->bn_scale, &e->bn_shift, &e->agg_w, &e->agg_b, &e->head_w, &e->head_b, &e->lut, &e->crops,
                       &e->lines, &e->feat, &e->xproj, &e->hbuf, &e->cbuf, &e->logits, &e->best, &e->labels, &e->lens})
         b->release();
@@ -559,7 +664,8 @@ int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t
     size_t sz = 0;
     if (what >= 0 && what < 9) { src = e->act[what].as<float>(); sz = (size_t)n * e->act_h[what] * e->act_w[what] * e->act_c[what]; }
     else if (what == 9) { src = e->feat.as<float>(); sz = (size_t)n * T * e->cfg.conv_out; }
-    else if (what >= 10 && what < 10 + e->cfg.lstm_layers) { src = e->lstm_y[what - 10].as<float>(); sz = (size_t)n * T * 2 * e->cfg.lstm_hidden; }
+    else if (e->cfg.arch == POCR_ARCH_SA && what >= 11 && what < 11 + e->cfg.sa_layers) { src = e->sa_y[what - 11].as<float>(); sz = (size_t)n * T * e->cfg.conv_out; }
+    else if (e->cfg.arch == POCR_ARCH_BLSTM && what >= 10 && what < 10 + e->cfg.lstm_layers) { src = e->lstm_y[what - 10].as<float>(); sz = (size_t)n * T * 2 * e->cfg.lstm_hidden; }
     else return fail("unknown activation id %d", what);
     if (n_floats) *n_floats = sz;
     const size_t k = cap < sz ? cap : sz;

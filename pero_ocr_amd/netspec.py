@@ -40,6 +40,8 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 ARCH = "vgg_blstm_ctc"
+ARCH_SA = "vgg_sa_ctc"          # same backbone, self-attention encoder instead of the BiLSTM (BASELINE config 4)
+LN_EPS = 1e-5
 MAGIC = b"POCRW001"
 LEAKY_SLOPE = 0.01
 BN_EPS = 1e-5
@@ -69,10 +71,19 @@ class NetSpec:
     lstm_hidden: int = 256
     lstm_layers: int = 2
     arch: str = ARCH
+    # "vgg_sa_ctc" only: self-attention encoder (LineSelfAttentionEncoder, transformer.py:366-385)
+    sa_layers: int = 2
+    sa_heads: int = 8
+    sa_ff: int = 2048
 
     def __post_init__(self):
-        if self.arch != ARCH:
+        if self.arch not in (ARCH, ARCH_SA):
             raise ValueError(f"unknown arch {self.arch!r}")
+        if self.arch == ARCH_SA:
+            if self.conv_out % self.sa_heads or (self.conv_out // self.sa_heads) % 16:
+                raise ValueError("conv_out / sa_heads must be a multiple of 16")
+            if self.sa_ff % 16 or self.sa_layers < 1:
+                raise ValueError("sa_ff must be a multiple of 16 and sa_layers >= 1")
         if self.height % 8 or self.height <= 0:
             raise ValueError("height must be a positive multiple of 8")
         if self.conv_out % 16 or self.lstm_hidden % 16:
@@ -91,7 +102,7 @@ class NetSpec:
     def from_json(d: dict) -> "NetSpec":
         return NetSpec(**{k: d[k] for k in
                           ("num_classes", "height", "in_channels", "conv_out",
-                           "lstm_hidden", "lstm_layers", "arch") if k in d})
+                           "lstm_hidden", "lstm_layers", "arch", "sa_layers", "sa_heads", "sa_ff") if k in d})
 
 
 def tensor_table(spec: NetSpec) -> List[Tuple[str, Tuple[int, ...], str, int]]:
@@ -110,6 +121,26 @@ def tensor_table(spec: NetSpec) -> List[Tuple[str, Tuple[int, ...], str, int]]:
     ah = spec.agg_height
     t.append(("agg.weight", (spec.conv_out, c_last, ah, 1), "conv_w", c_last * ah))
     t.append(("agg.bias", (spec.conv_out,), "bias", c_last * ah))
+    if spec.arch == ARCH_SA:
+        e, ff = spec.conv_out, spec.sa_ff
+        t.append(("sa.norm.weight", (e,), "ln_w", 0))
+        t.append(("sa.norm.bias", (e,), "ln_b", 0))
+        for l in range(spec.sa_layers):
+            t.append((f"sa{l}.in_proj.weight", (3 * e, e), "sa_w", e))
+            t.append((f"sa{l}.in_proj.bias", (3 * e,), "sa_b", e))
+            t.append((f"sa{l}.out_proj.weight", (e, e), "sa_w", e))
+            t.append((f"sa{l}.out_proj.bias", (e,), "sa_b", e))
+            t.append((f"sa{l}.lin1.weight", (ff, e), "sa_w", e))
+            t.append((f"sa{l}.lin1.bias", (ff,), "sa_b", e))
+            t.append((f"sa{l}.lin2.weight", (e, ff), "sa_w", ff))
+            t.append((f"sa{l}.lin2.bias", (e,), "sa_b", ff))
+            t.append((f"sa{l}.norm1.weight", (e,), "ln_w", 0))
+            t.append((f"sa{l}.norm1.bias", (e,), "ln_b", 0))
+            t.append((f"sa{l}.norm2.weight", (e,), "ln_w", 0))
+            t.append((f"sa{l}.norm2.bias", (e,), "ln_b", 0))
+        t.append(("head.weight", (spec.num_classes, e), "head_w", e))
+        t.append(("head.bias", (spec.num_classes,), "head_b", e))
+        return t
     hh = spec.lstm_hidden
     for l in range(spec.lstm_layers):
         din = spec.conv_out if l == 0 else 2 * hh
@@ -155,13 +186,16 @@ def uniform01(seed: int, stream: int, n: int) -> np.ndarray:
 
 
 def generate_weights(spec: NetSpec, seed: int, head_gain: float = 20.0,
-                     lstm_gain: float = 3.0, blank_bias: float = 9.0) -> Dict[str, np.ndarray]:
+                     lstm_gain: float = 3.0, blank_bias: float = 9.0, sa_gain: float = 1.0) -> Dict[str, np.ndarray]:
     """Seeded synthetic weights (no real pero checkpoint exists offline).
     He-uniform for conv layers so activations keep their scale through the
     ReLU stack; torch-default U(-1/sqrt(H), 1/sqrt(H)) * lstm_gain for the LSTM;
     head scaled so logits span several units (a 1e-3 logit tolerance and the
     p<1e-4 sparsification are then meaningful)."""
     out: Dict[str, np.ndarray] = {}
+    if spec.arch == ARCH_SA:
+        head_gain = head_gain * 0.4        # the encoder output is LayerNorm'ed (unit scale), the LSTM's is in (-1, 1)
+        blank_bias = blank_bias * 0.6
     for ti, (name, shape, kind, fan_in) in enumerate(tensor_table(spec)):
         n = int(np.prod(shape))
         u = uniform01(seed, ti + 1, n)
@@ -182,6 +216,14 @@ def generate_weights(spec: NetSpec, seed: int, head_gain: float = 20.0,
             v = (2.0 * u - 1.0) * (lstm_gain / fan_in ** 0.5)
         elif kind in ("lstm_whh", "lstm_b"):
             v = (2.0 * u - 1.0) * (1.0 / fan_in ** 0.5)   # torch default; keeps the recurrence contractive
+        elif kind == "sa_w":
+            v = (2.0 * u - 1.0) * (sa_gain * (3.0 / fan_in) ** 0.5)      # variance sa_gain^2 / fan_in
+        elif kind == "sa_b":
+            v = (2.0 * u - 1.0) * 0.05
+        elif kind == "ln_w":
+            v = 0.8 + 0.4 * u
+        elif kind == "ln_b":
+            v = (2.0 * u - 1.0) * 0.1
         elif kind == "head_w":
             v = (2.0 * u - 1.0) * (head_gain / fan_in ** 0.5)
         elif kind == "head_b":

@@ -13,6 +13,10 @@ Engine JSON: the reference's keys (line_px_height, line_vertical_scale, checkpoi
 characters, net_name, optional embed_*/max_line_width) plus the build-specific key
   "net": {"arch": "vgg_blstm_ctc", "conv_out": 512, "lstm_hidden": 256, "lstm_layers": 2,
           "weight_seed": <int, optional>}
+  or, for the self-attention variant (LineSelfAttentionEncoder, transformer.py:366-385; the JSON names of
+  transformer.build_net :13-20 are accepted as aliases):
+  "net": {"arch": "vgg_sa_ctc", "conv_out": 512, "sa_layers"|"encoder_layers": 2, "sa_heads"|"heads": 8,
+          "sa_ff"|"dim_ff": 2048}
 `checkpoint` names a POCRW001 weight blob (pero_ocr_amd/netspec.py); if the file does
 not exist and "weight_seed" is given, seeded synthetic weights are generated instead
 (there is no network access to fetch real pero checkpoints).
@@ -70,7 +74,10 @@ class PytorchEngineLineOCR(BaseEngineLineOCR):
                                    conv_out=int(net_cfg.get("conv_out", 512)),
                                    lstm_hidden=int(net_cfg.get("lstm_hidden", 256)),
                                    lstm_layers=int(net_cfg.get("lstm_layers", 2)),
-                                   arch=net_cfg.get("arch", netspec.ARCH))
+                                   arch=net_cfg.get("arch", netspec.ARCH),
+                                   sa_layers=int(net_cfg.get("sa_layers", net_cfg.get("encoder_layers", 2))),
+                                   sa_heads=int(net_cfg.get("sa_heads", net_cfg.get("heads", 8))),
+                                   sa_ff=int(net_cfg.get("sa_ff", net_cfg.get("dim_ff", 2048))))
             weights = netspec.generate_weights(spec, int(net_cfg["weight_seed"]))
         else:
             raise FileNotFoundError(f"weight blob {self.checkpoint} not found and no net.weight_seed in the engine JSON")

@@ -48,6 +48,10 @@ class Golden:
     def argmax(self, i):
         return self.arrays[f"argmax_{i}"].astype(np.int64)
 
+    def margin(self, i):
+        """Reference top-2 logit margin per frame (how robust 'argmax identical' is on that frame)."""
+        return self.arrays[f"margin_{i}"]
+
     def write_engine_json(self, tmpdir):
         """Engine JSON in the reference's schema + the build-specific "net" key."""
         path = os.path.join(str(tmpdir), "ocr.json")
@@ -55,7 +59,8 @@ class Golden:
             json.dump({"line_px_height": self.meta["height"], "line_vertical_scale": 1.0,
                        "checkpoint": "absent.pocrw", "characters": self.meta["characters"][:-1],
                        "net_name": "VGG_BLSTM_CTC",
-                       "net": {"arch": "vgg_blstm_ctc", "weight_seed": self.meta["weight_seed"]}}, f)
+                       "net": {"arch": self.meta["spec"].get("arch", "vgg_blstm_ctc"),
+                               "weight_seed": self.meta["weight_seed"]}}, f)
         return path
 
 

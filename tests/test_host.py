@@ -119,3 +119,18 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(root, f), encoding="utf8").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(root, f)
                 assert "/root/reference" not in src, os.path.join(root, f)
+
+
+def test_export_weights_roundtrip_from_torch_state_dict(tmp_path):
+    """tools/export_weights.py: a torch state_dict with the engine's topology -> identical blob."""
+    import importlib.util
+    from oracle import model_oracle
+    spec = netspec.NetSpec(num_classes=37, conv_out=64, lstm_hidden=32, lstm_layers=2)
+    w = netspec.generate_weights(spec, 11)
+    net = model_oracle.OracleNet(spec, w)
+    sp = importlib.util.spec_from_file_location("export_weights", os.path.join(REPO, "tools", "export_weights.py"))
+    mod = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(mod)
+    spec2, w2 = mod.state_to_weights(net.state_dict(), height=40)
+    assert spec2 == spec
+    assert all(np.array_equal(w[k], w2[k]) for k in w), [k for k in w if not np.array_equal(w[k], w2[k])]
