@@ -87,9 +87,13 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("POCR_FORCE_DIST") == "1"      # exercise the RCCL path with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -106,12 +110,12 @@ def main():
     pool = np.concatenate([c.reshape(-1) for c in crops])
     offsets = np.arange(N_LINES, dtype=np.int64) * (HEIGHT * WIDTH * 3)
     eng.stage_lines(pool, offsets, np.full(N_LINES, WIDTH, np.int32), w_pad, 32)    # inputs resident in HBM
-    gather_dev = torch.device("cuda", local_rank) if world > 1 else None
+    gather_dev = torch.device("cuda", local_rank) if dist is not None else None
     line_ids = np.arange(N_LINES, dtype=np.int32) + rank * N_LINES
 
     def step():
         _lg, _am, labels, lens = eng.run_staged(want_logits=False, want_argmax=False)
-        if world > 1:
+        if dist is not None:
             labels, lens, _ids = sharding.allgather_labels(labels, lens, line_ids, gather_dev)
         return labels_to_strings(labels, lens, chars)
 
@@ -143,6 +147,14 @@ def main():
 
     if rank == 0:
         ms = {k: v / args.steps for k, v in stage_sum.items()}
+        traffic = None          # HBM bytes per launch of the dominant kernel, from the committed PMC passes
+        try:
+            pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_summary.json")))
+            for kname, ctr in pmc.items():
+                if "5, 1, 4, 4, 16, 1, 1, 2, true" in kname and "hbm_bytes_per_launch" in ctr:
+                    traffic = ctr["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         fl = conv_flops_per_line(w_pad)
         dom = "conv9"                                    # 24 % of the conv FLOPs, the largest single kernel
         dom_tf = fl[dom] * N_LINES / (ms[dom] * 1e-3) / 1e12
@@ -161,7 +173,9 @@ def main():
                        "lines_per_step_per_gpu": N_LINES, "parallelism": f"chunk-sharded x{world}, RCCL all-gather of labels"},
             "roofline": {"bound": "mfma", "kernel": f"conv_igemm_kernel<3x3,TH5,NT256,leaky+BN> ({dom}, 512->512 @5x144)",
                          "achieved": round(dom_tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(dom_tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(dom_tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (KiB -> B; gfx950 FETCH_SIZE x2 correction) from "
+                                         "separate rocprofv3 --pmc passes of this bench, profiles/pmc_summary.json",
                          "flops_per_launch": fl[dom] * N_LINES, "avg_launch_ms": round(ms[dom], 4),
                          "peak_dtype": "fp32 MFMA (v_mfma_f32_16x16x4_f32), dense"},
             "conv_backbone": {"achieved": round(conv_tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

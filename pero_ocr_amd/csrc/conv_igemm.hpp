@@ -94,8 +94,15 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
     const int wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
 
-    // tile coordinates: ntile fastest so the workgroups sharing one input tile run together
+    // tile coordinates: ntile fastest so the workgroups sharing one input tile are neighbours, and an
+    // XCD-aware remap of the block id: block b is dispatched to XCD b % 8 (each XCD has its own L2),
+    // so every XCD gets a contiguous range of logical tiles and the re-reads of a halo tile (by the
+    // other N-tiles and by the neighbouring column tiles) hit that XCD's L2 instead of HBM.
     int b = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
     const int nt = b % a.tiles_n; b /= a.tiles_n;
     const int wt = b % a.tiles_w; b /= a.tiles_w;
     const int ht = b % a.tiles_h; b /= a.tiles_h;
