@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define POCR_ABI_VERSION 2
+#define POCR_ABI_VERSION 3
+#define POCR_NUM_SLOTS 2
 
 typedef struct pocr_engine pocr_engine;
 
@@ -88,6 +89,21 @@ int pocr_stage_lines(pocr_engine *e, const uint8_t *crops, const int64_t *crop_o
 int pocr_run_staged(pocr_engine *e, float *logits_ntc, int32_t *frame_argmax_nt,
                     int32_t *labels_nt, int32_t *label_len_n);
 
+/* ---- pipelined chunks (no reference counterpart: the reference runs its chunks strictly one
+ * after the other, line_ocr_engine.py:80-129).  An engine has POCR_NUM_SLOTS independent slots, each
+ * with its own HIP stream and activation buffers.  stage -> launch -> collect per slot; launch returns
+ * as soon as the work is enqueued, so chunk k+1 can be staged and launched on the other slot while
+ * chunk k is still running its latency-bound LSTM tail / copying results back.  The caller's input
+ * buffers are free as soon as pocr_slot_stage_lines returns (they are copied to pinned memory);
+ * the output buffers are written by pocr_slot_collect.  Outputs must be requested at launch.
+ * pocr_stage_lines / pocr_run_staged / pocr_run_batch above are the blocking forms on slot 0. */
+int pocr_num_slots(void);
+int pocr_slot_stage_lines(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
+                          const int32_t *widths, int32_t n, int32_t w_pad, int32_t pad_left);
+int pocr_slot_launch(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t want_argmax);
+int pocr_slot_collect(pocr_engine *e, int32_t slot, float *logits_ntc, int32_t *frame_argmax_nt,
+                      int32_t *labels_nt, int32_t *label_len_n);
+
 /* ---- measurement / test taps (not part of the reference surface) ----
  * Per-stage GPU time of the last pocr_run_* call in milliseconds, measured with HIP
  * events on the engine's stream.  Stage ids: POCR_STAGE_*.  Returns the number of
@@ -104,6 +120,7 @@ enum {
     POCR_NUM_STAGES
 };
 int pocr_last_stage_ms(pocr_engine *e, float *ms, int32_t cap);
+int pocr_slot_stage_ms(pocr_engine *e, int32_t slot, float *ms, int32_t cap);
 /* Enable/disable per-stage event recording (default off: events cost a little). */
 int pocr_set_profiling(pocr_engine *e, int32_t enabled);
 

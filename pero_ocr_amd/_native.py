@@ -14,7 +14,7 @@ import numpy as np
 from .netspec import NetSpec
 
 LIB_NAME = "libpocr_hip.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 STAGE_NAMES = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv8", "conv9",
                "agg", "lstm", "head", "ctc", "total")
 
@@ -47,6 +47,11 @@ SYMBOLS = {
     "pocr_run_batch": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, _f32p, _i32p, _i32p, _i32p]),
     "pocr_stage_lines": (C.c_int, [C.c_void_p, _u8p, _i64p, _i32p, C.c_int32, C.c_int32, C.c_int32]),
     "pocr_run_staged": (C.c_int, [C.c_void_p, _f32p, _i32p, _i32p, _i32p]),
+    "pocr_num_slots": (C.c_int, []),
+    "pocr_slot_stage_lines": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, C.c_int32, C.c_int32, C.c_int32]),
+    "pocr_slot_launch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "pocr_slot_collect": (C.c_int, [C.c_void_p, C.c_int32, _f32p, _i32p, _i32p, _i32p]),
+    "pocr_slot_stage_ms": (C.c_int, [C.c_void_p, C.c_int32, _f32p, C.c_int32]),
     "pocr_last_stage_ms": (C.c_int, [C.c_void_p, _f32p, C.c_int32]),
     "pocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "pocr_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -93,6 +98,8 @@ class NativeEngine:
             raise RuntimeError("pocr_create: " + self._err())
         self._n = 0
         self._T = 0
+        self.num_slots = int(self._lib.pocr_num_slots())
+        self._slot_shape = [(0, 0, False, False)] * self.num_slots     # (n, T, want_logits, want_argmax) per slot
 
     def _err(self) -> str:
         return (self._lib.pocr_last_error() or b"").decode("utf8", "replace")
@@ -153,6 +160,41 @@ class NativeEngine:
         if rc:
             raise RuntimeError("pocr_run_staged: " + self._err())
         return logits, amax, labels, lens
+
+    # ---- pipelined form: stage -> launch (returns at once) -> collect, per slot -------------
+    def slot_stage_lines(self, slot: int, pool_u8, offsets, widths, w_pad: int, pad_left: int):
+        pool = np.ascontiguousarray(pool_u8, dtype=np.uint8).reshape(-1)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        wd = np.ascontiguousarray(widths, dtype=np.int32)
+        if pool.size == 0:
+            pool = np.zeros(1, dtype=np.uint8)
+        rc = self._lib.pocr_slot_stage_lines(self._h, int(slot), _ptr(pool, _u8p), _ptr(off, _i64p), _ptr(wd, _i32p),
+                                             int(wd.size), int(w_pad), int(pad_left))
+        if rc:
+            raise RuntimeError("pocr_slot_stage_lines: " + self._err())
+        self._slot_shape[slot] = (int(wd.size), self.frames_for(w_pad), False, False)
+        if slot == 0:
+            self._n, self._T = int(wd.size), self.frames_for(w_pad)
+
+    def slot_launch(self, slot: int, want_logits=True, want_argmax=False):
+        if self._lib.pocr_slot_launch(self._h, int(slot), 1 if want_logits else 0, 1 if want_argmax else 0):
+            raise RuntimeError("pocr_slot_launch: " + self._err())
+        n, T, _a, _b = self._slot_shape[slot]
+        self._slot_shape[slot] = (n, T, bool(want_logits), bool(want_argmax))
+
+    def slot_collect(self, slot: int):
+        n, T, want_logits, want_argmax = self._slot_shape[slot]
+        logits, amax, labels, lens = self._alloc_out(n, T, want_logits, want_argmax)
+        rc = self._lib.pocr_slot_collect(self._h, int(slot), _ptr(logits, _f32p), _ptr(amax, _i32p),
+                                         _ptr(labels, _i32p), _ptr(lens, _i32p))
+        if rc:
+            raise RuntimeError("pocr_slot_collect: " + self._err())
+        return logits, amax, labels, lens
+
+    def slot_stage_ms(self, slot: int) -> dict:
+        buf = np.zeros(len(STAGE_NAMES), dtype=np.float32)
+        k = self._lib.pocr_slot_stage_ms(self._h, int(slot), _ptr(buf, _f32p), buf.size)
+        return {STAGE_NAMES[i]: float(buf[i]) for i in range(k)}
 
     def set_profiling(self, on: bool):
         self._lib.pocr_set_profiling(self._h, 1 if on else 0)

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(64) void ctc_collapse_kernel(const int32_t *best, i
         if (keep) out[count + __popcll(m & ((1ull << lane) - 1ull))] = cur;
         count += __popcll(m);
     }
+    for (int t = count + lane; t < T; t += 64) out[t] = -1;      // deterministic tail
     if (lane == 0) len[line] = count;
 }
 

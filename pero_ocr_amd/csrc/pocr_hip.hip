@@ -123,10 +123,42 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
 
+// Per-chunk state.  An engine owns POCR_NUM_SLOTS of these, each with its own HIP stream and
+// activation buffers, so that chunk k+1 (conv backbone, MFMA-bound, fills the chip) overlaps the
+// latency-bound tail of chunk k (2*T*L serial LSTM step launches, D2H, host decode).
+struct Slot {
+    hipStream_t stream = nullptr;        // uploads + conv backbone
+    hipStream_t seq_stream = nullptr;    // sequence model, head, CTC, D2H: high priority, so its short
+                                         // latency-bound kernels are dispatched ahead of the other slot's conv workgroups
+    // staged chunk
+    DevBuf crops, lines;
+    void *host_in = nullptr;         // pinned staging for the crop pool
+    size_t host_in_cap = 0;
+    int n = 0, w_pad = 0;
+    bool staged = false, in_flight = false, want_logits = false, want_argmax = false;
+    // activations
+    DevBuf act[9], feat, xproj, hbuf, cbuf, logits, best, labels, lens;
+    std::vector<DevBuf> lstm_y, sa_y;
+    DevBuf sa_x, sa_x1, sa_qkv, sa_att, sa_tmp, sa_ff;
+    int act_h[9]{}, act_w[9]{}, act_c[9]{};
+    // host pinned staging for the outputs
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+    // profiling
+    hipEvent_t ev[POCR_NUM_STAGES + 1]{};
+    float stage_ms[POCR_NUM_STAGES]{};
+    bool have_ms = false;
+    // recorded after the conv backbone of a launch: the next launch (on another slot) starts its own
+    // MFMA-bound backbone only then, so backbones run one after the other at full speed and only the
+    // latency-bound sequence tail of the previous chunk shares the chip with them
+    hipEvent_t conv_done = nullptr;
+    bool conv_done_valid = false;
+};
+
 struct pocr_engine {
     pocr_config cfg{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // set-up stream (weight uploads)
     // weights (device)
     DevBuf conv_w[9], conv_b[9], bn_scale, bn_shift, agg_w, agg_b, head_w, head_b, lut;
     std::vector<DevBuf> proj_w, proj_b, whh;       // per LSTM layer
@@ -135,26 +167,11 @@ struct pocr_engine {
     std::vector<SaLayer> sa;
     DevBuf sa_nw, sa_nb, pe;
     int pe_rows = 0;
-    DevBuf sa_x, sa_x1, sa_qkv, sa_att, sa_tmp, sa_ff;
-    std::vector<DevBuf> sa_y;
     int conv_cout16[9]{};
     int agg_cout16 = 0, head_cout16 = 0, proj_cout16 = 0;
-    // staged chunk
-    DevBuf crops, lines;
-    int n = 0, w_pad = 0;
-    bool staged = false;
-    // activations
-    DevBuf act[9], feat, xproj, hbuf, cbuf, logits, best, labels, lens;
-    std::vector<DevBuf> lstm_y;
-    int act_h[9]{}, act_w[9]{}, act_c[9]{};
-    // host pinned staging for the small outputs
-    void *pinned = nullptr;
-    size_t pinned_cap = 0;
-    // profiling
+    Slot slot[POCR_NUM_SLOTS];
+    int last_slot = 0;               // slot of the most recent launch (stage timings / debug taps)
     bool profiling = false;
-    hipEvent_t ev[POCR_NUM_STAGES + 1]{};
-    float stage_ms[POCR_NUM_STAGES]{};
-    bool have_ms = false;
 };
 
 namespace {
@@ -195,32 +212,36 @@ struct WeightCursor {
     const float *take(size_t n) { const float *r = p; p += n; return r; }
 };
 
-int run_network(pocr_engine *e) {
+int run_network(pocr_engine *e, Slot &s) {
     const pocr_config &c = e->cfg;
-    hipStream_t st = e->stream;
-    const int n = e->n, H = c.height, W = e->w_pad;
+    hipStream_t st = s.stream;          // switches to s.seq_stream after the backbone
+    const int n = s.n, H = c.height, W = s.w_pad;
     const bool prof = e->profiling;
-    auto mark = [&](int i) { if (prof) (void)hipEventRecord(e->ev[i], st); };
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(s.ev[i], st); };
 
-    // ---- conv stack
+    // ---- conv stack (after the previous launch's backbone, if that ran on another slot)
+    {
+        Slot &prev = e->slot[e->last_slot];
+        if (&prev != &s && prev.conv_done_valid) HIP_TRY(hipStreamWaitEvent(st, prev.conv_done, 0));
+    }
     int h = H, w = W;
     for (int i = 0; i < 9; ++i) {
         const ConvLayer &L = kConvPlan[i];
         const int ho = h / L.ph, wo = w / L.pw;
-        if (e->act[i].reserve((size_t)n * ho * wo * L.cout * sizeof(float))) return 1;
+        if (s.act[i].reserve((size_t)n * ho * wo * L.cout * sizeof(float))) return 1;
         ConvArgs a{};
         a.n = n; a.H = h; a.W = w; a.Ho = h; a.Wo = w;
         a.cout16 = e->conv_cout16[i]; a.cout_valid = L.cout; a.out_stride = L.cout;
         a.wfrag = e->conv_w[i].as<float>(); a.bias = e->conv_b[i].as<float>();
-        a.y = e->act[i].as<float>();
+        a.y = s.act[i].as<float>();
         mark(i);
         int rc = 0;
         if (i == 0) {
-            a.crops = e->crops.as<uint8_t>(); a.lines = e->lines.as<LineDesc>(); a.lut = e->lut.as<float>();
+            a.crops = s.crops.as<uint8_t>(); a.lines = s.lines.as<LineDesc>(); a.lut = e->lut.as<float>();
             a.cin = 32;
             rc = conv1_u8(a, st);
         } else {
-            a.x = e->act[i - 1].as<float>(); a.cin = L.cin;
+            a.x = s.act[i - 1].as<float>(); a.cin = L.cin;
             if (i == 8) { a.bn_scale = e->bn_scale.as<float>(); a.bn_shift = e->bn_shift.as<float>(); }
             switch (i) {
                 case 1: rc = conv2_k(a, st); break;
@@ -234,29 +255,33 @@ int run_network(pocr_engine *e) {
         }
         if (rc) return rc;
         h = ho; w = wo;
-        e->act_h[i] = h; e->act_w[i] = w; e->act_c[i] = L.cout;
+        s.act_h[i] = h; s.act_w[i] = w; s.act_c[i] = L.cout;
     }
     // ---- aggregation conv: [n][H/8][T][512] -> [n][T][E]
     const int T = w, E = c.conv_out, AH = h;
     {
-        if (e->feat.reserve((size_t)n * T * E * sizeof(float))) return 1;
+        if (s.feat.reserve((size_t)n * T * E * sizeof(float))) return 1;
         ConvArgs a{};
-        a.x = e->act[8].as<float>(); a.n = n; a.H = AH; a.W = T; a.Ho = 1; a.Wo = T; a.cin = 512;
+        a.x = s.act[8].as<float>(); a.n = n; a.H = AH; a.W = T; a.Ho = 1; a.Wo = T; a.cin = 512;
         a.cout16 = e->agg_cout16; a.cout_valid = E; a.out_stride = E;
-        a.wfrag = e->agg_w.as<float>(); a.bias = e->agg_b.as<float>(); a.y = e->feat.as<float>();
+        a.wfrag = e->agg_w.as<float>(); a.bias = e->agg_b.as<float>(); a.y = s.feat.as<float>();
         mark(POCR_STAGE_AGG);
         int rc = AH == 4 ? agg4_k(a, st) : AH == 5 ? agg5_k(a, st) : AH == 6 ? agg6_k(a, st) : agg8_k(a, st);
         if (rc) return rc;
     }
-    const float *layer_in = e->feat.as<float>();
+    HIP_TRY(hipEventRecord(s.conv_done, st));
+    s.conv_done_valid = true;
+    HIP_TRY(hipStreamWaitEvent(s.seq_stream, s.conv_done, 0));
+    st = s.seq_stream;
+    const float *layer_in = s.feat.as<float>();
     int din = E;
     mark(POCR_STAGE_LSTM);
     if (c.arch == POCR_ARCH_SA) {
     // ---- self-attention encoder (transformer.py:366-385)
     const int rows = n * T, FF = c.sa_ff, heads = c.sa_heads, D = E / heads;
     const size_t xe = (size_t)rows * E * sizeof(float);
-    if (e->sa_x.reserve(xe) || e->sa_x1.reserve(xe) || e->sa_att.reserve(xe) || e->sa_tmp.reserve(xe)) return 1;
-    if (e->sa_qkv.reserve(3 * xe) || e->sa_ff.reserve((size_t)rows * FF * sizeof(float))) return 1;
+    if (s.sa_x.reserve(xe) || s.sa_x1.reserve(xe) || s.sa_att.reserve(xe) || s.sa_tmp.reserve(xe)) return 1;
+    if (s.sa_qkv.reserve(3 * xe) || s.sa_ff.reserve((size_t)rows * FF * sizeof(float))) return 1;
     if (T > e->pe_rows) {      // sinusoidal table, float32 like PositionalEncoding (transformer.py:316-332)
         const int rows_pe = round_up(T, 256);
         std::vector<float> pe((size_t)rows_pe * E);
@@ -267,6 +292,7 @@ int run_network(pocr_engine *e) {
                 if (k + 1 < E) pe[(size_t)t * E + k + 1] = cosf((float)t * div);
             }
         }
+        HIP_TRY(hipDeviceSynchronize());     // another slot may still be reading the old table
         if (upload(e->pe, pe, st)) return 1;
         e->pe_rows = rows_pe;
     }
@@ -281,50 +307,50 @@ int run_network(pocr_engine *e) {
         g.wfrag = w_.as<float>(); g.bias = b_.as<float>(); g.y = y_;
         return relu ? gemm128_relu_k(g, st) : gemm128_k(g, st);
     };
-    ln(e->feat.as<float>(), nullptr, e->sa_nw, e->sa_nb, e->pe.as<float>(), e->sa_x.as<float>());
+    ln(s.feat.as<float>(), nullptr, e->sa_nw, e->sa_nb, e->pe.as<float>(), s.sa_x.as<float>());
     for (int l = 0; l < c.sa_layers; ++l) {
         pocr_engine::SaLayer &L = e->sa[l];
-        if (e->sa_y[l].reserve(xe)) return 1;
-        if (gemm(e->sa_x.as<float>(), E, L.w_in, L.b_in, 3 * E, e->sa_qkv.as<float>(), false)) return 1;
+        if (s.sa_y[l].reserve(xe)) return 1;
+        if (gemm(s.sa_x.as<float>(), E, L.w_in, L.b_in, 3 * E, s.sa_qkv.as<float>(), false)) return 1;
         const dim3 agrid((T + 15) / 16, heads, n);
         const float scale = 1.0f / sqrtf((float)D);
-        if (D == 32) hipLaunchKernelGGL(attention_kernel<32>, agrid, dim3(64), 0, st, e->sa_qkv.as<float>(), e->sa_att.as<float>(), T, E, scale);
-        else if (D == 64) hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(64), 0, st, e->sa_qkv.as<float>(), e->sa_att.as<float>(), T, E, scale);
-        else hipLaunchKernelGGL(attention_kernel<128>, agrid, dim3(64), 0, st, e->sa_qkv.as<float>(), e->sa_att.as<float>(), T, E, scale);
-        if (gemm(e->sa_att.as<float>(), E, L.w_out, L.b_out, E, e->sa_tmp.as<float>(), false)) return 1;
-        ln(e->sa_x.as<float>(), e->sa_tmp.as<float>(), L.n1w, L.n1b, nullptr, e->sa_x1.as<float>());
-        if (gemm(e->sa_x1.as<float>(), E, L.w1, L.b1, FF, e->sa_ff.as<float>(), true)) return 1;
-        if (gemm(e->sa_ff.as<float>(), FF, L.w2, L.b2, E, e->sa_tmp.as<float>(), false)) return 1;
-        ln(e->sa_x1.as<float>(), e->sa_tmp.as<float>(), L.n2w, L.n2b, nullptr, e->sa_y[l].as<float>());
+        if (D == 32) hipLaunchKernelGGL(attention_kernel<32>, agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale);
+        else if (D == 64) hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale);
+        else hipLaunchKernelGGL(attention_kernel<128>, agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale);
+        if (gemm(s.sa_att.as<float>(), E, L.w_out, L.b_out, E, s.sa_tmp.as<float>(), false)) return 1;
+        ln(s.sa_x.as<float>(), s.sa_tmp.as<float>(), L.n1w, L.n1b, nullptr, s.sa_x1.as<float>());
+        if (gemm(s.sa_x1.as<float>(), E, L.w1, L.b1, FF, s.sa_ff.as<float>(), true)) return 1;
+        if (gemm(s.sa_ff.as<float>(), FF, L.w2, L.b2, E, s.sa_tmp.as<float>(), false)) return 1;
+        ln(s.sa_x1.as<float>(), s.sa_tmp.as<float>(), L.n2w, L.n2b, nullptr, s.sa_y[l].as<float>());
         HIP_TRY(hipGetLastError());
         // the next layer reads sa_x: keep per-layer outputs for the test taps, copy is avoided by swapping roles
-        if (l + 1 < c.sa_layers) HIP_TRY(hipMemcpyAsync(e->sa_x.p, e->sa_y[l].p, xe, hipMemcpyDeviceToDevice, st));
+        if (l + 1 < c.sa_layers) HIP_TRY(hipMemcpyAsync(s.sa_x.p, s.sa_y[l].p, xe, hipMemcpyDeviceToDevice, st));
     }
-    layer_in = e->sa_y[c.sa_layers - 1].as<float>();
+    layer_in = s.sa_y[c.sa_layers - 1].as<float>();
     din = E;
     } else {
     // ---- BiLSTM stack
     const int Hh = c.lstm_hidden, npad = round_up(n, 16);
-    if (e->xproj.reserve((size_t)n * T * 8 * Hh * sizeof(float))) return 1;
-    if (e->hbuf.reserve((size_t)2 * 2 * npad * Hh * sizeof(float))) return 1;
-    if (e->cbuf.reserve((size_t)2 * npad * Hh * sizeof(float))) return 1;
+    if (s.xproj.reserve((size_t)n * T * 8 * Hh * sizeof(float))) return 1;
+    if (s.hbuf.reserve((size_t)2 * 2 * npad * Hh * sizeof(float))) return 1;
+    if (s.cbuf.reserve((size_t)2 * npad * Hh * sizeof(float))) return 1;
     for (int l = 0; l < c.lstm_layers; ++l) {
-        if (e->lstm_y[l].reserve((size_t)n * T * 2 * Hh * sizeof(float))) return 1;
+        if (s.lstm_y[l].reserve((size_t)n * T * 2 * Hh * sizeof(float))) return 1;
         ConvArgs a{};
         a.x = layer_in; a.n = 1; a.H = 1; a.W = n * T; a.Ho = 1; a.Wo = n * T; a.cin = din;
         a.cout16 = e->proj_cout16; a.cout_valid = 8 * Hh; a.out_stride = 8 * Hh;
-        a.wfrag = e->proj_w[l].as<float>(); a.bias = e->proj_b[l].as<float>(); a.y = e->xproj.as<float>();
+        a.wfrag = e->proj_w[l].as<float>(); a.bias = e->proj_b[l].as<float>(); a.y = s.xproj.as<float>();
         if (gemm128_k(a, st)) return 1;
         const size_t hsz = (size_t)2 * npad * Hh;
-        HIP_TRY(hipMemsetAsync(e->hbuf.p, 0, 2 * hsz * sizeof(float), st));
-        HIP_TRY(hipMemsetAsync(e->cbuf.p, 0, hsz * sizeof(float), st));
-        for (int s = 0; s < T; ++s) {
+        HIP_TRY(hipMemsetAsync(s.hbuf.p, 0, 2 * hsz * sizeof(float), st));
+        HIP_TRY(hipMemsetAsync(s.cbuf.p, 0, hsz * sizeof(float), st));
+        for (int step = 0; step < T; ++step) {
             LstmStepArgs la{};
-            la.xproj = e->xproj.as<float>(); la.whh_frag = e->whh[l].as<float>();
-            la.h_in = e->hbuf.as<float>() + (size_t)(s & 1) * hsz;
-            la.h_out = e->hbuf.as<float>() + (size_t)((s + 1) & 1) * hsz;
-            la.c = e->cbuf.as<float>(); la.y = e->lstm_y[l].as<float>();
-            la.n = n; la.npad = npad; la.T = T; la.H = Hh; la.step = s;
+            la.xproj = s.xproj.as<float>(); la.whh_frag = e->whh[l].as<float>();
+            la.h_in = s.hbuf.as<float>() + (size_t)(step & 1) * hsz;
+            la.h_out = s.hbuf.as<float>() + (size_t)((step + 1) & 1) * hsz;
+            la.c = s.cbuf.as<float>(); la.y = s.lstm_y[l].as<float>();
+            la.n = n; la.npad = npad; la.T = T; la.H = Hh; la.step = step;
             const dim3 grid(Hh / 16, npad / 16, 2);
             switch (Hh) {
                 case 64: hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, st, la); break;
@@ -335,66 +361,85 @@ int run_network(pocr_engine *e) {
             }
         }
         HIP_TRY(hipGetLastError());
-        layer_in = e->lstm_y[l].as<float>();
+        layer_in = s.lstm_y[l].as<float>();
         din = 2 * Hh;
     }
     }
     // ---- head: [n*T][din] -> logits [n][T][C]
     const int C = c.num_classes;
     {
-        if (e->logits.reserve((size_t)n * T * C * sizeof(float))) return 1;
+        if (s.logits.reserve((size_t)n * T * C * sizeof(float))) return 1;
         ConvArgs a{};
         a.x = layer_in; a.n = 1; a.H = 1; a.W = n * T; a.Ho = 1; a.Wo = n * T; a.cin = din;
         a.cout16 = e->head_cout16; a.cout_valid = C; a.out_stride = C;
-        a.wfrag = e->head_w.as<float>(); a.bias = e->head_b.as<float>(); a.y = e->logits.as<float>();
+        a.wfrag = e->head_w.as<float>(); a.bias = e->head_b.as<float>(); a.y = s.logits.as<float>();
         mark(POCR_STAGE_HEAD);
         if (gemm64_k(a, st)) return 1;
     }
     // ---- greedy CTC
     {
-        if (e->best.reserve((size_t)n * T * sizeof(int32_t))) return 1;
-        if (e->labels.reserve((size_t)n * T * sizeof(int32_t))) return 1;
-        if (e->lens.reserve((size_t)n * sizeof(int32_t))) return 1;
+        if (s.best.reserve((size_t)n * T * sizeof(int32_t))) return 1;
+        if (s.labels.reserve((size_t)n * T * sizeof(int32_t))) return 1;
+        if (s.lens.reserve((size_t)n * sizeof(int32_t))) return 1;
         mark(POCR_STAGE_CTC);
         const int frames = n * T;
         hipLaunchKernelGGL(frame_argmax_kernel, dim3((frames + 3) / 4), dim3(256), 0, st,
-                           e->logits.as<float>(), e->best.as<int32_t>(), frames, C);
-        hipLaunchKernelGGL(ctc_collapse_kernel, dim3(n), dim3(64), 0, st, e->best.as<int32_t>(),
-                           e->labels.as<int32_t>(), e->lens.as<int32_t>(), T, C - 1);
+                           s.logits.as<float>(), s.best.as<int32_t>(), frames, C);
+        hipLaunchKernelGGL(ctc_collapse_kernel, dim3(n), dim3(64), 0, st, s.best.as<int32_t>(),
+                           s.labels.as<int32_t>(), s.lens.as<int32_t>(), T, C - 1);
         HIP_TRY(hipGetLastError());
         mark(POCR_NUM_STAGES);
     }
     return 0;
 }
 
-int fetch_outputs(pocr_engine *e, float *logits_ntc, int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n) {
-    const int n = e->n, T = (e->w_pad / 2) / 2, C = e->cfg.num_classes;
-    hipStream_t st = e->stream;
+// async D2H of the chunk's results into the slot's pinned buffer (layout: labels | argmax | lens | logits)
+int enqueue_outputs(pocr_engine *e, Slot &s) {
+    const int n = s.n, T = (s.w_pad / 2) / 2, C = e->cfg.num_classes;
+    hipStream_t st = s.seq_stream;
     const size_t nt_bytes = (size_t)n * T * sizeof(int32_t);
-    const size_t need = 2 * nt_bytes + (size_t)n * sizeof(int32_t);
-    if (need > e->pinned_cap) {
-        if (e->pinned) (void)hipHostFree(e->pinned);
-        e->pinned = nullptr; e->pinned_cap = 0;
-        HIP_TRY(hipHostMalloc(&e->pinned, need + need / 4, hipHostMallocDefault));
-        e->pinned_cap = need + need / 4;
+    const size_t lg_bytes = s.want_logits ? (size_t)n * T * C * sizeof(float) : 0;
+    const size_t need = 2 * nt_bytes + (size_t)round_up(n, 4) * sizeof(int32_t) + lg_bytes;
+    if (need > s.pinned_cap) {
+        if (s.pinned) (void)hipHostFree(s.pinned);
+        s.pinned = nullptr; s.pinned_cap = 0;
+        HIP_TRY(hipHostMalloc(&s.pinned, need + need / 4, hipHostMallocDefault));
+        s.pinned_cap = need + need / 4;
     }
-    char *pin = static_cast<char *>(e->pinned);
-    if (labels_nt) HIP_TRY(hipMemcpyAsync(pin, e->labels.p, nt_bytes, hipMemcpyDeviceToHost, st));
-    if (frame_argmax_nt) HIP_TRY(hipMemcpyAsync(pin + nt_bytes, e->best.p, nt_bytes, hipMemcpyDeviceToHost, st));
-    if (label_len_n) HIP_TRY(hipMemcpyAsync(pin + 2 * nt_bytes, e->lens.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    if (logits_ntc) HIP_TRY(hipMemcpyAsync(logits_ntc, e->logits.p, (size_t)n * T * C * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    char *pin = static_cast<char *>(s.pinned);
+    HIP_TRY(hipMemcpyAsync(pin, s.labels.p, nt_bytes, hipMemcpyDeviceToHost, st));
+    if (s.want_argmax) HIP_TRY(hipMemcpyAsync(pin + nt_bytes, s.best.p, nt_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(pin + 2 * nt_bytes, s.lens.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (lg_bytes) HIP_TRY(hipMemcpyAsync(pin + 2 * nt_bytes + (size_t)round_up(n, 4) * sizeof(int32_t), s.logits.p, lg_bytes, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+int collect_outputs(pocr_engine *e, Slot &s, float *logits_ntc, int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n) {
+    const int n = s.n, T = (s.w_pad / 2) / 2, C = e->cfg.num_classes;
+    HIP_TRY(hipStreamSynchronize(s.seq_stream));
+    s.in_flight = false;
+    const size_t nt_bytes = (size_t)n * T * sizeof(int32_t);
+    const char *pin = static_cast<const char *>(s.pinned);
+    if (logits_ntc && !s.want_logits) return fail("logits were not requested at launch");
+    if (frame_argmax_nt && !s.want_argmax) return fail("frame argmax was not requested at launch");
     if (labels_nt) memcpy(labels_nt, pin, nt_bytes);
     if (frame_argmax_nt) memcpy(frame_argmax_nt, pin + nt_bytes, nt_bytes);
     if (label_len_n) memcpy(label_len_n, pin + 2 * nt_bytes, (size_t)n * sizeof(int32_t));
+    if (logits_ntc) memcpy(logits_ntc, pin + 2 * nt_bytes + (size_t)round_up(n, 4) * sizeof(int32_t), (size_t)n * T * C * sizeof(float));
     if (e->profiling) {
-        for (int i = 0; i < POCR_NUM_STAGES; ++i) e->stage_ms[i] = 0.f;
+        for (int i = 0; i < POCR_NUM_STAGES; ++i) s.stage_ms[i] = 0.f;
         const int order[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, POCR_STAGE_AGG, POCR_STAGE_LSTM, POCR_STAGE_HEAD, POCR_STAGE_CTC, POCR_NUM_STAGES};
         for (int k = 0; k + 1 < (int)(sizeof(order) / sizeof(int)); ++k)
-            HIP_TRY(hipEventElapsedTime(&e->stage_ms[order[k]], e->ev[order[k]], e->ev[order[k + 1]]));
-        HIP_TRY(hipEventElapsedTime(&e->stage_ms[POCR_STAGE_TOTAL], e->ev[0], e->ev[POCR_NUM_STAGES]));
-        e->have_ms = true;
+            HIP_TRY(hipEventElapsedTime(&s.stage_ms[order[k]], s.ev[order[k]], s.ev[order[k + 1]]));
+        HIP_TRY(hipEventElapsedTime(&s.stage_ms[POCR_STAGE_TOTAL], s.ev[0], s.ev[POCR_NUM_STAGES]));
+        s.have_ms = true;
     }
+    return 0;
+}
+
+int check_slot(pocr_engine *e, int32_t slot) {
+    if (!e) return fail("engine is NULL");
+    if (slot < 0 || slot >= POCR_NUM_SLOTS) return fail("slot %d out of range (0..%d)", slot, POCR_NUM_SLOTS - 1);
     return 0;
 }
 
@@ -455,8 +500,19 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     e->device = device_id;
     auto bail = [&](int rc) { pocr_destroy(e); return rc; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
-    for (auto &ev : e->ev)
-        if (hipEventCreate(&ev) != hipSuccess) return bail(fail("hipEventCreate failed"));
+    for (Slot &sl : e->slot) {
+        // (A CU-masked partition - backbone on 256-k CUs, sequence kernels on k - was measured and is
+        //  slower on this stack: 6.9k / 4.7k / 8.4k lines/s for k = 8 / 16 / 32 vs 8.4k unmasked.)
+        if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically lower = higher priority
+        if (hipStreamCreateWithPriority(&sl.seq_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(fail("hipStreamCreate failed"));
+        for (auto &ev : sl.ev)
+            if (hipEventCreate(&ev) != hipSuccess) return bail(fail("hipEventCreate failed"));
+        if (hipEventCreateWithFlags(&sl.conv_done, hipEventDisableTiming) != hipSuccess) return bail(fail("hipEventCreate failed"));
+        sl.lstm_y.resize(cfg->arch == POCR_ARCH_BLSTM ? cfg->lstm_layers : 0);
+        sl.sa_y.resize(cfg->arch == POCR_ARCH_SA ? cfg->sa_layers : 0);
+    }
     hipStream_t st = e->stream;
 
     WeightCursor cur{weights};
@@ -513,7 +569,6 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         };
         if (upload(e->sa_nw, vec(E), st) || upload(e->sa_nb, vec(E), st)) return bail(1);
         e->sa.resize(cfg->sa_layers);
-        e->sa_y.resize(cfg->sa_layers);
         for (int l = 0; l < cfg->sa_layers; ++l) {
             pocr_engine::SaLayer &L = e->sa[l];
             if (lin(L.w_in, L.b_in, 3 * E, E) || lin(L.w_out, L.b_out, E, E) || lin(L.w1, L.b1, FF, E) || lin(L.w2, L.b2, E, FF)) return bail(1);
@@ -523,7 +578,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         const int Hh = cfg->lstm_hidden, KGT = Hh / 16;
         e->proj_cout16 = round_up(8 * Hh, kProjNT) / 16;
         e->proj_w.resize(cfg->lstm_layers); e->proj_b.resize(cfg->lstm_layers);
-        e->whh.resize(cfg->lstm_layers); e->lstm_y.resize(cfg->lstm_layers);
+        e->whh.resize(cfg->lstm_layers);
         for (int l = 0; l < cfg->lstm_layers; ++l) {
             const int din = l == 0 ? cfg->conv_out : 2 * Hh;
             const float *wih[2], *whh[2], *bih[2], *bhh[2];
@@ -570,61 +625,110 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
 void pocr_destroy(pocr_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    (void)hipDeviceSynchronize();
     for (auto &b : e->conv_w) b.release();
     for (auto &b : e->conv_b) b.release();
-    for (auto &b : e->act) b.release();
-    for (auto &v : {&e->proj_w, &e->proj_b, &e->whh, &e->lstm_y, &e->sa_y})
+    for (auto &v : {&e->proj_w, &e->proj_b, &e->whh})
         for (auto &b : *v) b.release();
     for (auto &L : e->sa)
         for (DevBuf *b : {&L.w_in, &L.b_in, &L.w_out, &L.b_out, &L.w1, &L.b1, &L.w2, &L.b2, &L.n1w, &L.n1b, &L.n2w, &L.n2b}) b->release();
-    for (DevBuf *b : {&e->sa_nw, &e->sa_nb, &e->pe, &e->sa_x, &e->sa_x1, &e->sa_qkv, &e->sa_att, &e->sa_tmp, &e->sa_ff}) b->release();
-    for (DevBuf *b : {&e->bn_scale, &e->bn_shift, &e->agg_w, &e->agg_b, &e->head_w, &e->head_b, &e->lut, &e->crops,
-                      &e->lines, &e->feat, &e->xproj, &e->hbuf, &e->cbuf, &e->logits, &e->best, &e->labels, &e->lens})
+    for (DevBuf *b : {&e->sa_nw, &e->sa_nb, &e->pe, &e->bn_scale, &e->bn_shift, &e->agg_w, &e->agg_b, &e->head_w, &e->head_b, &e->lut})
         b->release();
-    if (e->pinned) (void)hipHostFree(e->pinned);
-    for (auto &ev : e->ev)
-        if (ev) (void)hipEventDestroy(ev);
+    for (Slot &s : e->slot) {
+        for (auto &b : s.act) b.release();
+        for (auto &v : {&s.lstm_y, &s.sa_y})
+            for (auto &b : *v) b.release();
+        for (DevBuf *b : {&s.crops, &s.lines, &s.feat, &s.xproj, &s.hbuf, &s.cbuf, &s.logits, &s.best, &s.labels, &s.lens,
+                          &s.sa_x, &s.sa_x1, &s.sa_qkv, &s.sa_att, &s.sa_tmp, &s.sa_ff})
+            b->release();
+        if (s.pinned) (void)hipHostFree(s.pinned);
+        if (s.host_in) (void)hipHostFree(s.host_in);
+        for (auto &ev : s.ev)
+            if (ev) (void)hipEventDestroy(ev);
+        if (s.conv_done) (void)hipEventDestroy(s.conv_done);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.seq_stream) (void)hipStreamDestroy(s.seq_stream);
+    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
-int pocr_stage_lines(pocr_engine *e, const uint8_t *crops, const int64_t *crop_offsets, const int32_t *widths,
-                     int32_t n, int32_t w_pad, int32_t pad_left) {
-    if (!e) return fail("engine is NULL");
-    e->staged = false;
+int pocr_num_slots(void) { return POCR_NUM_SLOTS; }
+
+int pocr_slot_stage_lines(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
+                          const int32_t *widths, int32_t n, int32_t w_pad, int32_t pad_left) {
+    if (check_slot(e, slot)) return 1;
+    Slot &s = e->slot[slot];
+    if (s.in_flight) return fail("slot %d has a launch in flight: collect it first", slot);
+    s.staged = false;
     if (n <= 0) return fail("n must be positive (got %d)", n);
     if (w_pad < 4) return fail("w_pad must be >= 4 (got %d)", w_pad);
     if (pad_left < 0) return fail("pad_left must be >= 0");
     if (!crops || !crop_offsets || !widths) return fail("NULL input pointer");
     HIP_TRY(hipSetDevice(e->device));
     const int H = e->cfg.height;
-    std::vector<LineDesc> desc(n);
     size_t total = 0;
     for (int i = 0; i < n; ++i) {
         if (widths[i] < 0) return fail("line %d has negative width", i);
         if (crop_offsets[i] < 0) return fail("line %d has negative offset", i);
-        desc[i].offset = crop_offsets[i];
-        desc[i].width = widths[i];
-        desc[i].pad_left = pad_left;
         const size_t end = (size_t)crop_offsets[i] + (size_t)H * widths[i] * 3;
         if (end > total) total = end;
     }
-    if (e->crops.reserve(total ? total : 1)) return 1;
-    if (e->lines.reserve((size_t)n * sizeof(LineDesc))) return 1;
-    if (total) HIP_TRY(hipMemcpyAsync(e->crops.p, crops, total, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->lines.p, desc.data(), (size_t)n * sizeof(LineDesc), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    e->n = n; e->w_pad = w_pad; e->staged = true;
+    // pinned staging: [LineDesc table | crop pool]; the H2D copies then run asynchronously on the slot's
+    // stream (they overlap the other slot's kernels) and the caller's buffers are free on return
+    const size_t desc_bytes = (size_t)round_up(n, 4) * sizeof(LineDesc);
+    const size_t need = desc_bytes + total;
+    if (need > s.host_in_cap) {
+        if (s.host_in) (void)hipHostFree(s.host_in);
+        s.host_in = nullptr; s.host_in_cap = 0;
+        HIP_TRY(hipHostMalloc(&s.host_in, need + need / 4, hipHostMallocDefault));
+        s.host_in_cap = need + need / 4;
+    }
+    LineDesc *desc = static_cast<LineDesc *>(s.host_in);
+    for (int i = 0; i < n; ++i) { desc[i].offset = crop_offsets[i]; desc[i].width = widths[i]; desc[i].pad_left = pad_left; }
+    if (total) memcpy(static_cast<char *>(s.host_in) + desc_bytes, crops, total);
+    if (s.crops.reserve(total ? total : 1)) return 1;
+    if (s.lines.reserve((size_t)n * sizeof(LineDesc))) return 1;
+    if (total) HIP_TRY(hipMemcpyAsync(s.crops.p, static_cast<char *>(s.host_in) + desc_bytes, total, hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(hipMemcpyAsync(s.lines.p, desc, (size_t)n * sizeof(LineDesc), hipMemcpyHostToDevice, s.stream));
+    s.n = n; s.w_pad = w_pad; s.staged = true; s.have_ms = false;
+    return 0;
+}
+
+int pocr_slot_launch(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t want_argmax) {
+    if (check_slot(e, slot)) return 1;
+    Slot &s = e->slot[slot];
+    if (!s.staged) return fail("slot %d: no chunk staged", slot);
+    if (s.in_flight) return fail("slot %d already has a launch in flight", slot);
+    HIP_TRY(hipSetDevice(e->device));
+    s.want_logits = want_logits != 0;
+    s.want_argmax = want_argmax != 0;
+    if (run_network(e, s)) return 1;
+    if (enqueue_outputs(e, s)) return 1;
+    s.in_flight = true;
+    e->last_slot = slot;
+    return 0;
+}
+
+int pocr_slot_collect(pocr_engine *e, int32_t slot, float *logits_ntc, int32_t *frame_argmax_nt,
+                      int32_t *labels_nt, int32_t *label_len_n) {
+    if (check_slot(e, slot)) return 1;
+    Slot &s = e->slot[slot];
+    if (!s.in_flight) return fail("slot %d has nothing in flight", slot);
+    HIP_TRY(hipSetDevice(e->device));
+    return collect_outputs(e, s, logits_ntc, frame_argmax_nt, labels_nt, label_len_n);
+}
+
+int pocr_stage_lines(pocr_engine *e, const uint8_t *crops, const int64_t *crop_offsets, const int32_t *widths,
+                     int32_t n, int32_t w_pad, int32_t pad_left) {
+    if (pocr_slot_stage_lines(e, 0, crops, crop_offsets, widths, n, w_pad, pad_left)) return 1;
+    HIP_TRY(hipStreamSynchronize(e->slot[0].stream));       // resident in HBM on return
     return 0;
 }
 
 int pocr_run_staged(pocr_engine *e, float *logits_ntc, int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n) {
-    if (!e) return fail("engine is NULL");
-    if (!e->staged) return fail("no chunk staged: call pocr_stage_lines first");
-    HIP_TRY(hipSetDevice(e->device));
-    if (run_network(e)) return 1;
-    return fetch_outputs(e, logits_ntc, frame_argmax_nt, labels_nt, label_len_n);
+    if (pocr_slot_launch(e, 0, logits_ntc != nullptr, frame_argmax_nt != nullptr)) return 1;
+    return pocr_slot_collect(e, 0, logits_ntc, frame_argmax_nt, labels_nt, label_len_n);
 }
 
 int pocr_run_batch(pocr_engine *e, const uint8_t *batch_nhwc, int32_t n, int32_t w_pad, float *logits_ntc,
@@ -643,35 +747,48 @@ int pocr_run_batch(pocr_engine *e, const uint8_t *batch_nhwc, int32_t n, int32_t
 int pocr_set_profiling(pocr_engine *e, int32_t enabled) {
     if (!e) return fail("engine is NULL");
     e->profiling = enabled != 0;
-    e->have_ms = false;
+    for (Slot &s : e->slot) s.have_ms = false;
     return 0;
 }
 
 int pocr_last_stage_ms(pocr_engine *e, float *ms, int32_t cap) {
     if (!e || !ms) return 0;
-    if (!e->have_ms) return 0;
+    const Slot &s = e->slot[e->last_slot];
+    if (!s.have_ms) return 0;
     int k = cap < POCR_NUM_STAGES ? cap : POCR_NUM_STAGES;
-    for (int i = 0; i < k; ++i) ms[i] = e->stage_ms[i];
+    for (int i = 0; i < k; ++i) ms[i] = s.stage_ms[i];
+    return k;
+}
+
+int pocr_slot_stage_ms(pocr_engine *e, int32_t slot, float *ms, int32_t cap) {
+    if (!e || !ms || slot < 0 || slot >= POCR_NUM_SLOTS) return 0;
+    const Slot &s = e->slot[slot];
+    if (!s.have_ms) return 0;
+    int k = cap < POCR_NUM_STAGES ? cap : POCR_NUM_STAGES;
+    for (int i = 0; i < k; ++i) ms[i] = s.stage_ms[i];
     return k;
 }
 
 int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t *n_floats) {
     if (!e) return fail("engine is NULL");
-    if (!e->staged) return fail("nothing has been run");
+    Slot &s = e->slot[e->last_slot];
+    if (!s.staged) return fail("nothing has been run");
     HIP_TRY(hipSetDevice(e->device));
-    const int n = e->n, T = (e->w_pad / 2) / 2;
+    const int n = s.n, T = (s.w_pad / 2) / 2;
     const float *src = nullptr;
     size_t sz = 0;
-    if (what >= 0 && what < 9) { src = e->act[what].as<float>(); sz = (size_t)n * e->act_h[what] * e->act_w[what] * e->act_c[what]; }
-    else if (what == 9) { src = e->feat.as<float>(); sz = (size_t)n * T * e->cfg.conv_out; }
-    else if (e->cfg.arch == POCR_ARCH_SA && what >= 11 && what < 11 + e->cfg.sa_layers) { src = e->sa_y[what - 11].as<float>(); sz = (size_t)n * T * e->cfg.conv_out; }
-    else if (e->cfg.arch == POCR_ARCH_BLSTM && what >= 10 && what < 10 + e->cfg.lstm_layers) { src = e->lstm_y[what - 10].as<float>(); sz = (size_t)n * T * 2 * e->cfg.lstm_hidden; }
+    if (what >= 0 && what < 9) { src = s.act[what].as<float>(); sz = (size_t)n * s.act_h[what] * s.act_w[what] * s.act_c[what]; }
+    else if (what == 9) { src = s.feat.as<float>(); sz = (size_t)n * T * e->cfg.conv_out; }
+    else if (e->cfg.arch == POCR_ARCH_SA && what == 10) { src = nullptr; return fail("activation 10 (LayerNorm+PE) is not retained"); }
+    else if (e->cfg.arch == POCR_ARCH_SA && what >= 11 && what < 11 + e->cfg.sa_layers) { src = s.sa_y[what - 11].as<float>(); sz = (size_t)n * T * e->cfg.conv_out; }
+    else if (e->cfg.arch == POCR_ARCH_BLSTM && what >= 10 && what < 10 + e->cfg.lstm_layers) { src = s.lstm_y[what - 10].as<float>(); sz = (size_t)n * T * 2 * e->cfg.lstm_hidden; }
     else return fail("unknown activation id %d", what);
     if (n_floats) *n_floats = sz;
     const size_t k = cap < sz ? cap : sz;
     if (out && k) {
-        HIP_TRY(hipMemcpyAsync(out, src, k * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipStreamSynchronize(s.seq_stream));
+        HIP_TRY(hipMemcpyAsync(out, src, k * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(hipStreamSynchronize(s.stream));
     }
     return 0;
 }

@@ -116,18 +116,13 @@ class BaseEngineLineOCR:
 
         sub = int(self.net_subsampling)
         pad = int(self.line_padding_px)
-        for chunk in plan_chunks([l.shape[1] for l in lines], self.max_input_horizontal_pixels, pad):
-            if chunk.max_width + 2 * pad > chunk.w_pad:
-                print(f"WARNING: Line too long for OCR engine. Cropping from {chunk.max_width + 2 * pad} px "
-                      f"down to {chunk.w_pad}.")
-            texts, chunk_logits = self._recognise_chunk(lines, chunk, want_logits=not no_logits)
+
+        def scatter(chunk, texts, chunk_logits):
             for k, i in enumerate(chunk.line_ids):
                 transcriptions[i] = texts[k]
             if no_logits:
-                continue
-            probs = None
-            if sparse_logits:
-                probs = softmax(chunk_logits, axis=2)       # one vectorised pass per chunk; rows are independent
+                return
+            probs = softmax(chunk_logits, axis=2) if sparse_logits else None   # one vectorised pass per chunk
             for k, i in enumerate(chunk.line_ids):
                 w = lines[i].shape[1]
                 first, last = pad // sub, (pad + w) // sub
@@ -139,7 +134,26 @@ class BaseEngineLineOCR:
                     coords_out[i] = [first, last]
                 if sparse_logits:
                     pp = probs[k][first:last] if tight_crop_logits else probs[k]
-                    ll = np.where(pp < SPARSE_PROB_THRESHOLD, np.float32(0), ll)
-                    ll = sparse.csc_matrix(ll)
+                    ll = sparse.csc_matrix(np.where(pp < SPARSE_PROB_THRESHOLD, np.float32(0), ll))
                 logits_out[i] = ll
+
+        # One-deep software pipeline over the chunks: chunk k+1 is enqueued on the other engine slot
+        # before chunk k is collected, so its GPU work overlaps chunk k's read-back and the host-side
+        # softmax / CSC assembly.  (The reference runs chunk after chunk, line_ocr_engine.py:80-129;
+        # the chunks are independent, so the results are the same.)
+        pipelined = hasattr(self, "_submit_chunk")
+        pending = None
+        for k, chunk in enumerate(plan_chunks([l.shape[1] for l in lines], self.max_input_horizontal_pixels, pad)):
+            if chunk.max_width + 2 * pad > chunk.w_pad:
+                print(f"WARNING: Line too long for OCR engine. Cropping from {chunk.max_width + 2 * pad} px "
+                      f"down to {chunk.w_pad}.")
+            if not pipelined:
+                scatter(chunk, *self._recognise_chunk(lines, chunk, want_logits=not no_logits))
+                continue
+            handle = self._submit_chunk(lines, chunk, not no_logits, k % 2)
+            if pending is not None:
+                scatter(pending[0], *self._collect_chunk(pending[1]))
+            pending = (chunk, handle)
+        if pending is not None:
+            scatter(pending[0], *self._collect_chunk(pending[1]))
         return transcriptions, logits_out, coords_out

@@ -94,17 +94,29 @@ class PytorchEngineLineOCR(BaseEngineLineOCR):
         logits, _amax, labels, lens = self.model.run_batch(batch_data, want_logits=True, want_argmax=False)
         return labels_to_strings(labels, lens, self.characters), logits
 
-    def _recognise_chunk(self, lines, chunk: Chunk, want_logits: bool):
-        """Ragged path: the crops go to the GPU un-padded; the zero padding of
-        line_ocr_engine.py:121-123 happens inside the first kernel's staging."""
+    def _pack_chunk(self, lines, chunk: Chunk):
         flat = [np.ascontiguousarray(lines[i], dtype=np.uint8).reshape(-1) for i in chunk.line_ids]
         widths = np.array([lines[i].shape[1] for i in chunk.line_ids], dtype=np.int32)
         sizes = np.array([f.size for f in flat], dtype=np.int64)
         offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
         pool = np.concatenate(flat) if flat else np.zeros(0, np.uint8)
-        self.model.stage_lines(pool, offsets, widths, chunk.w_pad, self.line_padding_px)
-        logits, _amax, labels, lens = self.model.run_staged(want_logits=want_logits, want_argmax=False)
+        return pool, offsets, widths
+
+    def _submit_chunk(self, lines, chunk: Chunk, want_logits: bool, slot: int):
+        """Ragged, asynchronous: the crops go to the GPU un-padded (the zero padding of
+        line_ocr_engine.py:121-123 happens inside the first kernel's staging) and the call returns
+        as soon as the chunk is enqueued on the slot's stream."""
+        pool, offsets, widths = self._pack_chunk(lines, chunk)
+        self.model.slot_stage_lines(slot, pool, offsets, widths, chunk.w_pad, self.line_padding_px)
+        self.model.slot_launch(slot, want_logits=want_logits, want_argmax=False)
+        return slot
+
+    def _collect_chunk(self, handle):
+        logits, _amax, labels, lens = self.model.slot_collect(handle)
         return labels_to_strings(labels, lens, self.characters), logits
+
+    def _recognise_chunk(self, lines, chunk: Chunk, want_logits: bool):
+        return self._collect_chunk(self._submit_chunk(lines, chunk, want_logits, 0))
 
     def frame_argmax(self, batch_data) -> np.ndarray:
         """Per-frame class ids [n, T] (what greedy_decode_ctc's torch.argmax sees)."""

@@ -300,3 +300,40 @@ def test_c4_full_batch_matches_reference_golden(golden, tmp_path):
     texts, logits, coords = eng.process_lines(g.crops(), sparse_logits=False)
     flips = _check_against_golden(g, texts, logits, coords, exact_margin=2e-4)
     assert flips <= 3, flips
+
+
+def test_pipelined_slots_match_blocking_calls(small):
+    """stage/launch/collect on both slots (two chunks in flight) == the blocking calls, bit for bit;
+    misuse of the slot protocol is reported, not silently accepted."""
+    spec, weights, eng, net = small
+    crops_a = synth.make_crops(21, [200, 150, 64, 131, 97])
+    crops_b = synth.make_crops(22, [512, 480])
+
+    def pack(crops):
+        pool = np.concatenate([c.reshape(-1) for c in crops])
+        sizes = np.array([c.size for c in crops], dtype=np.int64)
+        return pool, np.concatenate([[0], np.cumsum(sizes)[:-1]]), np.array([c.shape[1] for c in crops], np.int32)
+
+    pa, oa, wa = pack(crops_a)
+    pb, ob, wb = pack(crops_b)
+    eng.stage_lines(pa, oa, wa, 288, 32)
+    ref_a = eng.run_staged()
+    eng.stage_lines(pb, ob, wb, 576, 32)
+    ref_b = eng.run_staged()
+    eng.slot_stage_lines(0, pa, oa, wa, 288, 32)
+    eng.slot_launch(0, want_logits=True, want_argmax=True)
+    eng.slot_stage_lines(1, pb, ob, wb, 576, 32)
+    eng.slot_launch(1, want_logits=True, want_argmax=True)
+    with pytest.raises(RuntimeError, match="in flight"):
+        eng.slot_launch(1)
+    with pytest.raises(RuntimeError, match="in flight"):
+        eng.slot_stage_lines(0, pa, oa, wa, 288, 32)
+    got_a = eng.slot_collect(0)
+    got_b = eng.slot_collect(1)
+    for ref, got in ((ref_a, got_a), (ref_b, got_b)):
+        for r, g in zip(ref, got):
+            assert np.array_equal(r, g)
+    with pytest.raises(RuntimeError, match="nothing in flight"):
+        eng.slot_collect(1)
+    with pytest.raises(RuntimeError, match="out of range"):
+        eng.slot_launch(7)
