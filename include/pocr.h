@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define POCR_ABI_VERSION 3
+#define POCR_ABI_VERSION 4
 #define POCR_NUM_SLOTS 2
 
 typedef struct pocr_engine pocr_engine;
@@ -103,6 +103,24 @@ int pocr_slot_stage_lines(pocr_engine *e, int32_t slot, const uint8_t *crops, co
 int pocr_slot_launch(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t want_argmax);
 int pocr_slot_collect(pocr_engine *e, int32_t slot, float *logits_ntc, int32_t *frame_argmax_nt,
                       int32_t *labels_nt, int32_t *label_len_n);
+
+/* ---- sparse logits: replaces `softmax -> logits[p < 1e-4] = 0 -> scipy.sparse.csc_matrix` per line
+ * (line_ocr_engine.py:168-171, softmax.py:4-46) with device kernels, so only CSC triplets cross PCIe.
+ * pocr_slot_launch_sparse = pocr_slot_launch(no dense logits) + sparsification with `threshold`
+ * (the reference uses 0.0001).  row_begin/row_end (both int32 [n] or both NULL) restrict line i to the
+ * frames [row_begin[i], row_end[i]) - the tight_crop_logits slice of line_ocr_engine.py:146-150; stored
+ * row indices are relative to row_begin[i].
+ * pocr_slot_sparse_nnz waits for the launch and returns the total number of kept entries, so the
+ * caller can size `data` / `indices`.  pocr_slot_collect_sparse then fills:
+ *   line_off [n+1] int64 : entries of line i are data/indices[line_off[i] .. line_off[i+1])
+ *   indptr   [n][C+1]    : CSC column pointers of line i (starting at 0)
+ *   data, indices        : values and row (frame) indices, column-major within a line, rows ascending
+ * i.e. scipy.sparse.csc_matrix((data[a:b], indices[a:b], indptr[i]), shape=(rows_i, C)). */
+int pocr_slot_launch_sparse(pocr_engine *e, int32_t slot, const int32_t *row_begin, const int32_t *row_end,
+                            float threshold, int32_t want_argmax);
+int pocr_slot_sparse_nnz(pocr_engine *e, int32_t slot, int64_t *total_nnz);
+int pocr_slot_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t *indices, int32_t *indptr,
+                             int64_t *line_off, int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n);
 
 /* ---- measurement / test taps (not part of the reference surface) ----
  * Per-stage GPU time of the last pocr_run_* call in milliseconds, measured with HIP

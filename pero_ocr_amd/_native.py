@@ -14,7 +14,7 @@ import numpy as np
 from .netspec import NetSpec
 
 LIB_NAME = "libpocr_hip.so"
-ABI_VERSION = 3
+ABI_VERSION = 4
 STAGE_NAMES = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv8", "conv9",
                "agg", "lstm", "head", "ctc", "total")
 
@@ -52,6 +52,9 @@ SYMBOLS = {
     "pocr_slot_launch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pocr_slot_collect": (C.c_int, [C.c_void_p, C.c_int32, _f32p, _i32p, _i32p, _i32p]),
     "pocr_slot_stage_ms": (C.c_int, [C.c_void_p, C.c_int32, _f32p, C.c_int32]),
+    "pocr_slot_launch_sparse": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.c_float, C.c_int32]),
+    "pocr_slot_sparse_nnz": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
+    "pocr_slot_collect_sparse": (C.c_int, [C.c_void_p, C.c_int32, _f32p, _i32p, _i32p, _i64p, _i32p, _i32p, _i32p]),
     "pocr_last_stage_ms": (C.c_int, [C.c_void_p, _f32p, C.c_int32]),
     "pocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "pocr_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -190,6 +193,34 @@ class NativeEngine:
         if rc:
             raise RuntimeError("pocr_slot_collect: " + self._err())
         return logits, amax, labels, lens
+
+    def slot_launch_sparse(self, slot: int, row_begin=None, row_end=None, threshold: float = 1e-4, want_argmax=False):
+        """Like slot_launch without dense logits, plus on-device softmax/threshold/CSC compaction."""
+        rb = None if row_begin is None else np.ascontiguousarray(row_begin, dtype=np.int32)
+        re_ = None if row_end is None else np.ascontiguousarray(row_end, dtype=np.int32)
+        if self._lib.pocr_slot_launch_sparse(self._h, int(slot), _ptr(rb, _i32p), _ptr(re_, _i32p), float(threshold),
+                                             1 if want_argmax else 0):
+            raise RuntimeError("pocr_slot_launch_sparse: " + self._err())
+        n, T, _a, _b = self._slot_shape[slot]
+        self._slot_shape[slot] = (n, T, False, bool(want_argmax))
+
+    def slot_collect_sparse(self, slot: int):
+        """-> (data f32 [nnz], indices i32 [nnz], indptr i32 [n, C+1], line_off i64 [n+1], argmax|None, labels, lens)"""
+        n, T, _wl, want_argmax = self._slot_shape[slot]
+        total = C.c_int64(0)
+        if self._lib.pocr_slot_sparse_nnz(self._h, int(slot), C.byref(total)):
+            raise RuntimeError("pocr_slot_sparse_nnz: " + self._err())
+        data = np.empty(max(1, total.value), dtype=np.float32)
+        indices = np.empty(max(1, total.value), dtype=np.int32)
+        indptr = np.empty((n, self.spec.num_classes + 1), dtype=np.int32)
+        line_off = np.empty(n + 1, dtype=np.int64)
+        _lg, amax, labels, lens = self._alloc_out(n, T, False, want_argmax)
+        rc = self._lib.pocr_slot_collect_sparse(self._h, int(slot), _ptr(data, _f32p), _ptr(indices, _i32p),
+                                                _ptr(indptr, _i32p), _ptr(line_off, _i64p), _ptr(amax, _i32p),
+                                                _ptr(labels, _i32p), _ptr(lens, _i32p))
+        if rc:
+            raise RuntimeError("pocr_slot_collect_sparse: " + self._err())
+        return data[:total.value], indices[:total.value], indptr, line_off, amax, labels, lens
 
     def slot_stage_ms(self, slot: int) -> dict:
         buf = np.zeros(len(STAGE_NAMES), dtype=np.float32)

@@ -15,6 +15,7 @@
 #include "ctc.hpp"
 #include "encoder.hpp"
 #include "lstm.hpp"
+#include "sparsify.hpp"
 
 using namespace pocr;
 
@@ -144,6 +145,13 @@ struct Slot {
     // host pinned staging for the outputs
     void *pinned = nullptr;
     size_t pinned_cap = 0;
+    // device-side CSC sparsification of the logits (sparsify.hpp)
+    bool want_sparse = false;
+    float sp_thr = 1e-4f;
+    DevBuf sp_rowstat, sp_colcount, sp_line_nnz, sp_line_off, sp_indptr, sp_data, sp_indices, sp_rows;
+    bool sp_has_rows = false;
+    void *sp_pinned = nullptr;       // [line_off (n+1) int64 | indptr n*(C+1) int32] then data | indices at collect time
+    size_t sp_pinned_cap = 0;
     // profiling
     hipEvent_t ev[POCR_NUM_STAGES + 1]{};
     float stage_ms[POCR_NUM_STAGES]{};
@@ -411,6 +419,36 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
     if (s.want_argmax) HIP_TRY(hipMemcpyAsync(pin + nt_bytes, s.best.p, nt_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(pin + 2 * nt_bytes, s.lens.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (lg_bytes) HIP_TRY(hipMemcpyAsync(pin + 2 * nt_bytes + (size_t)round_up(n, 4) * sizeof(int32_t), s.logits.p, lg_bytes, hipMemcpyDeviceToHost, st));
+    if (s.want_sparse) {
+        if (T > SP_MAXT) return fail("sparse logits: T = %d exceeds %d frames", T, SP_MAXT);
+        if (C > 256 * SP_COLS) return fail("sparse logits: C = %d exceeds %d classes", C, 256 * SP_COLS);
+        const size_t cap = (size_t)n * T * C;
+        if (s.sp_rowstat.reserve((size_t)n * T * 2 * sizeof(float)) || s.sp_colcount.reserve((size_t)n * C * sizeof(int32_t)) ||
+            s.sp_line_nnz.reserve((size_t)n * sizeof(int32_t)) || s.sp_line_off.reserve((size_t)(n + 1) * sizeof(int64_t)) ||
+            s.sp_indptr.reserve((size_t)n * (C + 1) * sizeof(int32_t)) || s.sp_data.reserve(cap * sizeof(float)) ||
+            s.sp_indices.reserve(cap * sizeof(int32_t)))
+            return 1;
+        const int32_t *r0 = s.sp_has_rows ? s.sp_rows.as<int32_t>() : nullptr;
+        const int32_t *r1 = s.sp_has_rows ? s.sp_rows.as<int32_t>() + n : nullptr;
+        hipLaunchKernelGGL(sparse_count_kernel, dim3(n), dim3(256), 0, st, s.logits.as<float>(), r0, r1, s.sp_rowstat.as<float>(),
+                           s.sp_colcount.as<int32_t>(), s.sp_line_nnz.as<int32_t>(), T, C, s.sp_thr);
+        hipLaunchKernelGGL(sparse_scan_kernel, dim3(1), dim3(64), 0, st, s.sp_line_nnz.as<int32_t>(), s.sp_line_off.as<int64_t>(), n);
+        hipLaunchKernelGGL(sparse_fill_kernel, dim3(n), dim3(256), 0, st, s.logits.as<float>(), r0, r1, s.sp_rowstat.as<float>(),
+                           s.sp_colcount.as<int32_t>(), s.sp_line_off.as<int64_t>(), s.sp_indptr.as<int32_t>(), s.sp_data.as<float>(),
+                           s.sp_indices.as<int32_t>(), T, C, s.sp_thr, (int64_t)cap);
+        HIP_TRY(hipGetLastError());
+        const size_t off_bytes = (size_t)(n + 1) * sizeof(int64_t), ip_bytes = (size_t)n * (C + 1) * sizeof(int32_t);
+        const size_t need_sp = off_bytes + ip_bytes + cap / 4 * 8;     // room for 25 % density before a re-allocation
+        if (need_sp > s.sp_pinned_cap) {
+            if (s.sp_pinned) (void)hipHostFree(s.sp_pinned);
+            s.sp_pinned = nullptr; s.sp_pinned_cap = 0;
+            HIP_TRY(hipHostMalloc(&s.sp_pinned, need_sp, hipHostMallocDefault));
+            s.sp_pinned_cap = need_sp;
+        }
+        char *sp = static_cast<char *>(s.sp_pinned);
+        HIP_TRY(hipMemcpyAsync(sp, s.sp_line_off.p, off_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(sp + off_bytes, s.sp_indptr.p, ip_bytes, hipMemcpyDeviceToHost, st));
+    }
     return 0;
 }
 
@@ -639,9 +677,11 @@ void pocr_destroy(pocr_engine *e) {
         for (auto &v : {&s.lstm_y, &s.sa_y})
             for (auto &b : *v) b.release();
         for (DevBuf *b : {&s.crops, &s.lines, &s.feat, &s.xproj, &s.hbuf, &s.cbuf, &s.logits, &s.best, &s.labels, &s.lens,
-                          &s.sa_x, &s.sa_x1, &s.sa_qkv, &s.sa_att, &s.sa_tmp, &s.sa_ff})
+                          &s.sa_x, &s.sa_x1, &s.sa_qkv, &s.sa_att, &s.sa_tmp, &s.sa_ff, &s.sp_rowstat, &s.sp_colcount,
+                          &s.sp_line_nnz, &s.sp_line_off, &s.sp_indptr, &s.sp_data, &s.sp_indices, &s.sp_rows})
             b->release();
         if (s.pinned) (void)hipHostFree(s.pinned);
+        if (s.sp_pinned) (void)hipHostFree(s.sp_pinned);
         if (s.host_in) (void)hipHostFree(s.host_in);
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);
@@ -703,6 +743,7 @@ int pocr_slot_launch(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t 
     HIP_TRY(hipSetDevice(e->device));
     s.want_logits = want_logits != 0;
     s.want_argmax = want_argmax != 0;
+    s.want_sparse = false;
     if (run_network(e, s)) return 1;
     if (enqueue_outputs(e, s)) return 1;
     s.in_flight = true;
@@ -717,6 +758,70 @@ int pocr_slot_collect(pocr_engine *e, int32_t slot, float *logits_ntc, int32_t *
     if (!s.in_flight) return fail("slot %d has nothing in flight", slot);
     HIP_TRY(hipSetDevice(e->device));
     return collect_outputs(e, s, logits_ntc, frame_argmax_nt, labels_nt, label_len_n);
+}
+
+int pocr_slot_launch_sparse(pocr_engine *e, int32_t slot, const int32_t *row_begin, const int32_t *row_end,
+                            float threshold, int32_t want_argmax) {
+    if (check_slot(e, slot)) return 1;
+    Slot &s = e->slot[slot];
+    if (!s.staged) return fail("slot %d: no chunk staged", slot);
+    if (s.in_flight) return fail("slot %d already has a launch in flight", slot);
+    if ((row_begin == nullptr) != (row_end == nullptr)) return fail("row_begin and row_end must both be given or both be NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    const int T = (s.w_pad / 2) / 2;
+    s.sp_has_rows = row_begin != nullptr;
+    if (s.sp_has_rows) {
+        std::vector<int32_t> rows(2 * (size_t)s.n);
+        for (int i = 0; i < s.n; ++i) {
+            if (row_begin[i] < 0 || row_end[i] > T || row_begin[i] > row_end[i])
+                return fail("line %d: row range [%d, %d) outside [0, %d]", i, row_begin[i], row_end[i], T);
+            rows[i] = row_begin[i]; rows[s.n + i] = row_end[i];
+        }
+        if (s.sp_rows.reserve(rows.size() * sizeof(int32_t))) return 1;
+        HIP_TRY(hipMemcpyAsync(s.sp_rows.p, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(hipStreamSynchronize(s.stream));       // `rows` is a stack-lifetime pageable buffer
+    }
+    s.want_logits = false;
+    s.want_argmax = want_argmax != 0;
+    s.want_sparse = true;
+    s.sp_thr = threshold;
+    if (run_network(e, s)) return 1;
+    if (enqueue_outputs(e, s)) return 1;
+    s.in_flight = true;
+    e->last_slot = slot;
+    return 0;
+}
+
+int pocr_slot_sparse_nnz(pocr_engine *e, int32_t slot, int64_t *total_nnz) {
+    if (check_slot(e, slot)) return 1;
+    Slot &s = e->slot[slot];
+    if (!s.in_flight || !s.want_sparse) return fail("slot %d has no sparse launch in flight", slot);
+    if (!total_nnz) return fail("total_nnz is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(s.seq_stream));
+    *total_nnz = static_cast<const int64_t *>(s.sp_pinned)[s.n];
+    return 0;
+}
+
+int pocr_slot_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t *indices, int32_t *indptr,
+                             int64_t *line_off, int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n) {
+    if (check_slot(e, slot)) return 1;
+    Slot &s = e->slot[slot];
+    if (!s.in_flight || !s.want_sparse) return fail("slot %d has no sparse launch in flight", slot);
+    if (!data || !indices || !indptr || !line_off) return fail("NULL output pointer");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(s.seq_stream));
+    const int n = s.n, C = e->cfg.num_classes;
+    const size_t off_bytes = (size_t)(n + 1) * sizeof(int64_t), ip_bytes = (size_t)n * (C + 1) * sizeof(int32_t);
+    const char *sp = static_cast<const char *>(s.sp_pinned);
+    const int64_t total = reinterpret_cast<const int64_t *>(sp)[n];
+    memcpy(line_off, sp, off_bytes);
+    memcpy(indptr, sp + off_bytes, ip_bytes);
+    if (total > 0) {     // the triplets: exact size is known only now
+        HIP_TRY(hipMemcpyAsync(data, s.sp_data.p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, s.seq_stream));
+        HIP_TRY(hipMemcpyAsync(indices, s.sp_indices.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, s.seq_stream));
+    }
+    return collect_outputs(e, s, nullptr, frame_argmax_nt, labels_nt, label_len_n);
 }
 
 int pocr_stage_lines(pocr_engine *e, const uint8_t *crops, const int64_t *crop_offsets, const int32_t *widths,

@@ -117,10 +117,18 @@ class BaseEngineLineOCR:
         sub = int(self.net_subsampling)
         pad = int(self.line_padding_px)
 
+        device_sparse = sparse_logits and not no_logits and getattr(self, "supports_device_sparsify", False)
+
         def scatter(chunk, texts, chunk_logits):
             for k, i in enumerate(chunk.line_ids):
                 transcriptions[i] = texts[k]
             if no_logits:
+                return
+            if device_sparse:           # chunk_logits is already a list of csc_matrix (built on the GPU)
+                for k, i in enumerate(chunk.line_ids):
+                    w = lines[i].shape[1]
+                    coords_out[i] = [None, None] if tight_crop_logits else [pad // sub, (pad + w) // sub]
+                    logits_out[i] = chunk_logits[k]
                 return
             probs = softmax(chunk_logits, axis=2) if sparse_logits else None   # one vectorised pass per chunk
             for k, i in enumerate(chunk.line_ids):
@@ -150,7 +158,14 @@ class BaseEngineLineOCR:
             if not pipelined:
                 scatter(chunk, *self._recognise_chunk(lines, chunk, want_logits=not no_logits))
                 continue
-            handle = self._submit_chunk(lines, chunk, not no_logits, k % 2)
+            rows = None
+            if device_sparse:
+                rows = (None, None)
+                if tight_crop_logits:
+                    ws = [lines[i].shape[1] for i in chunk.line_ids]
+                    rows = ([min(pad // sub, chunk.frames)] * len(ws), [min((pad + w) // sub, chunk.frames) for w in ws])
+            handle = self._submit_chunk(lines, chunk, not no_logits, k % 2, rows) if device_sparse else \
+                self._submit_chunk(lines, chunk, not no_logits, k % 2)
             if pending is not None:
                 scatter(pending[0], *self._collect_chunk(pending[1]))
             pending = (chunk, handle)

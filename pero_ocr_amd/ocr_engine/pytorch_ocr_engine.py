@@ -29,7 +29,9 @@ from typing import List, Tuple
 import numpy as np
 
 from .. import _native, netspec
-from .line_ocr_engine import BaseEngineLineOCR, Chunk
+from scipy import sparse
+
+from .line_ocr_engine import BaseEngineLineOCR, Chunk, SPARSE_PROB_THRESHOLD
 
 BLANK_PLACEHOLDER = "\u200B"      # pytorch_ocr_engine.py:42
 
@@ -102,21 +104,41 @@ class PytorchEngineLineOCR(BaseEngineLineOCR):
         pool = np.concatenate(flat) if flat else np.zeros(0, np.uint8)
         return pool, offsets, widths
 
-    def _submit_chunk(self, lines, chunk: Chunk, want_logits: bool, slot: int):
+    def _submit_chunk(self, lines, chunk: Chunk, want_logits: bool, slot: int, sparse_rows=None):
         """Ragged, asynchronous: the crops go to the GPU un-padded (the zero padding of
         line_ocr_engine.py:121-123 happens inside the first kernel's staging) and the call returns
-        as soon as the chunk is enqueued on the slot's stream."""
+        as soon as the chunk is enqueued on the slot's stream.  sparse_rows = None: dense logits (if
+        wanted); sparse_rows = (row_begin, row_end) or (None, None): the softmax / p < 1e-4 / CSC step
+        of line_ocr_engine.py:168-171 runs on the GPU and only CSC triplets come back."""
         pool, offsets, widths = self._pack_chunk(lines, chunk)
         self.model.slot_stage_lines(slot, pool, offsets, widths, chunk.w_pad, self.line_padding_px)
+        if sparse_rows is not None and want_logits:
+            self.model.slot_launch_sparse(slot, sparse_rows[0], sparse_rows[1], SPARSE_PROB_THRESHOLD)
+            return ("sparse", slot, sparse_rows)
         self.model.slot_launch(slot, want_logits=want_logits, want_argmax=False)
-        return slot
+        return ("dense", slot, None)
 
     def _collect_chunk(self, handle):
-        logits, _amax, labels, lens = self.model.slot_collect(handle)
-        return labels_to_strings(labels, lens, self.characters), logits
+        kind, slot, rows = handle
+        if kind == "dense":
+            logits, _amax, labels, lens = self.model.slot_collect(slot)
+            return labels_to_strings(labels, lens, self.characters), logits
+        data, indices, indptr, line_off, _amax, labels, lens = self.model.slot_collect_sparse(slot)
+        n, C = indptr.shape[0], indptr.shape[1] - 1
+        mats = []
+        for i in range(n):
+            a, b = int(line_off[i]), int(line_off[i + 1])
+            nrows = (int(rows[1][i]) - int(rows[0][i])) if rows[0] is not None else self._slot_frames(slot)
+            mats.append(sparse.csc_matrix((data[a:b], indices[a:b], indptr[i]), shape=(nrows, C)))
+        return labels_to_strings(labels, lens, self.characters), mats
+
+    def _slot_frames(self, slot):
+        return self.model._slot_shape[slot][1]
 
     def _recognise_chunk(self, lines, chunk: Chunk, want_logits: bool):
         return self._collect_chunk(self._submit_chunk(lines, chunk, want_logits, 0))
+
+    supports_device_sparsify = True
 
     def frame_argmax(self, batch_data) -> np.ndarray:
         """Per-frame class ids [n, T] (what greedy_decode_ctc's torch.argmax sees)."""

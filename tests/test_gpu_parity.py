@@ -337,3 +337,59 @@ def test_pipelined_slots_match_blocking_calls(small):
         eng.slot_collect(1)
     with pytest.raises(RuntimeError, match="out of range"):
         eng.slot_launch(7)
+
+
+def test_sharded_page_stream_matches_single_engine(golden, tmp_path):
+    """BASELINE config 3 shape (seeded width distribution 128..1024, chunk-sharded) on ONE rank:
+    ShardedLineOCR (chunk assignment + label all-gather through torch.distributed) must return exactly
+    what the plain engine returns for the same page stream, and every chunk keeps the reference plan."""
+    import os
+    import torch.distributed as dist
+    from pero_ocr_amd import sharding
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    g = golden("c1")
+    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=32)
+    widths = synth.make_widths(3, 384)
+    lines = synth.make_crops(9, widths)
+    expect, _l, _c = eng.process_lines(lines, no_logits=True)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        sh = sharding.ShardedLineOCR(sharding.engine_recogniser(eng), eng.characters, eng.max_input_horizontal_pixels)
+        got = sh.process_lines(lines)
+    finally:
+        dist.destroy_process_group()
+    assert got == expect
+    assert sum(len(t) for t in got) > 0
+
+
+def test_device_sparsify_equals_host_sparsify(golden, tmp_path):
+    """The on-GPU softmax / p < 1e-4 / CSC compaction (line_ocr_engine.py:168-171) against the same rule
+    applied on the host to the engine's own dense logits: identical values and structure except
+    entries whose probability sits within 1e-7 of the threshold; canonical CSC; tight-crop row ranges."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    from pero_ocr_amd.ocr_engine.softmax import softmax
+    g = golden("ragged")
+    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=g.batch_size)
+    crops = g.crops()
+    for tight in (False, True):
+        _t, dense, _c = eng.process_lines(crops, sparse_logits=False, tight_crop_logits=tight)
+        texts, sp, coords = eng.process_lines(crops, tight_crop_logits=tight)
+        assert texts == g.transcriptions
+        for i in range(g.n):
+            d = np.asarray(dense[i])
+            m = sp[i]
+            assert m.format == "csc" and m.dtype == np.float32 and m.shape == d.shape
+            assert m.has_sorted_indices and m.indptr[0] == 0 and m.indptr[-1] == m.nnz
+            if d.shape[0] == 0:
+                assert m.nnz == 0
+                continue
+            p = softmax(d, axis=1)
+            ref = np.where(p < 1e-4, np.float32(0), d)
+            borderline = np.abs(p - 1e-4) < 1e-7
+            got = m.toarray()
+            assert np.array_equal(got[~borderline], ref[~borderline]), f"line {i} tight={tight}"
+        if not tight:
+            assert coords == g.logit_coords
+            for i in range(g.n):
+                assert abs(int(sp[i].nnz) - g.nnz_sparse[i]) <= max(2, g.nnz_sparse[i] // 200)

@@ -57,6 +57,7 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+@pytest.mark.timeout(600)
 def test_gloo_world2_allgather_labels(tmp_path):
     import torch.multiprocessing as mp
     s = socket.socket()
