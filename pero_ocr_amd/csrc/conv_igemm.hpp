@@ -57,6 +57,17 @@ struct ConvArgs {
     int32_t tiles_w, tiles_h, tiles_n;
 };
 
+// number of workgroups for a conv launch (must match the block -> tile mapping in the kernel)
+inline size_t conv_grid_blocks(const ConvArgs &a) {
+    const size_t P = (size_t)a.tiles_w * a.tiles_h * a.n;
+    const int tn = a.tiles_n;
+    if (tn >= 2 && tn <= 8 && (tn & (tn - 1)) == 0) {
+        const size_t groups = 8 / tn;
+        return (P + groups - 1) / groups * 8;
+    }
+    return P * tn;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == ACT_LEAKY) return v > 0.f ? v : v * 0.01f;
@@ -64,7 +75,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 template <int KH, int KW, int PADH, int PADW, int TH, int MW, int NS, int NWAVE, int KC,
-          int POOLH, int POOLW, int ACT, bool BN, int STAGER, int PIPE = 0>
+          int POOLH, int POOLW, int ACT, bool BN, int STAGER, int PIPE = 0, int ABL3 = 0>
 __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
     constexpr int TW = 16 * MW;
     constexpr int MS = TH * MW;                 // 16-pixel row-tiles per workgroup (every wave holds all of them)
@@ -94,19 +105,33 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
     const int wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
 
-    // tile coordinates: ntile fastest so the workgroups sharing one input tile are neighbours, and an
-    // XCD-aware remap of the block id: block b is dispatched to XCD b % 8 (each XCD has its own L2),
-    // so every XCD gets a contiguous range of logical tiles and the re-reads of a halo tile (by the
-    // other N-tiles and by the neighbouring column tiles) hit that XCD's L2 instead of HBM.
-    int b = blockIdx.x;
+    // Block -> tile mapping, XCD-aware.  Block b is dispatched to XCD b % 8 and every XCD has its own
+    // 4 MiB L2.  (a) When the layer has 2, 4 or 8 output-channel tiles, each XCD works on ONE of them
+    // (nt = xcd % tiles_n): the weight stream an XCD re-reads for every pixel tile is 1/tiles_n of the
+    // layer's weights and stays L2-resident (conv9: 9.4 MB of weights, 2.4 MB per XCD at NT = 128).
+    // With 16 KB weight tiles needed every ~2.6 us by every workgroup, an L2 miss on that stream
+    // (2-4 us from HBM/MALL) stalls the whole workgroup at the next barrier.  (b) Otherwise each XCD
+    // gets a contiguous range of logical tiles so halo re-reads hit its L2.
+    int nt, ptile;
     {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
-        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        const int tn = a.tiles_n;
+        const int P = a.tiles_w * a.tiles_h * a.n;
+        if (tn >= 2 && tn <= 8 && (tn & (tn - 1)) == 0) {
+            const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, groups = 8 / tn;
+            nt = xcd % tn;
+            ptile = k * groups + xcd / tn;
+            if (ptile >= P) return;                 // grid is padded to a multiple of 8 (whole block leaves)
+        } else {
+            int b = blockIdx.x;
+            const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
+            b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+            nt = b % tn;
+            ptile = b / tn;
+        }
     }
-    const int nt = b % a.tiles_n; b /= a.tiles_n;
-    const int wt = b % a.tiles_w; b /= a.tiles_w;
-    const int ht = b % a.tiles_h; b /= a.tiles_h;
-    const int img = b;
+    const int wt = ptile % a.tiles_w;
+    const int ht = (ptile / a.tiles_w) % a.tiles_h;
+    const int img = ptile / (a.tiles_w * a.tiles_h);
     const int h0 = ht * TH, w0 = wt * TW;
 
     f32x4 acc[MS][NS];
@@ -268,7 +293,8 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
         if (newA) abuf ^= 1;
         tap = ntap; chunk = nchunk;
     }
-    } else if constexpr (PIPE == 3) {
+    } else if constexpr (PIPE == 3 || PIPE == 4) {
+    constexpr bool DEEP = PIPE == 4;     // weight tile s+2 is requested right after tile s+1 has been written to LDS
     // ------------------------------------------------------------------ interleaved two-stage pipeline
     // Same LDS double buffering as PIPE 0, but (a) the tap loop is fully unrolled inside a runtime
     // chunk loop, so tap offsets are immediates and the per-step scalar bookkeeping disappears,
@@ -278,7 +304,10 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
     static_assert(KG == 1, "PIPE 3 is written for KC == 16");
     static_assert(STAGER == STAGE_F32_NHWC, "PIPE 3 stages fp32 NHWC input");
     constexpr int NMFMA = 4 * MS * NS;
-    constexpr int NSLOT = 16;                               // issue slots per step
+    // issue slots per step: the largest of 16, 12, 10, 8 that divides the MFMA count and leaves
+    // separate halves for the loads (first half) and the LDS writes (second half)
+    constexpr int NSLOT = (NMFMA % 16 == 0 && B_LD + A_LD <= 8) ? 16 : (NMFMA % 12 == 0 && B_LD + A_LD <= 6) ? 12
+                        : (NMFMA % 10 == 0 && B_LD + A_LD <= 5) ? 10 : 8;
     constexpr int STRIDE = NMFMA / NSLOT;                   // MFMAs between slots
     static_assert(NMFMA % NSLOT == 0 && B_LD + A_LD <= NSLOT / 2, "slot plan does not fit");
     // per-thread constant parts of the staging addresses
@@ -319,8 +348,22 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
     for (int r = 0; r < A_LD; ++r) stA(r, 0);
 #pragma unroll
     for (int r = 0; r < B_LD; ++r) stB(r, 0);
+    if constexpr (DEEP) {
+        if (nsteps > 1) {
+            const f32x4 *t1 = NTAPS > 1 ? wf4 + tap_stride : wf4 + chunk_stride;
+#pragma unroll
+            for (int r = 0; r < B_LD; ++r) ldB(r, t1);
+        }
+    }
     __syncthreads();
 
+    f32x4 abl_a3[MS], abl_b3[NS];
+    if constexpr (ABL3 & 4) {
+#pragma unroll
+        for (int m = 0; m < MS; ++m) abl_a3[m] = ldsA[li + kq * NPPAD + (m / MW) * HW + (m % MW) * 16];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) abl_b3[n] = ldsB[(wave * NS + n) * 64 + lane];
+    }
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int abuf = chunk & 1;
         const int par = (NTAPS & 1) ? (chunk & 1) : 0;      // parity of the global step index at tap 0
@@ -331,6 +374,10 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
             const bool more = !last || next_chunk;          // is there a step after this one?
             const int bcur = (tap & 1) ^ par, bnext = bcur ^ 1;
             const f32x4 *tile = wf4 + (size_t)(last ? 0 : tap + 1) * tap_stride + (size_t)(last ? chunk + 1 : chunk) * chunk_stride;
+            // DEEP: the tile two steps ahead (requested in this step's late slots, right after the writes of tile s+1)
+            const int tap2 = (tap + 2) % NTAPS, adv2 = (tap + 2) / NTAPS;
+            const bool more2 = chunk + adv2 < nchunks;
+            const f32x4 *tile2 = wf4 + (size_t)tap2 * tap_stride + (size_t)(chunk + adv2) * chunk_stride;
             const bool ldA_now = (NTAPS == 1 ? next_chunk : (tap == 0 && next_chunk));   // request the next halo tile early
             const bool stA_now = last && next_chunk;
 
@@ -338,10 +385,17 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
             const f32x4 *Ab = ldsA + abuf * A_F4 + dy * HW + dx + li + kq * NPPAD;
             const f32x4 *Bb = ldsB + bcur * B_F4 + (wave * NS) * 64 + lane;
             f32x4 af[MS], bf[NS];
+            if constexpr (ABL3 & 4) {     // ablation (tools/conv_bench only): operands from fixed LDS addresses, hoistable
+#pragma unroll
+                for (int m = 0; m < MS; ++m) af[m] = abl_a3[m];
+#pragma unroll
+                for (int n = 0; n < NS; ++n) bf[n] = abl_b3[n];
+            } else {
 #pragma unroll
             for (int m = 0; m < MS; ++m) af[m] = Ab[(m / MW) * HW + (m % MW) * 16];
 #pragma unroll
             for (int n = 0; n < NS; ++n) bf[n] = Bb[n * 64];
+            }
 #pragma unroll
             for (int q = 0; q < NMFMA; ++q) {
                 const int j = q / (MS * NS), m = (q / NS) % MS, n = q % NS;
@@ -349,15 +403,28 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
                 if ((q + 1) % STRIDE == 0) {
                     const int slot = (q + 1) / STRIDE - 1;
                     __builtin_amdgcn_sched_barrier(0);
-                    if (slot < B_LD) { if (more) ldB(slot, tile); }
-                    else if (slot < B_LD + A_LD) { if (ldA_now) ldA(slot - B_LD, chunk + 1); }
+                    if constexpr (!(ABL3 & 1)) {
+                        if (slot < B_LD) { if constexpr (!DEEP) { if (more) ldB(slot, tile); } }
+                        else if (slot < B_LD + A_LD) { if (ldA_now) ldA(slot - B_LD, chunk + 1); }
+                    }
                     const int sslot = slot - (NSLOT - B_LD - A_LD);
-                    if (sslot >= 0 && sslot < B_LD) { if (more) stB(sslot, bnext); }
-                    else if (sslot >= B_LD) { if (stA_now) stA(sslot - B_LD, abuf ^ 1); }
+                    if constexpr (!(ABL3 & 2)) {
+                        if (sslot >= 0 && sslot < B_LD) {
+                            if (more) stB(sslot, bnext);
+                            if constexpr (DEEP) { if (more2) ldB(sslot, tile2); }
+                        }
+                        else if (sslot >= B_LD) { if (stA_now) stA(sslot - B_LD, abuf ^ 1); }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            __syncthreads();
+            if constexpr (ABL3 & 16) {      // ablation: loads kept alive, consumed (waited for) only at the very end of the step
+#pragma unroll
+                for (int r = 0; r < B_LD; ++r) asm volatile("" ::"v"(rb[r]));
+#pragma unroll
+                for (int r = 0; r < A_LD; ++r) asm volatile("" ::"v"(ra[r]));
+            }
+            if constexpr (!(ABL3 & 8)) __syncthreads();
         }
     }
     } else {

@@ -86,7 +86,7 @@ int launch_conv(Kern kern, int TH, int TW, int NT, int nthreads, ConvArgs a, hip
     a.tiles_w = (a.Wo + TW - 1) / TW;
     a.tiles_h = (a.Ho + TH - 1) / TH;
     a.tiles_n = (a.cout16 * 16) / NT;
-    const size_t blocks = (size_t)a.tiles_w * a.tiles_h * a.tiles_n * a.n;
+    const size_t blocks = conv_grid_blocks(a);
     if (blocks == 0) return 0;
     if (blocks > 0x7fffffffull) return fail("conv grid too large (%zu blocks)", blocks);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(nthreads), 0, st, a);

@@ -20,7 +20,7 @@ struct Shape { int cin, cout, H, W, ph, pw, act; bool bn; };
 template <class K>
 static void launch(K kern, int TH, int TW, int NT, int nthr, ConvArgs a, hipStream_t st) {
     a.tiles_w = (a.Wo + TW - 1) / TW; a.tiles_h = (a.Ho + TH - 1) / TH; a.tiles_n = (a.cout16 * 16) / NT;
-    size_t blocks = (size_t)a.tiles_w * a.tiles_h * a.tiles_n * a.n;
+    size_t blocks = conv_grid_blocks(a);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(nthr), 0, st, a);
 }
 
@@ -57,10 +57,24 @@ VARP(h5_abl16,    5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 24)
 VARP(h5_abl32,    5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 40)
 VARP(h5_abl7,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 15)
 VARP(h5_pipe3,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 3)
+VARP(h5_pipe4,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 4)
+VARP(h5_pipe4_nt128, 5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, 4)
+VARP(h10_pipe4,    10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, 4)
+VARP(p22_pipe4,    4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, 4)
+VARP(p22_pipe4_nt64, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, 4)
+VARP(h20_pipe4,    4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, 4)
+VARP(h5_pipe3_nt128, 5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, 3)
+VARP(h5_pipe3_nt64,  5, 1, 1, 4, 16, 1, 1, ACT_LEAKY, true, 3)
+VARP(h5_pipe3_nw8,   5, 1, 1, 8, 16, 1, 1, ACT_LEAKY, true, 3)
 VARP(h10_pipe3,    10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, 3)
 VARP(h20_pipe3,    4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, 3)
 VARP(p22_pipe3,    4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, 3)
 VARP(p22_pipe3_nt64, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, 3)
+#define VARA(NAME, ABL)                                                                                              \
+    static void NAME(ConvArgs a, hipStream_t st) {                                                                 \
+        launch(conv_igemm_kernel<3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, STAGE_F32_NHWC, 3, ABL>, 5, 16, 256, 256, a, st); \
+    }
+VARA(p3_a1, 1) VARA(p3_a2, 2) VARA(p3_a3, 3) VARA(p3_a4, 4) VARA(p3_a7, 7) VARA(p3_a8, 8) VARA(p3_a15, 15) VARA(p3_a18, 18)
 // conv8/9-shaped (H=5): pool none
 VAR(h5_base,      5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true)
 VAR(h5_kc32_nt128,5, 1, 2, 4, 32, 1, 1, ACT_LEAKY, true)
@@ -102,7 +116,11 @@ int main(int argc, char **argv) {
                             {"TH5 MW1 NS2 NW4 KC16 NT128", h5_nt128, 128}, {"TH5 MW2 NS2 NW4 KC16 NT128", h5_mw2_nt128, 128},
                             {"TH5 MW1 NS4 NW4 KC32", h5_kc32, 256},
                             {"PIPE1 TH5 MW1 NS4 NW4 KC16", h5_pipe1, 256}, {"PIPE1 TH5 MW1 NS2 NW4 NT128", h5_pipe1_nt128, 128},
-                            {"PIPE2 TH5 MW1 NS4 NW4", h5_pipe2, 256}, {"PIPE3 TH5 MW1 NS4 NW4", h5_pipe3, 256},
+                            {"PIPE2 TH5 MW1 NS4 NW4", h5_pipe2, 256}, {"PIPE3 TH5 MW1 NS4 NW4", h5_pipe3, 256}, {"PIPE4 TH5 MW1 NS4 NW4", h5_pipe4, 256}, {"PIPE4 TH5 MW1 NS2 NW4 NT128", h5_pipe4_nt128, 128}, {"PIPE3 TH5 MW1 NS2 NW4 NT128", h5_pipe3_nt128, 128},
+                            {"PIPE3 TH5 MW1 NS1 NW4 NT64", h5_pipe3_nt64, 64}, {"PIPE3 TH5 MW1 NS1 NW8 NT128", h5_pipe3_nw8, 128},
+                            {"P3ABL no-loads", p3_a1, 256}, {"P3ABL no-stores", p3_a2, 256}, {"P3ABL no-loads/stores", p3_a3, 256},
+                            {"P3ABL no-ds_read", p3_a4, 256}, {"P3ABL no-ld/st/read", p3_a7, 256}, {"P3ABL no-barrier", p3_a8, 256},
+                            {"P3ABL mfma only", p3_a15, 256}, {"P3ABL loads, waited at step end, no stores", p3_a18, 256},
                             {"ABL no-loads/stores", h5_abl1, 256}, {"ABL no-barrier", h5_abl2, 256}, {"ABL no-loads no-barrier", h5_abl3, 256},
                             {"ABL no-ds_read", h5_abl4, 256}, {"ABL no-loads no-ds_read", h5_abl5, 256}, {"ABL mfma only", h5_abl7, 256},
                             {"ABL stores-no-loads", h5_abl16, 256}, {"ABL loads-no-stores", h5_abl32, 256}};
@@ -110,16 +128,17 @@ int main(int argc, char **argv) {
                             {"TH10 MW1 NS1 NW8 KC16", h10_nw8, 128}, {"TH10 MW1 NS2 NW4 KC32", h10_kc32, 128},
                             {"TH5 MW2 NS2 NW4 KC16", h10_th5_mw2, 128},
                             {"PIPE1 TH10 MW1 NS2 NW4", h10_pipe1, 128}, {"PIPE1 TH5 MW1 NS4 NW4", h10_pipe1_th5, 256},
-                            {"PIPE2 TH10 MW1 NS2 NW4", h10_pipe2, 128}, {"PIPE3 TH10 MW1 NS2 NW4", h10_pipe3, 128}};
+                            {"PIPE2 TH10 MW1 NS2 NW4", h10_pipe2, 128}, {"PIPE3 TH10 MW1 NS2 NW4", h10_pipe3, 128}, {"PIPE4 TH10 MW1 NS2 NW4", h10_pipe4, 128}};
     else if (layer == 3) vars = {{"TH4 MW2 NS2 NW4 KC16 (base)", h20_base, 128}, {"TH10 MW1 NS2 NW4", h20_th10, 128},
                             {"TH5 MW1 NS4 NW4 (NT256: cout pad)", h20_th5_ns4, 256}, {"TH4 MW4 NS1 NW4 NT64", h20_th4mw4ns1, 64},
-                            {"PIPE1 TH4 MW2 NS2 NW4", h20_pipe1, 128}, {"PIPE3 TH4 MW2 NS2 NW4", h20_pipe3, 128}};
+                            {"PIPE1 TH4 MW2 NS2 NW4", h20_pipe1, 128}, {"PIPE3 TH4 MW2 NS2 NW4", h20_pipe3, 128}, {"PIPE4 TH4 MW2 NS2 NW4", h20_pipe4, 128}};
     else if (layer == 2 || layer == 4) vars = {{"TH4 MW2 NS2 NW4 KC16 NT128", p22_base, 128}, {"TH10 MW1 NS2 NW4", p22_th10, 128},
                             {"TH4 MW4 NS1 NW4 NT64", p22_th4mw4, 64}, {"TH2 MW4 NS2 NW4 NT128", p22_th2mw4ns2, 128},
                             {"TH4 MW2 NS2 NW4 KC32", p22_kc32, 128},
                             {"PIPE1 TH4 MW2 NS2 NW4 NT128", p22_pipe1, 128}, {"PIPE1 TH4 MW4 NS1 NW4 NT64", p22_pipe1_nt64, 64},
                             {"PIPE2 TH4 MW2 NS2 NW4 NT128", p22_pipe2, 128}, {"PIPE2 TH4 MW4 NS1 NW4 NT64", p22_pipe2_nt64, 64},
-                            {"PIPE3 TH4 MW2 NS2 NW4 NT128", p22_pipe3, 128}, {"PIPE3 TH4 MW4 NS1 NW4 NT64", p22_pipe3_nt64, 64}};
+                            {"PIPE3 TH4 MW2 NS2 NW4 NT128", p22_pipe3, 128}, {"PIPE3 TH4 MW4 NS1 NW4 NT64", p22_pipe3_nt64, 64},
+                            {"PIPE4 TH4 MW2 NS2 NW4 NT128", p22_pipe4, 128}, {"PIPE4 TH4 MW4 NS1 NW4 NT64", p22_pipe4_nt64, 64}};
     else { printf("layer %d not covered\n", layer); return 1; }
 
     const size_t xin = (size_t)n * s.H * s.W * s.cin;
