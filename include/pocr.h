@@ -89,6 +89,12 @@ int pocr_stage_lines(pocr_engine *e, const uint8_t *crops, const int64_t *crop_o
 int pocr_run_staged(pocr_engine *e, float *logits_ntc, int32_t *frame_argmax_nt,
                     int32_t *labels_nt, int32_t *label_len_n);
 
+/* ---- stand-alone greedy CTC decode on the GPU: replaces greedy_decode_ctc(scores_probs, chars)
+ * (pytorch_ocr_engine.py:13-34, 3-D branch) for caller-supplied scores.  logits_ntc: float32 [n, T, C]
+ * (the reference takes [N, C, T]; transpose on the caller's side), blank = C-1.  No engine needed. */
+int pocr_ctc_greedy(int device_id, const float *logits_ntc, int32_t n, int32_t T, int32_t C,
+                    int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n);
+
 /* ---- pipelined chunks (no reference counterpart: the reference runs its chunks strictly one
  * after the other, line_ocr_engine.py:80-129).  An engine has POCR_NUM_SLOTS independent slots, each
  * with its own HIP stream and activation buffers.  stage -> launch -> collect per slot; launch returns

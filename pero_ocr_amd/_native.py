@@ -47,6 +47,7 @@ SYMBOLS = {
     "pocr_run_batch": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, _f32p, _i32p, _i32p, _i32p]),
     "pocr_stage_lines": (C.c_int, [C.c_void_p, _u8p, _i64p, _i32p, C.c_int32, C.c_int32, C.c_int32]),
     "pocr_run_staged": (C.c_int, [C.c_void_p, _f32p, _i32p, _i32p, _i32p]),
+    "pocr_ctc_greedy": (C.c_int, [C.c_int, _f32p, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _i32p]),
     "pocr_num_slots": (C.c_int, []),
     "pocr_slot_stage_lines": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, C.c_int32, C.c_int32, C.c_int32]),
     "pocr_slot_launch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
@@ -243,6 +244,19 @@ class NativeEngine:
         if self._lib.pocr_debug_read(self._h, what, _ptr(out, _f32p), out.size, C.byref(n)):
             raise RuntimeError("pocr_debug_read: " + self._err())
         return out
+
+
+def ctc_greedy(logits_ntc: np.ndarray, device_id: int = 0):
+    """float32 [n, T, C] -> (frame_argmax [n, T], labels [n, T] (-1 padded), lens [n]) on the GPU."""
+    lib = load()
+    x = np.ascontiguousarray(logits_ntc, dtype=np.float32)
+    n, T, Cc = x.shape
+    amax = np.empty((n, T), np.int32)
+    labels = np.empty((n, T), np.int32)
+    lens = np.empty(n, np.int32)
+    if lib.pocr_ctc_greedy(int(device_id), _ptr(x, _f32p), n, T, Cc, _ptr(amax, _i32p), _ptr(labels, _i32p), _ptr(lens, _i32p)):
+        raise RuntimeError("pocr_ctc_greedy: " + (lib.pocr_last_error() or b"").decode("utf8", "replace"))
+    return amax, labels, lens
 
 
 def device_count() -> int:

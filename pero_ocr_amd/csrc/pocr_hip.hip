@@ -849,6 +849,30 @@ int pocr_run_batch(pocr_engine *e, const uint8_t *batch_nhwc, int32_t n, int32_t
     return pocr_run_staged(e, logits_ntc, frame_argmax_nt, labels_nt, label_len_n);
 }
 
+int pocr_ctc_greedy(int device_id, const float *logits_ntc, int32_t n, int32_t T, int32_t C,
+                    int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n) {
+    if (!logits_ntc || !labels_nt || !label_len_n) return fail("NULL pointer");
+    if (n <= 0 || T <= 0 || C < 2) return fail("need n > 0, T > 0, C >= 2 (got %d, %d, %d)", n, T, C);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available: this library has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail("device_id %d out of range (%d devices)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    DevBuf lg, best, lab, len;
+    const size_t nt = (size_t)n * T;
+    int rc = lg.reserve(nt * C * sizeof(float)) || best.reserve(nt * sizeof(int32_t)) || lab.reserve(nt * sizeof(int32_t)) ||
+             len.reserve((size_t)n * sizeof(int32_t));
+    auto done = [&](int r) { lg.release(); best.release(); lab.release(); len.release(); return r; };
+    if (rc) return done(1);
+    if (hipMemcpy(lg.p, logits_ntc, nt * C * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
+    hipLaunchKernelGGL(frame_argmax_kernel, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, 0, lg.as<float>(), best.as<int32_t>(), (int)nt, C);
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(n), dim3(64), 0, 0, best.as<int32_t>(), lab.as<int32_t>(), len.as<int32_t>(), T, C - 1);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return done(fail("CTC kernels failed"));
+    if (frame_argmax_nt && hipMemcpy(frame_argmax_nt, best.p, nt * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    if (hipMemcpy(labels_nt, lab.p, nt * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    if (hipMemcpy(label_len_n, len.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    return done(0);
+}
+
 int pocr_set_profiling(pocr_engine *e, int32_t enabled) {
     if (!e) return fail("engine is NULL");
     e->profiling = enabled != 0;

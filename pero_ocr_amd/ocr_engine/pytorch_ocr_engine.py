@@ -57,6 +57,16 @@ def labels_to_strings(labels: np.ndarray, lens: np.ndarray, characters) -> List[
     return ["".join(characters[c] for c in labels[i, :lens[i]]) for i in range(labels.shape[0])]
 
 
+def greedy_decode_ctc(scores_probs, chars, device_id: int = 0) -> List[str]:
+    """GPU counterpart of the reference's module-level greedy_decode_ctc (pytorch_ocr_engine.py:13-34,
+    3-D branch): scores_probs [N, C, T], blank is the last class; returns the decoded strings."""
+    x = np.asarray(scores_probs, dtype=np.float32)
+    if x.ndim != 3:
+        raise ValueError("scores_probs must be [N, C, T]")
+    _amax, labels, lens = _native.ctc_greedy(np.ascontiguousarray(x.transpose(0, 2, 1)), device_id)
+    return labels_to_strings(labels, lens, chars)
+
+
 class PytorchEngineLineOCR(BaseEngineLineOCR):
     def __init__(self, json_def, device, batch_size=8):
         super().__init__(json_def, device, batch_size=batch_size)

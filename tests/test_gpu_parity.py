@@ -393,3 +393,61 @@ def test_device_sparsify_equals_host_sparsify(golden, tmp_path):
             assert coords == g.logit_coords
             for i in range(g.n):
                 assert abs(int(sp[i].nnz) - g.nnz_sparse[i]) <= max(2, g.nnz_sparse[i] // 200)
+
+
+def test_gpu_ctc_kernels_known_answers_ties_nan_inf():
+    """The GPU arg-max / collapse kernels alone (pocr_ctc_greedy) on adversarial scores: the CTC
+    known-answer cases of the reference's tests (test/test_decoding/test_decoders.py:24-96), exact
+    ties (first index wins), NaN (maximal, first NaN wins), +-inf, C not a multiple of 64, T > 64."""
+    import torch
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import greedy_decode_ctc
+    chars = ["a", "b", "c", "~"]
+    for best, expected in (([0, 3, 3], "a"), ([3, 3, 3], ""), ([0, 3, 0], "aa"), ([0, 1, 3], "ab"),
+                           ([0, 0, 3], "a"), ([0, 0, 1, 1, 3, 1], "abb")):
+        x = np.full((1, 4, len(best)), -5.0, np.float32)
+        for t, c in enumerate(best):
+            x[0, c, t] = 5.0
+        assert greedy_decode_ctc(x, chars) == [expected]
+    rng = np.random.RandomState(0)
+    for (n, C, T) in ((5, 7, 33), (3, 100, 200), (2, 232, 144), (1, 2, 1), (4, 65, 129)):
+        x = rng.randint(-2, 3, size=(n, C, T)).astype(np.float32)        # many exact ties
+        x[0, C // 2, T // 2] = np.nan
+        if C > 4:
+            x[0, C - 2, T // 2] = np.nan
+        x[n - 1, C - 1, 0] = np.inf
+        x[n - 1, 0, T - 1] = -np.inf
+        amax, labels, lens = _native.ctc_greedy(np.ascontiguousarray(x.transpose(0, 2, 1)))
+        ref_best = torch.argmax(torch.from_numpy(x), 1).numpy()
+        assert np.array_equal(amax, ref_best)
+        ob, ol = engine_oracle.greedy_ctc(x)
+        assert np.array_equal(ob, ref_best)
+        for i in range(n):
+            assert np.array_equal(labels[i, :lens[i]], ol[i])
+            assert np.all(labels[i, lens[i]:] == -1)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(height=32, conv_out=256, lstm_hidden=128, lstm_layers=1, num_classes=50),
+    dict(height=48, conv_out=128, lstm_hidden=64, lstm_layers=3, num_classes=301),
+    dict(height=64, conv_out=512, lstm_hidden=48, lstm_layers=2, num_classes=17),       # generic-H LSTM path
+    dict(height=40, conv_out=256, num_classes=77, arch="vgg_sa_ctc", sa_layers=1, sa_heads=8, sa_ff=512),    # head dim 32
+    dict(height=32, conv_out=256, num_classes=40, arch="vgg_sa_ctc", sa_layers=3, sa_heads=2, sa_ff=1024),   # head dim 128
+])
+def test_other_geometries_against_oracle(kw):
+    """Engine geometry is a parameter of the C ABI (pocr_config): other heights, widths of the
+    sequence model, class counts and both architectures against the oracle."""
+    spec = netspec.NetSpec(**kw)
+    weights = netspec.generate_weights(spec, 4242)
+    eng = _native.NativeEngine(spec, netspec.pack_weights(spec, weights), 0)
+    net = model_oracle.OracleNet(spec, weights)
+    crops = synth.make_crops(31, [150, 77, 200, 64], spec.height)
+    batch = engine_oracle.assemble_batch(crops, [0, 1, 2, 3], spec.height, 224, 3840)
+    logits, amax, labels, lens = eng.run_batch(batch)
+    ref = model_oracle.forward_logits(net, batch)
+    assert logits.shape == (4, ref.shape[2], ref.shape[1])
+    err = float(np.max(np.abs(logits - ref.transpose(0, 2, 1))))
+    assert err < LOGIT_TOL, err
+    srt = np.sort(ref, axis=1)
+    safe = (srt[:, -1] - srt[:, -2]) > 10 * max(err, 1e-5)
+    assert np.array_equal(amax[safe], np.argmax(ref, axis=1)[safe])
+    eng.close()
