@@ -16,8 +16,9 @@
 // LDS:  A tile  [2][KC/4][NPPAD][4]  (input halo tile, channel-quad planes; NPPAD % 16 == 0 makes the
 //                                    ds_read_b128 of 16 consecutive pixels x 4 k-lanes conflict-free)
 //       B tile  [2][KC/16][NT/16][64][4] (the fragment-order slice for one (chunk, tap) step)
-// Pipeline: one barrier per (chunk, tap) step; the global loads for step s+1 are issued before the
-// MFMAs of step s and written to the other LDS buffer after them.
+// Main loop: one barrier per (chunk, tap) step, LDS double-buffered.  PIPE_INTERLEAVED (shipped for the
+// 3x3 / aggregation / GEMM layers) unrolls the taps and issues the next step's global loads and LDS
+// writes one at a time between MFMAs; PIPE_PLAIN is the straightforward loop (conv1's u8 stager).
 //
 // Epilogue (fused): + bias, ReLU / LeakyReLU(0.01), optional BatchNorm affine (eval), optional
 // max-pool (2,2) or (2,1), store NHWC.
@@ -31,6 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
 enum { STAGE_F32_NHWC = 0, STAGE_U8_LINES = 1 };
+// main-loop variants (template parameter PIPE).  ABL3 is an ablation mask used only by tools/conv_bench.hip
+// (1 no global loads, 2 no LDS writes, 4 no ds_reads, 8 no barrier, 16 loads waited for at the step end).
+enum { PIPE_PLAIN = 0, PIPE_INTERLEAVED = 3, PIPE_DEEP = 4 };
 
 struct LineDesc {            // one text line of a staged chunk (STAGE_U8_LINES)
     int64_t offset;          // byte offset of the crop [H, width, 3] inside the crop pool
@@ -75,7 +79,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 template <int KH, int KW, int PADH, int PADW, int TH, int MW, int NS, int NWAVE, int KC,
-          int POOLH, int POOLW, int ACT, bool BN, int STAGER, int PIPE = 0, int ABL3 = 0>
+          int POOLH, int POOLW, int ACT, bool BN, int STAGER, int PIPE = PIPE_PLAIN, int ABL3 = 0>
 __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
     constexpr int TW = 16 * MW;
     constexpr int MS = TH * MW;                 // 16-pixel row-tiles per workgroup (every wave holds all of them)
@@ -94,9 +98,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
     static_assert(POOLH == 1 || TH % 2 == 0, "H-pool needs an even tile height");
     static_assert(KC % 16 == 0, "KC must be a multiple of 16");
 
-    constexpr int NB = PIPE == 1 ? 3 : 2;       // weight-tile ring depth
-    static_assert(PIPE == 0 || KG == 1, "the 3-stage pipeline is written for KC == 16");
-    __shared__ f32x4 lds[2 * A_F4 + NB * B_F4];
+    __shared__ f32x4 lds[2 * A_F4 + 2 * B_F4];
     f32x4 *ldsA = lds;
     f32x4 *ldsB = lds + 2 * A_F4;
 
@@ -216,25 +218,15 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
         }
     };
 
-    constexpr int ABL = PIPE >= 8 ? PIPE - 8 : 0;   // ablation bits (tools/conv_bench only): 1 no loads/stores, 2 no barrier, 4 no ds_read
-    if constexpr (PIPE == 0 || PIPE == 2 || PIPE >= 8) {
-    // ------------------------------------------------------------------ two-stage pipeline
-    // PIPE == 2: the input halo tile of chunk c+1 is requested at the FIRST tap of chunk c (it comes
-    // from HBM, ~2 us under load) and held in registers until the last tap; PIPE == 0 requests it
-    // at the last tap.
+    if constexpr (PIPE == PIPE_PLAIN) {
+    // ------------------------------------------------------------------ plain two-stage loop
+    // (conv1's u8 stager and the rare aggregation heights use it; KC may be 32 here)
     load_A(0);
     load_B(0, 0);
     store_A(0);
     store_B(0);
     __syncthreads();
 
-    f32x4 abl_a[MS], abl_b[NS];
-    if constexpr (ABL & 4) {
-#pragma unroll
-        for (int m = 0; m < MS; ++m) abl_a[m] = ldsA[li + kq * NPPAD + (m / MW) * HW + (m % MW) * 16];
-#pragma unroll
-        for (int n = 0; n < NS; ++n) abl_b[n] = ldsB[(wave * NS + n) * 64 + lane];
-    }
     int chunk = 0, tap = 0, abuf = 0;
     for (int s = 0; s < nsteps; ++s) {
         // ---- prefetch step s+1 into registers
@@ -242,13 +234,8 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
         if (ntap == NTAPS) { ntap = 0; nchunk = chunk + 1; }
         const bool more = (s + 1 < nsteps);
         const bool newA = more && (ntap == 0);
-        if (more && !(ABL & 1) && !(ABL & 16)) load_B(nchunk, ntap);
-        if constexpr ((ABL & 1) || (ABL & 16)) {
-        } else if constexpr (PIPE == 2 && NTAPS > 1) {
-            if (tap == 0 && chunk + 1 < nchunks) load_A(chunk + 1);
-        } else {
-            if (newA) load_A(nchunk);
-        }
+        if (more) load_B(nchunk, ntap);
+        if (newA) load_A(nchunk);
 
         // ---- MFMAs of step s
         const int dy = tap / KW, dx = tap % KW;
@@ -264,12 +251,6 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
             }
 #pragma unroll
             for (int n = 0; n < NS; ++n) bf[n] = Bb[(kg * (NT / 16) + n) * 64];
-            if constexpr (ABL & 4) {
-#pragma unroll
-                for (int m = 0; m < MS; ++m) af[m] = abl_a[m];
-#pragma unroll
-                for (int n = 0; n < NS; ++n) bf[n] = abl_b[n];
-            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -280,29 +261,23 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
         }
 
         // ---- commit the prefetched tiles to the other LDS buffers
-        if constexpr (ABL & 32) {        // loads only: keep the results alive, skip the LDS writes
-#pragma unroll
-            for (int r = 0; r < B_LD; ++r) asm volatile("" ::"v"(rb[r]));
-#pragma unroll
-            for (int r = 0; r < A_LD; ++r) asm volatile("" ::"v"(ra[r]));
-        } else if constexpr (!(ABL & 1)) {
-            if (more) store_B((s + 1) & 1);
-            if (newA) { store_A(abuf ^ 1); }
-        }
-        if constexpr (!(ABL & 2)) __syncthreads();
+        if (more) store_B((s + 1) & 1);
+        if (newA) store_A(abuf ^ 1);
+        __syncthreads();
         if (newA) abuf ^= 1;
         tap = ntap; chunk = nchunk;
     }
-    } else if constexpr (PIPE == 3 || PIPE == 4) {
-    constexpr bool DEEP = PIPE == 4;     // weight tile s+2 is requested right after tile s+1 has been written to LDS
+    } else {
+    static_assert(PIPE == PIPE_INTERLEAVED || PIPE == PIPE_DEEP, "unknown pipeline id");
+    constexpr bool DEEP = PIPE == PIPE_DEEP;     // weight tile s+2 is requested right after tile s+1 has been written to LDS
     // ------------------------------------------------------------------ interleaved two-stage pipeline
-    // Same LDS double buffering as PIPE 0, but (a) the tap loop is fully unrolled inside a runtime
+    // Same LDS double buffering as the plain loop, but (a) the tap loop is fully unrolled inside a runtime
     // chunk loop, so tap offsets are immediates and the per-step scalar bookkeeping disappears,
     // and (b) the global loads of the next step and the LDS writes that publish them are issued
     // one at a time in the shadow of the MFMA stream (a 32-cycle MFMA hides ~5 issue slots)
     // instead of as bursts before the first / after the last MFMA of a step.
-    static_assert(KG == 1, "PIPE 3 is written for KC == 16");
-    static_assert(STAGER == STAGE_F32_NHWC, "PIPE 3 stages fp32 NHWC input");
+    static_assert(KG == 1, "the interleaved pipeline is written for KC == 16");
+    static_assert(STAGER == STAGE_F32_NHWC, "the interleaved pipeline stages fp32 NHWC input");
     constexpr int NMFMA = 4 * MS * NS;
     // issue slots per step: the largest of 16, 12, 10, 8 that divides the MFMA count and leaves
     // separate halves for the loads (first half) and the LDS writes (second half)
@@ -427,76 +402,6 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
             if constexpr (!(ABL3 & 8)) __syncthreads();
         }
     }
-    } else {
-    // ------------------------------------------------------------------ three-stage pipeline
-    // Tile t (weights of one (chunk, tap) step, plus the input halo tile when t opens a chunk) is
-    // loaded from HBM/L2 into registers during step t-2, written to LDS in the middle of step t-2,
-    // published by the barrier that ends step t-2, read into MFMA operand registers during step
-    // t-1 ("early read", hidden behind step t-1's MFMAs) and consumed by the MFMAs of step t.
-    // So the MFMA stream never waits for LDS after a barrier, and the ds_writes retire behind MFMAs.
-    // Buffers: weights ring of 3; input tiles 2 (chunk c lives in buffer c & 1).
-    auto read_frags = [&](f32x4 (&af)[MS], f32x4 (&bf)[NS], int chunk_, int tap_, int bbuf) {
-        const int dy = tap_ / KW, dx = tap_ % KW;
-        const f32x4 *Ab = ldsA + (chunk_ & 1) * A_F4 + dy * HW + dx + li + kq * NPPAD;
-        const f32x4 *Bb = ldsB + bbuf * B_F4 + (wave * NS) * 64 + lane;
-#pragma unroll
-        for (int m = 0; m < MS; ++m) af[m] = Ab[(m / MW) * HW + (m % MW) * 16];
-#pragma unroll
-        for (int n = 0; n < NS; ++n) bf[n] = Bb[n * 64];
-    };
-    auto mfma_j = [&](const f32x4 (&af)[MS], const f32x4 (&bf)[NS], int j) {
-#pragma unroll
-        for (int m = 0; m < MS; ++m)
-#pragma unroll
-            for (int n = 0; n < NS; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[n][j], acc[m][n], 0, 0, 0);
-    };
-
-    int chunk = 0, tap = 0;                       // step s
-    int chunk1 = NTAPS > 1 ? 0 : 1, tap1 = NTAPS > 1 ? 1 : 0;   // step s+1
-    load_A(0);
-    load_B(0, 0);
-    store_A(0);
-    store_B(0);
-    if (nsteps > 1) {
-        load_B(chunk1, tap1);
-        if (tap1 == 0) load_A(chunk1);
-        store_B(1);
-        if (tap1 == 0) store_A(1);
-    }
-    __syncthreads();
-    f32x4 af[MS], bf[NS];
-    read_frags(af, bf, 0, 0, 0);
-    int b0 = 0;                                   // ring slot of step s
-    for (int s = 0; s < nsteps; ++s) {
-        int tap2 = tap1 + 1, chunk2 = chunk1;
-        if (tap2 == NTAPS) { tap2 = 0; chunk2 = chunk1 + 1; }
-        const bool more1 = s + 1 < nsteps, more2 = s + 2 < nsteps;
-        const bool newA2 = more2 && tap2 == 0;
-        const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-        if (more2) load_B(chunk2, tap2);
-        if (newA2) load_A(chunk2);
-        mfma_j(af, bf, 0);
-        mfma_j(af, bf, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 af2[MS], bf2[NS];
-        if (more1) read_frags(af2, bf2, chunk1, tap1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_j(af, bf, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more2) store_B(b2);
-        if (newA2) store_A(chunk2 & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_j(af, bf, 3);
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < MS; ++m) af[m] = af2[m];
-#pragma unroll
-        for (int n = 0; n < NS; ++n) bf[n] = bf2[n];
-        b0 = b1;
-        chunk = chunk1; tap = tap1; chunk1 = chunk2; tap1 = tap2;
-    }
-    (void)chunk; (void)tap;
     }
 
     // ---- epilogue.  D layout: col = lane & 15 (cout), row = (lane >> 4) * 4 + reg (pixel).

@@ -95,28 +95,28 @@ int launch_conv(Kern kern, int TH, int TW, int NT, int nthreads, ConvArgs a, hip
 }
 
 // tile configurations (KH,KW,PADH,PADW, TH,MW,NS,NWAVE,KC, POOLH,POOLW, ACT,BN, STAGER, PIPE)
-// PIPE 3 = unrolled-tap, MFMA-interleaved staging (see conv_igemm.hpp); PIPE 0 = plain two-stage loop.
+// PI = PIPE_INTERLEAVED (unrolled taps, MFMA-interleaved staging, see conv_igemm.hpp); PP = PIPE_PLAIN.
 #define POCR_CONV(name, KH, KW, PH, PW, TH, MW, NS, NWAVE, KC, POOLH, POOLW, ACT, BN, STG, PIPE)                       \
     int name(ConvArgs a, hipStream_t st) {                                                                           \
         return launch_conv(conv_igemm_kernel<KH, KW, PH, PW, TH, MW, NS, NWAVE, KC, POOLH, POOLW, ACT, BN, STG, PIPE>, \
                            TH, 16 * MW, NS * NWAVE * 16, NWAVE * 64, a, st);                                        \
     }
 //                 KH KW P  P  TH MW NS NW KC PH PW
-POCR_CONV(conv1_u8,  1, 1, 0, 0, 4, 2, 1, 4, 32, 1, 1, ACT_RELU, false, STAGE_U8_LINES, 0)   // 3->64 (im2col K=27->32)
-POCR_CONV(conv2_k,   3, 3, 1, 1, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, STAGE_F32_NHWC, 3)   // 64->64   + pool 2x2
-POCR_CONV(conv3_k,   3, 3, 1, 1, 4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, 3)   // 64->128
-POCR_CONV(conv4_k,   3, 3, 1, 1, 4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, STAGE_F32_NHWC, 3)   // 128->128 + pool 2x2
-POCR_CONV(conv56_k,  3, 3, 1, 1, 10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, 3)  // ->256
-POCR_CONV(conv7_k,   3, 3, 1, 1, 10, 1, 2, 4, 16, 2, 1, ACT_RELU, false, STAGE_F32_NHWC, 3)  // 256->256 + pool 2x1
-POCR_CONV(conv8_k,   3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, 3)  // 256->512
-POCR_CONV(conv9_k,   3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, STAGE_F32_NHWC, 3)   // 512->512 + BN
-POCR_CONV(agg4_k,    4, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, 3)
-POCR_CONV(agg5_k,    5, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, 3)
-POCR_CONV(agg6_k,    6, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, 0)
-POCR_CONV(agg8_k,    8, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, 0)
-POCR_CONV(gemm128_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC, 3)   // rows x 128 cols per WG
-POCR_CONV(gemm64_k,  1, 1, 0, 0, 1, 8, 1, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC, 3)   // rows x 64 cols per WG
-POCR_CONV(gemm128_relu_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, 3)   // FFN first linear
+POCR_CONV(conv1_u8,  1, 1, 0, 0, 4, 2, 1, 4, 32, 1, 1, ACT_RELU, false, STAGE_U8_LINES, PIPE_PLAIN)   // 3->64 (im2col K=27->32)
+POCR_CONV(conv2_k,   3, 3, 1, 1, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // 64->64   + pool 2x2
+POCR_CONV(conv3_k,   3, 3, 1, 1, 4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // 64->128
+POCR_CONV(conv4_k,   3, 3, 1, 1, 4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // 128->128 + pool 2x2
+POCR_CONV(conv56_k,  3, 3, 1, 1, 10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)  // ->256
+POCR_CONV(conv7_k,   3, 3, 1, 1, 10, 1, 2, 4, 16, 2, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)  // 256->256 + pool 2x1
+POCR_CONV(conv8_k,   3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)  // 256->512
+POCR_CONV(conv9_k,   3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // 512->512 + BN
+POCR_CONV(agg4_k,    4, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)
+POCR_CONV(agg5_k,    5, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)
+POCR_CONV(agg6_k,    6, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_PLAIN)
+POCR_CONV(agg8_k,    8, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_PLAIN)
+POCR_CONV(gemm128_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // rows x 128 cols per WG
+POCR_CONV(gemm64_k,  1, 1, 0, 0, 1, 8, 1, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // rows x 64 cols per WG
+POCR_CONV(gemm128_relu_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // FFN first linear
 const int kConvNT[9] = {64, 64, 128, 128, 128, 128, 128, 256, 256};
 const int kAggNT = 256, kProjNT = 128, kHeadNT = 64;
 

@@ -1,4 +1,5 @@
-// conv_bench.hip — within-probe A/B of conv_igemm_kernel tile configurations on one layer shape.
+// conv_bench.hip — within-probe A/B of conv_igemm_kernel tile configurations, main-loop pipelines and
+// ablations on one layer shape.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -o /tmp/conv_bench tools/conv_bench.hip
 // Run  : /tmp/conv_bench <layer 2..9> [n_lines=256] [w_pad=576]
 // Every variant runs on the same random input/weights; outputs are compared with variant 0
@@ -26,79 +27,49 @@ static void launch(K kern, int TH, int TW, int NT, int nthr, ConvArgs a, hipStre
 
 struct Variant { const char *name; void (*fn)(ConvArgs, hipStream_t); int nt; };
 
-#define VAR(NAME, TH, MW, NS, NW, KC, PH, PW, ACT, BN)                                                             \
+#define VARP(NAME, TH, MW, NS, NW, KC, PH, PW, ACT, BN, PIPE, ABL)                                                 \
     static void NAME(ConvArgs a, hipStream_t st) {                                                                 \
-        launch(conv_igemm_kernel<3, 3, 1, 1, TH, MW, NS, NW, KC, PH, PW, ACT, BN, STAGE_F32_NHWC>, TH, 16 * MW,     \
-               NS * NW * 16, NW * 64, a, st);                                                                      \
-    }
-
-#define VARP(NAME, TH, MW, NS, NW, KC, PH, PW, ACT, BN, PIPE)                                                      \
-    static void NAME(ConvArgs a, hipStream_t st) {                                                                 \
-        launch(conv_igemm_kernel<3, 3, 1, 1, TH, MW, NS, NW, KC, PH, PW, ACT, BN, STAGE_F32_NHWC, PIPE>, TH,        \
+        launch(conv_igemm_kernel<3, 3, 1, 1, TH, MW, NS, NW, KC, PH, PW, ACT, BN, STAGE_F32_NHWC, PIPE, ABL>, TH,   \
                16 * MW, NS * NW * 16, NW * 64, a, st);                                                             \
     }
-VARP(h5_pipe1,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 1)
-VARP(h5_pipe1_nt128, 5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, 1)
-VARP(h10_pipe1,    10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, 1)
-VARP(h10_pipe1_th5, 5, 1, 4, 4, 16, 1, 1, ACT_RELU, false, 1)
-VARP(h20_pipe1,    4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, 1)
-VARP(p22_pipe1,    4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, 1)
-VARP(p22_pipe1_nt64, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, 1)
-VARP(h5_pipe2,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 2)
-VARP(h10_pipe2,    10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, 2)
-VARP(p22_pipe2,    4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, 2)
-VARP(p22_pipe2_nt64, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, 2)
-VARP(h5_abl1,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 9)
-VARP(h5_abl2,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 10)
-VARP(h5_abl3,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 11)
-VARP(h5_abl4,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 12)
-VARP(h5_abl5,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 13)
-VARP(h5_abl16,    5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 24)
-VARP(h5_abl32,    5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 40)
-VARP(h5_abl7,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 15)
-VARP(h5_pipe3,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 3)
-VARP(h5_pipe4,     5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, 4)
-VARP(h5_pipe4_nt128, 5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, 4)
-VARP(h10_pipe4,    10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, 4)
-VARP(p22_pipe4,    4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, 4)
-VARP(p22_pipe4_nt64, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, 4)
-VARP(h20_pipe4,    4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, 4)
-VARP(h5_pipe3_nt128, 5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, 3)
-VARP(h5_pipe3_nt64,  5, 1, 1, 4, 16, 1, 1, ACT_LEAKY, true, 3)
-VARP(h5_pipe3_nw8,   5, 1, 1, 8, 16, 1, 1, ACT_LEAKY, true, 3)
-VARP(h10_pipe3,    10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, 3)
-VARP(h20_pipe3,    4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, 3)
-VARP(p22_pipe3,    4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, 3)
-VARP(p22_pipe3_nt64, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, 3)
-#define VARA(NAME, ABL)                                                                                              \
-    static void NAME(ConvArgs a, hipStream_t st) {                                                                 \
-        launch(conv_igemm_kernel<3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, STAGE_F32_NHWC, 3, ABL>, 5, 16, 256, 256, a, st); \
-    }
-VARA(p3_a1, 1) VARA(p3_a2, 2) VARA(p3_a3, 3) VARA(p3_a4, 4) VARA(p3_a7, 7) VARA(p3_a8, 8) VARA(p3_a15, 15) VARA(p3_a18, 18)
-// conv8/9-shaped (H=5): pool none
-VAR(h5_base,      5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true)
-VAR(h5_kc32_nt128,5, 1, 2, 4, 32, 1, 1, ACT_LEAKY, true)
-VAR(h5_nw8,       5, 1, 2, 8, 16, 1, 1, ACT_LEAKY, true)
-VAR(h5_nw8_kc32,  5, 1, 2, 8, 32, 1, 1, ACT_LEAKY, true)
-VAR(h5_nt128,     5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true)
-VAR(h5_mw2_nt128, 5, 2, 2, 4, 16, 1, 1, ACT_LEAKY, true)
-VAR(h5_kc32,      5, 1, 4, 4, 32, 1, 1, ACT_LEAKY, true)
-// conv5/6-shaped (H=10)
-VAR(h10_base,     10, 1, 2, 4, 16, 1, 1, ACT_RELU, false)
-VAR(h10_th5_ns4,  5, 1, 4, 4, 16, 1, 1, ACT_RELU, false)
-VAR(h10_nw8,      10, 1, 1, 8, 16, 1, 1, ACT_RELU, false)
-VAR(h10_kc32,     10, 1, 2, 4, 32, 1, 1, ACT_RELU, false)
-VAR(h10_th5_mw2,  5, 2, 2, 4, 16, 1, 1, ACT_RELU, false)
-// conv3-shaped (H=20, no pool) and conv2/4 (pool 2x2)
-VAR(h20_base,     4, 2, 2, 4, 16, 1, 1, ACT_RELU, false)
-VAR(h20_th10,     10, 1, 2, 4, 16, 1, 1, ACT_RELU, false)
-VAR(h20_th5_ns4,  5, 1, 4, 4, 16, 1, 1, ACT_RELU, false)
-VAR(h20_th4mw4ns1,4, 4, 1, 4, 16, 1, 1, ACT_RELU, false)
-VAR(p22_base,     4, 2, 2, 4, 16, 2, 2, ACT_RELU, false)
-VAR(p22_th10,     10, 1, 2, 4, 16, 2, 2, ACT_RELU, false)
-VAR(p22_th4mw4,   4, 4, 1, 4, 16, 2, 2, ACT_RELU, false)
-VAR(p22_th2mw4ns2,2, 4, 2, 4, 16, 2, 2, ACT_RELU, false)
-VAR(p22_kc32,     4, 2, 2, 4, 32, 2, 2, ACT_RELU, false)
+#define P0 PIPE_PLAIN
+#define P3 PIPE_INTERLEAVED
+#define P4 PIPE_DEEP
+// conv8/9-shaped (H = 5)
+VARP(h5_plain,      5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P0, 0)
+VARP(h5_plain_kc32, 5, 1, 4, 4, 32, 1, 1, ACT_LEAKY, true, P0, 0)
+VARP(h5_plain_nw8,  5, 1, 2, 8, 16, 1, 1, ACT_LEAKY, true, P0, 0)
+VARP(h5_plain_mw2,  5, 2, 2, 4, 16, 1, 1, ACT_LEAKY, true, P0, 0)
+VARP(h5_p3,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P3, 0)
+VARP(h5_p3_nt128,   5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, P3, 0)
+VARP(h5_p3_nt64,    5, 1, 1, 4, 16, 1, 1, ACT_LEAKY, true, P3, 0)
+VARP(h5_p4,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P4, 0)
+VARP(h5_p4_nt128,   5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, P4, 0)
+VARP(h5_a1,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P3, 1)
+VARP(h5_a2,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P3, 2)
+VARP(h5_a3,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P3, 3)
+VARP(h5_a4,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P3, 4)
+VARP(h5_a8,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P3, 8)
+VARP(h5_a15,        5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P3, 15)
+VARP(h5_a18,        5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P3, 18)
+// conv5/6-shaped (H = 10)
+VARP(h10_plain,     10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P0, 0)
+VARP(h10_plain_th5, 5, 1, 4, 4, 16, 1, 1, ACT_RELU, false, P0, 0)
+VARP(h10_p3,        10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P3, 0)
+VARP(h10_p3_th5,    5, 1, 4, 4, 16, 1, 1, ACT_RELU, false, P3, 0)
+VARP(h10_p4,        10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P4, 0)
+// conv3-shaped (H = 20, no pool) and conv2/4 (pool 2x2)
+VARP(h20_plain,     4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, P0, 0)
+VARP(h20_p3,        4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, P3, 0)
+VARP(h20_p3_th10,   10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P3, 0)
+VARP(h20_p4,        4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, P4, 0)
+VARP(p22_plain,     4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P0, 0)
+VARP(p22_plain_nt64, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, P0, 0)
+VARP(p22_p3,        4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P3, 0)
+VARP(p22_p3_nt64,   4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, P3, 0)
+VARP(p22_p3_th10,   10, 1, 2, 4, 16, 2, 2, ACT_RELU, false, P3, 0)
+VARP(p22_p4,        4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P4, 0)
+VARP(p22_p4_nt64,   4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, P4, 0)
 
 int main(int argc, char **argv) {
     int layer = argc > 1 ? atoi(argv[1]) : 9;
@@ -111,34 +82,22 @@ int main(int argc, char **argv) {
     Shape s = shapes[layer];
     if (argc > 4) s.cin = atoi(argv[4]);     // experiment: longer K loop per workgroup
     std::vector<Variant> vars;
-    if (layer >= 8) vars = {{"TH5 MW1 NS4 NW4 KC16 (base)", h5_base, 256}, {"TH5 MW1 NS2 NW4 KC32 NT128", h5_kc32_nt128, 128},
-                            {"TH5 MW1 NS2 NW8 KC16", h5_nw8, 256}, {"TH5 MW1 NS2 NW8 KC32", h5_nw8_kc32, 256},
-                            {"TH5 MW1 NS2 NW4 KC16 NT128", h5_nt128, 128}, {"TH5 MW2 NS2 NW4 KC16 NT128", h5_mw2_nt128, 128},
-                            {"TH5 MW1 NS4 NW4 KC32", h5_kc32, 256},
-                            {"PIPE1 TH5 MW1 NS4 NW4 KC16", h5_pipe1, 256}, {"PIPE1 TH5 MW1 NS2 NW4 NT128", h5_pipe1_nt128, 128},
-                            {"PIPE2 TH5 MW1 NS4 NW4", h5_pipe2, 256}, {"PIPE3 TH5 MW1 NS4 NW4", h5_pipe3, 256}, {"PIPE4 TH5 MW1 NS4 NW4", h5_pipe4, 256}, {"PIPE4 TH5 MW1 NS2 NW4 NT128", h5_pipe4_nt128, 128}, {"PIPE3 TH5 MW1 NS2 NW4 NT128", h5_pipe3_nt128, 128},
-                            {"PIPE3 TH5 MW1 NS1 NW4 NT64", h5_pipe3_nt64, 64}, {"PIPE3 TH5 MW1 NS1 NW8 NT128", h5_pipe3_nw8, 128},
-                            {"P3ABL no-loads", p3_a1, 256}, {"P3ABL no-stores", p3_a2, 256}, {"P3ABL no-loads/stores", p3_a3, 256},
-                            {"P3ABL no-ds_read", p3_a4, 256}, {"P3ABL no-ld/st/read", p3_a7, 256}, {"P3ABL no-barrier", p3_a8, 256},
-                            {"P3ABL mfma only", p3_a15, 256}, {"P3ABL loads, waited at step end, no stores", p3_a18, 256},
-                            {"ABL no-loads/stores", h5_abl1, 256}, {"ABL no-barrier", h5_abl2, 256}, {"ABL no-loads no-barrier", h5_abl3, 256},
-                            {"ABL no-ds_read", h5_abl4, 256}, {"ABL no-loads no-ds_read", h5_abl5, 256}, {"ABL mfma only", h5_abl7, 256},
-                            {"ABL stores-no-loads", h5_abl16, 256}, {"ABL loads-no-stores", h5_abl32, 256}};
-    else if (layer == 5 || layer == 6) vars = {{"TH10 MW1 NS2 NW4 KC16 (base)", h10_base, 128}, {"TH5 MW1 NS4 NW4 KC16", h10_th5_ns4, 256},
-                            {"TH10 MW1 NS1 NW8 KC16", h10_nw8, 128}, {"TH10 MW1 NS2 NW4 KC32", h10_kc32, 128},
-                            {"TH5 MW2 NS2 NW4 KC16", h10_th5_mw2, 128},
-                            {"PIPE1 TH10 MW1 NS2 NW4", h10_pipe1, 128}, {"PIPE1 TH5 MW1 NS4 NW4", h10_pipe1_th5, 256},
-                            {"PIPE2 TH10 MW1 NS2 NW4", h10_pipe2, 128}, {"PIPE3 TH10 MW1 NS2 NW4", h10_pipe3, 128}, {"PIPE4 TH10 MW1 NS2 NW4", h10_pipe4, 128}};
-    else if (layer == 3) vars = {{"TH4 MW2 NS2 NW4 KC16 (base)", h20_base, 128}, {"TH10 MW1 NS2 NW4", h20_th10, 128},
-                            {"TH5 MW1 NS4 NW4 (NT256: cout pad)", h20_th5_ns4, 256}, {"TH4 MW4 NS1 NW4 NT64", h20_th4mw4ns1, 64},
-                            {"PIPE1 TH4 MW2 NS2 NW4", h20_pipe1, 128}, {"PIPE3 TH4 MW2 NS2 NW4", h20_pipe3, 128}, {"PIPE4 TH4 MW2 NS2 NW4", h20_pipe4, 128}};
-    else if (layer == 2 || layer == 4) vars = {{"TH4 MW2 NS2 NW4 KC16 NT128", p22_base, 128}, {"TH10 MW1 NS2 NW4", p22_th10, 128},
-                            {"TH4 MW4 NS1 NW4 NT64", p22_th4mw4, 64}, {"TH2 MW4 NS2 NW4 NT128", p22_th2mw4ns2, 128},
-                            {"TH4 MW2 NS2 NW4 KC32", p22_kc32, 128},
-                            {"PIPE1 TH4 MW2 NS2 NW4 NT128", p22_pipe1, 128}, {"PIPE1 TH4 MW4 NS1 NW4 NT64", p22_pipe1_nt64, 64},
-                            {"PIPE2 TH4 MW2 NS2 NW4 NT128", p22_pipe2, 128}, {"PIPE2 TH4 MW4 NS1 NW4 NT64", p22_pipe2_nt64, 64},
-                            {"PIPE3 TH4 MW2 NS2 NW4 NT128", p22_pipe3, 128}, {"PIPE3 TH4 MW4 NS1 NW4 NT64", p22_pipe3_nt64, 64},
-                            {"PIPE4 TH4 MW2 NS2 NW4 NT128", p22_pipe4, 128}, {"PIPE4 TH4 MW4 NS1 NW4 NT64", p22_pipe4_nt64, 64}};
+    if (layer >= 8) vars = {{"plain TH5 MW1 NS4 NW4 KC16 (base)", h5_plain, 256}, {"plain KC32", h5_plain_kc32, 256},
+                            {"plain NS2 NW8", h5_plain_nw8, 256}, {"plain MW2 NS2 NT128", h5_plain_mw2, 128},
+                            {"interleaved (shipped)", h5_p3, 256}, {"interleaved NT128", h5_p3_nt128, 128},
+                            {"interleaved NT64", h5_p3_nt64, 64}, {"deep prefetch", h5_p4, 256}, {"deep prefetch NT128", h5_p4_nt128, 128},
+                            {"ABL no global loads", h5_a1, 256}, {"ABL no LDS writes (loads die too)", h5_a2, 256},
+                            {"ABL no loads/writes", h5_a3, 256}, {"ABL no ds_read", h5_a4, 256}, {"ABL no barrier", h5_a8, 256},
+                            {"ABL MFMA stream only", h5_a15, 256}, {"ABL loads waited at step end, no writes", h5_a18, 256}};
+    else if (layer >= 5) vars = {{"plain TH10 MW1 NS2 NW4 (base)", h10_plain, 128}, {"plain TH5 NS4 NT256", h10_plain_th5, 256},
+                            {"interleaved (shipped)", h10_p3, 128}, {"interleaved TH5 NS4 NT256", h10_p3_th5, 256},
+                            {"deep prefetch", h10_p4, 128}};
+    else if (layer == 3) vars = {{"plain TH4 MW2 NS2 NW4 (base)", h20_plain, 128}, {"interleaved (shipped)", h20_p3, 128},
+                            {"interleaved TH10 MW1", h20_p3_th10, 128}, {"deep prefetch", h20_p4, 128}};
+    else if (layer == 2 || layer == 4) vars = {{"plain TH4 MW2 NS2 NW4 NT128 (base)", p22_plain, 128}, {"plain TH4 MW4 NS1 NT64", p22_plain_nt64, 64},
+                            {"interleaved NT128 (conv4 shipped)", p22_p3, 128}, {"interleaved NT64 (conv2 shipped)", p22_p3_nt64, 64},
+                            {"interleaved TH10 MW1", p22_p3_th10, 128}, {"deep prefetch NT128", p22_p4, 128},
+                            {"deep prefetch NT64", p22_p4_nt64, 64}};
     else { printf("layer %d not covered\n", layer); return 1; }
 
     const size_t xin = (size_t)n * s.H * s.W * s.cin;
