@@ -34,7 +34,9 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
 enum { STAGE_F32_NHWC = 0, STAGE_U8_LINES = 1 };
 // main-loop variants (template parameter PIPE).  ABL3 is an ablation mask used only by tools/conv_bench.hip
 // (1 no global loads, 2 no LDS writes, 4 no ds_reads, 8 no barrier, 16 loads waited for at the step end).
-enum { PIPE_PLAIN = 0, PIPE_INTERLEAVED = 3, PIPE_DEEP = 4 };
+enum { PIPE_PLAIN = 0, PIPE_INTERLEAVED = 3, PIPE_DEEP = 4, PIPE_GLDS = 5 };
+// PIPE_GLDS = PIPE_INTERLEAVED with the weight tile copied HBM/L2 -> LDS by the load unit itself
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write; the tile is already lane-linear).
 
 struct LineDesc {            // one text line of a staged chunk (STAGE_U8_LINES)
     int64_t offset;          // byte offset of the crop [H, width, 3] inside the crop pool
@@ -268,7 +270,8 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
         tap = ntap; chunk = nchunk;
     }
     } else {
-    static_assert(PIPE == PIPE_INTERLEAVED || PIPE == PIPE_DEEP, "unknown pipeline id");
+    static_assert(PIPE == PIPE_INTERLEAVED || PIPE == PIPE_DEEP || PIPE == PIPE_GLDS, "unknown pipeline id");
+    constexpr bool GLDS = PIPE == PIPE_GLDS;
     constexpr bool DEEP = PIPE == PIPE_DEEP;     // weight tile s+2 is requested right after tile s+1 has been written to LDS
     // ------------------------------------------------------------------ interleaved two-stage pipeline
     // Same LDS double buffering as the plain loop, but (a) the tap loop is fully unrolled inside a runtime
@@ -314,6 +317,15 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
     auto stB = [&](int r, int buf) {
         const int f = tid + r * NTHR;
         if (B_F4 % NTHR == 0 || f < B_F4) ldsB[buf * B_F4 + f] = rb[r];
+    };
+    // direct-to-LDS copy of piece r of a weight tile: every lane supplies its own global address, the LDS
+    // destination is (wave-uniform base) + lane * 16 B, which is exactly the tile's linear layout
+    auto dmaB = [&](int r, const f32x4 *tile, int buf) {
+        static_assert(!GLDS || B_F4 % NTHR == 0, "GLDS needs whole-wave pieces");
+        const int f0 = __builtin_amdgcn_readfirstlane(wave * 64 + r * NTHR);
+        typedef const __attribute__((address_space(1))) void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
+        __builtin_amdgcn_global_load_lds((gptr_t)(tile + f0 + lane), (lptr_t)(ldsB + buf * B_F4 + f0), 16, 0, 0);
     };
 #pragma unroll
     for (int r = 0; r < A_LD; ++r) ldA(r, 0);
@@ -379,13 +391,16 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
                     const int slot = (q + 1) / STRIDE - 1;
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (!(ABL3 & 1)) {
-                        if (slot < B_LD) { if constexpr (!DEEP) { if (more) ldB(slot, tile); } }
+                        if (slot < B_LD) {
+                            if constexpr (GLDS) { if (more) dmaB(slot, tile, bnext); }
+                            else if constexpr (!DEEP) { if (more) ldB(slot, tile); }
+                        }
                         else if (slot < B_LD + A_LD) { if (ldA_now) ldA(slot - B_LD, chunk + 1); }
                     }
                     const int sslot = slot - (NSLOT - B_LD - A_LD);
                     if constexpr (!(ABL3 & 2)) {
                         if (sslot >= 0 && sslot < B_LD) {
-                            if (more) stB(sslot, bnext);
+                            if constexpr (!GLDS) { if (more) stB(sslot, bnext); }
                             if constexpr (DEEP) { if (more2) ldB(sslot, tile2); }
                         }
                         else if (sslot >= B_LD) { if (stA_now) stA(sslot - B_LD, abuf ^ 1); }

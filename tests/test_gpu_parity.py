@@ -451,3 +451,57 @@ def test_other_geometries_against_oracle(kw):
     safe = (srt[:, -1] - srt[:, -2]) > 10 * max(err, 1e-5)
     assert np.array_equal(amax[safe], np.argmax(ref, axis=1)[safe])
     eng.close()
+
+
+def test_random_page_stream_against_oracle(small, tmp_path):
+    """A page-like stream of 40 random-width lines through process_lines (default batch_size 8: many
+    chunks with different padded widths, tail chunks, n not a multiple of 16) against the oracle's
+    process_lines on the same crops: same chunk plan, strings, coords; logits within tolerance."""
+    import json
+    import os
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    spec, weights, _eng, net = small
+    chars = synth.make_charset(99)
+    path = os.path.join(str(tmp_path), "ocr.json")
+    json.dump({"line_px_height": 40, "line_vertical_scale": 1.0, "checkpoint": "absent.pocrw", "characters": chars,
+               "net_name": "x", "net": {"weight_seed": 20260928}}, open(path, "w"))
+    eng = PytorchEngineLineOCR(path, Dev())
+    widths = synth.make_widths(77, 40, lo=20, hi=900)
+    lines = synth.make_crops(78, widths)
+    texts, logits, coords = eng.process_lines(lines, sparse_logits=False)
+    o_t, o_l, o_c, extras = engine_oracle.process_lines(
+        lambda b: model_oracle.forward_logits(net, b), lines, eng.characters, 40, eng.max_input_horizontal_pixels,
+        sparse_logits=False)
+    assert coords == o_c
+    worst = 0.0
+    for i in range(len(lines)):
+        a, b = np.asarray(logits[i]), np.asarray(o_l[i])
+        assert a.shape == b.shape
+        err = float(np.max(np.abs(a - b)))
+        worst = max(worst, err)
+        srt = np.sort(b, axis=1)
+        safe = (srt[:, -1] - srt[:, -2]) > 1e-3
+        assert np.array_equal(np.argmax(a, axis=1)[safe], np.argmax(b, axis=1)[safe])
+        if safe.all():
+            assert texts[i] == o_t[i]
+    assert worst < LOGIT_TOL, worst
+
+
+def test_engine_lifecycle_and_buffer_growth(small):
+    """Engines can be created and destroyed repeatedly, and one engine can see growing and shrinking
+    chunks (device buffers are re-reserved on demand) without changing results."""
+    spec, weights, eng0, net = small
+    flat = netspec.pack_weights(spec, weights)
+    crops = synth.make_crops(3, [64, 64])
+    small_batch = engine_oracle.assemble_batch(crops, [0, 1], spec.height, 64, 3840)
+    ref = eng0.run_batch(small_batch)
+    for _ in range(3):
+        e = _native.NativeEngine(spec, flat, 0)
+        big = synth.random_u8_batch(5, 40, spec.height, 704)
+        e.run_batch(big, want_logits=False)
+        got = e.run_batch(small_batch)
+        for r, g in zip(ref, got):
+            assert np.array_equal(r, g)
+        e.close()
+    with pytest.raises(RuntimeError):
+        _native.NativeEngine(spec, flat[:-1], 0)            # wrong blob size is refused by pocr_create
