@@ -29,6 +29,8 @@ struct LstmStepArgs {
     float *h_out;           // [2][npad][H]
     float *c;               // [2][npad][H]  (in place)
     float *y;               // [n][T][2H]    layer output, fwd in [0,H), bwd in [H,2H)
+    const int32_t *dims;    // optional device pointer to {n, npad}: overrides the two fields below, so that a
+                            // captured hipGraph of the T step launches can be replayed for any chunk size
     int32_t n, npad, T, H, step;
 };
 
@@ -41,6 +43,8 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int ug = blockIdx.x, slice = blockIdx.y, dir = blockIdx.z;
+    if (a.dims) { a.n = a.dims[0]; a.npad = a.dims[1]; }
+    if (slice * 16 >= a.npad) return;           // replayed graphs are sized for a bucket of slices
     const int H = KPW > 0 ? 64 * KPW : a.H, KGT = H / 16;
     const int t = dir == 0 ? a.step : a.T - 1 - a.step;
 

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -156,6 +158,12 @@ struct Slot {
     hipEvent_t ev[POCR_NUM_STAGES + 1]{};
     float stage_ms[POCR_NUM_STAGES]{};
     bool have_ms = false;
+    // BiLSTM recurrence as replayable hipGraphs: key (layer, T, slice bucket) -> 2 memsets + T step launches.
+    // Node parameters hold this slot's buffer addresses; any re-allocation of those buffers flushes the cache.
+    std::map<std::tuple<int, int, int>, hipGraphExec_t> lstm_graphs;
+    DevBuf lstm_dims;                // device {n, npad} read by the replayed step kernels
+    int32_t *lstm_dims_host = nullptr;   // pinned source of that copy
+    size_t h_stride = 0;             // floats between the two h ping-pong buffers (capacity-based, stable)
     // recorded after the conv backbone of a launch: the next launch (on another slot) starts its own
     // MFMA-bound backbone only then, so backbones run one after the other at full speed and only the
     // latency-bound sequence tail of the previous chunk shares the chip with them
@@ -179,6 +187,7 @@ struct pocr_engine {
     int agg_cout16 = 0, head_cout16 = 0, proj_cout16 = 0;
     Slot slot[POCR_NUM_SLOTS];
     int last_slot = 0;               // slot of the most recent launch (stage timings / debug taps)
+    bool use_graphs = true;          // replay the LSTM recurrence from captured hipGraphs (POCR_NO_GRAPHS=1 disables)
     bool profiling = false;
 };
 
@@ -339,34 +348,88 @@ int run_network(pocr_engine *e, Slot &s) {
     } else {
     // ---- BiLSTM stack
     const int Hh = c.lstm_hidden, npad = round_up(n, 16);
-    if (s.xproj.reserve((size_t)n * T * 8 * Hh * sizeof(float))) return 1;
-    if (s.hbuf.reserve((size_t)2 * 2 * npad * Hh * sizeof(float))) return 1;
-    if (s.cbuf.reserve((size_t)2 * npad * Hh * sizeof(float))) return 1;
+    {   // (re)allocation of any buffer whose address is baked into the cached graphs flushes them
+        const void *before[4] = {s.xproj.p, s.hbuf.p, s.cbuf.p, nullptr};
+        if (s.xproj.reserve((size_t)n * T * 8 * Hh * sizeof(float))) return 1;
+        if (2 * (size_t)2 * npad * Hh > 2 * s.h_stride || !s.hbuf.p) {
+            const size_t cap_pad = (size_t)round_up(npad, 64);
+            if (s.hbuf.reserve((size_t)2 * 2 * cap_pad * Hh * sizeof(float))) return 1;
+            if (s.cbuf.reserve((size_t)2 * cap_pad * Hh * sizeof(float))) return 1;
+            s.h_stride = (size_t)2 * cap_pad * Hh;
+        }
+        bool moved = before[0] != s.xproj.p || before[1] != s.hbuf.p || before[2] != s.cbuf.p;
+        for (int l = 0; l < c.lstm_layers; ++l) {
+            const void *yb = s.lstm_y[l].p;
+            if (s.lstm_y[l].reserve((size_t)n * T * 2 * Hh * sizeof(float))) return 1;
+            moved = moved || yb != s.lstm_y[l].p;
+        }
+        if (moved) {
+            for (auto &kv : s.lstm_graphs) (void)hipGraphExecDestroy(kv.second);
+            s.lstm_graphs.clear();
+        }
+        if (!s.lstm_dims.p) {
+            if (s.lstm_dims.reserve(16)) return 1;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.lstm_dims_host), 16, hipHostMallocDefault));
+        }
+    }
+    auto launch_step = [&](int l, int step, int slices, const int32_t *dims) {
+        LstmStepArgs la{};
+        la.xproj = s.xproj.as<float>(); la.whh_frag = e->whh[l].as<float>();
+        la.h_in = s.hbuf.as<float>() + (size_t)(step & 1) * s.h_stride;
+        la.h_out = s.hbuf.as<float>() + (size_t)((step + 1) & 1) * s.h_stride;
+        la.c = s.cbuf.as<float>(); la.y = s.lstm_y[l].as<float>(); la.dims = dims;
+        la.n = n; la.npad = npad; la.T = T; la.H = Hh; la.step = step;
+        const dim3 grid(Hh / 16, slices, 2);
+        switch (Hh) {
+            case 64: hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, st, la); break;
+            case 128: hipLaunchKernelGGL(lstm_step_kernel<2>, grid, dim3(256), 0, st, la); break;
+            case 256: hipLaunchKernelGGL(lstm_step_kernel<4>, grid, dim3(256), 0, st, la); break;
+            case 512: hipLaunchKernelGGL(lstm_step_kernel<8>, grid, dim3(256), 0, st, la); break;
+            default: hipLaunchKernelGGL(lstm_step_kernel<0>, grid, dim3(256), 0, st, la); break;
+        }
+    };
+    int bucket = 1;                          // slices rounded up to a power of two: few distinct graphs
+    while (bucket * 16 < npad) bucket *= 2;
+    s.lstm_dims_host[0] = n; s.lstm_dims_host[1] = npad;
+    HIP_TRY(hipMemcpyAsync(s.lstm_dims.p, s.lstm_dims_host, 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
     for (int l = 0; l < c.lstm_layers; ++l) {
-        if (s.lstm_y[l].reserve((size_t)n * T * 2 * Hh * sizeof(float))) return 1;
         ConvArgs a{};
         a.x = layer_in; a.n = 1; a.H = 1; a.W = n * T; a.Ho = 1; a.Wo = n * T; a.cin = din;
         a.cout16 = e->proj_cout16; a.cout_valid = 8 * Hh; a.out_stride = 8 * Hh;
         a.wfrag = e->proj_w[l].as<float>(); a.bias = e->proj_b[l].as<float>(); a.y = s.xproj.as<float>();
         if (gemm128_k(a, st)) return 1;
-        const size_t hsz = (size_t)2 * npad * Hh;
-        HIP_TRY(hipMemsetAsync(s.hbuf.p, 0, 2 * hsz * sizeof(float), st));
-        HIP_TRY(hipMemsetAsync(s.cbuf.p, 0, hsz * sizeof(float), st));
-        for (int step = 0; step < T; ++step) {
-            LstmStepArgs la{};
-            la.xproj = s.xproj.as<float>(); la.whh_frag = e->whh[l].as<float>();
-            la.h_in = s.hbuf.as<float>() + (size_t)(step & 1) * hsz;
-            la.h_out = s.hbuf.as<float>() + (size_t)((step + 1) & 1) * hsz;
-            la.c = s.cbuf.as<float>(); la.y = s.lstm_y[l].as<float>();
-            la.n = n; la.npad = npad; la.T = T; la.H = Hh; la.step = step;
-            const dim3 grid(Hh / 16, npad / 16, 2);
-            switch (Hh) {
-                case 64: hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, st, la); break;
-                case 128: hipLaunchKernelGGL(lstm_step_kernel<2>, grid, dim3(256), 0, st, la); break;
-                case 256: hipLaunchKernelGGL(lstm_step_kernel<4>, grid, dim3(256), 0, st, la); break;
-                case 512: hipLaunchKernelGGL(lstm_step_kernel<8>, grid, dim3(256), 0, st, la); break;
-                default: hipLaunchKernelGGL(lstm_step_kernel<0>, grid, dim3(256), 0, st, la); break;
+        // the serial part: 2 memsets + T dependent step launches, replayed from a captured graph
+        const auto key = std::make_tuple(l, T, bucket);
+        auto it = s.lstm_graphs.find(key);
+        if (it == s.lstm_graphs.end() && e->use_graphs) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                (void)hipMemsetAsync(s.hbuf.p, 0, 2 * s.h_stride * sizeof(float), st);
+                (void)hipMemsetAsync(s.cbuf.p, 0, s.h_stride * sizeof(float), st);
+                for (int step = 0; step < T; ++step) launch_step(l, step, bucket, s.lstm_dims.as<int32_t>());
+                ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph != nullptr;
             }
+            if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (ok) {
+                if (s.lstm_graphs.size() >= 256) {       // bound the cache
+                    for (auto &kv : s.lstm_graphs) (void)hipGraphExecDestroy(kv.second);
+                    s.lstm_graphs.clear();
+                }
+                it = s.lstm_graphs.emplace(key, exec).first;
+            } else {
+                (void)hipGetLastError();
+                e->use_graphs = false;                   // capture is unavailable: plain launches from now on
+            }
+        }
+        if (it != s.lstm_graphs.end()) {
+            HIP_TRY(hipGraphLaunch(it->second, st));
+        } else {
+            HIP_TRY(hipMemsetAsync(s.hbuf.p, 0, 2 * s.h_stride * sizeof(float), st));
+            HIP_TRY(hipMemsetAsync(s.cbuf.p, 0, s.h_stride * sizeof(float), st));
+            for (int step = 0; step < T; ++step) launch_step(l, step, npad / 16, nullptr);
         }
         HIP_TRY(hipGetLastError());
         layer_in = s.lstm_y[l].as<float>();
@@ -535,6 +598,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
 
     pocr_engine *e = new pocr_engine();
     e->cfg = *cfg;
+    if (const char *env = getenv("POCR_NO_GRAPHS")) e->use_graphs = atoi(env) == 0;
     e->device = device_id;
     auto bail = [&](int rc) { pocr_destroy(e); return rc; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
@@ -682,6 +746,10 @@ void pocr_destroy(pocr_engine *e) {
             b->release();
         if (s.pinned) (void)hipHostFree(s.pinned);
         if (s.sp_pinned) (void)hipHostFree(s.sp_pinned);
+        for (auto &kv : s.lstm_graphs) (void)hipGraphExecDestroy(kv.second);
+        s.lstm_graphs.clear();
+        s.lstm_dims.release();
+        if (s.lstm_dims_host) (void)hipHostFree(s.lstm_dims_host);
         if (s.host_in) (void)hipHostFree(s.host_in);
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);
