@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define POCR_ABI_VERSION 4
+#define POCR_ABI_VERSION 5
 #define POCR_NUM_SLOTS 2
 
 typedef struct pocr_engine pocr_engine;
@@ -106,6 +106,17 @@ int pocr_ctc_greedy(int device_id, const float *logits_ntc, int32_t n, int32_t T
 int pocr_num_slots(void);
 int pocr_slot_stage_lines(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
                           const int32_t *widths, int32_t n, int32_t w_pad, int32_t pad_left);
+/* Ragged staging: like pocr_slot_stage_lines, but every line i is padded to its OWN width w_pads[i]
+ * (the W_pad of the reference chunk it belongs to, line_ocr_engine.py:81-82,121).  A line's padded width
+ * is part of the numerical contract; which lines share a device launch is not: lines of several
+ * reference chunks can be staged together and run as one launch sequence.  With ragged staging
+ *   T_i = (w_pads[i] / 2) / 2,  rows = sum of T_i,  T_max = max T_i
+ *   logits_ntc      : float32 [rows][C], line i = rows [sum_{j<i} T_j, +T_i)
+ *   frame_argmax_nt : int32 [rows], same row order
+ *   labels_nt       : int32 [n][T_max] (-1 padded), label_len_n : int32 [n]
+ *   sparse indptr / line_off as documented below, row indices relative to the line. */
+int pocr_slot_stage_ragged(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
+                           const int32_t *widths, const int32_t *w_pads, int32_t n, int32_t pad_left);
 int pocr_slot_launch(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t want_argmax);
 int pocr_slot_collect(pocr_engine *e, int32_t slot, float *logits_ntc, int32_t *frame_argmax_nt,
                       int32_t *labels_nt, int32_t *label_len_n);

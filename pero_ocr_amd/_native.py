@@ -14,7 +14,7 @@ import numpy as np
 from .netspec import NetSpec
 
 LIB_NAME = "libpocr_hip.so"
-ABI_VERSION = 4
+ABI_VERSION = 5
 STAGE_NAMES = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv8", "conv9",
                "agg", "lstm", "head", "ctc", "total")
 
@@ -50,6 +50,7 @@ SYMBOLS = {
     "pocr_ctc_greedy": (C.c_int, [C.c_int, _f32p, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _i32p]),
     "pocr_num_slots": (C.c_int, []),
     "pocr_slot_stage_lines": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, C.c_int32, C.c_int32, C.c_int32]),
+    "pocr_slot_stage_ragged": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, _i32p, C.c_int32, C.c_int32]),
     "pocr_slot_launch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pocr_slot_collect": (C.c_int, [C.c_void_p, C.c_int32, _f32p, _i32p, _i32p, _i32p]),
     "pocr_slot_stage_ms": (C.c_int, [C.c_void_p, C.c_int32, _f32p, C.c_int32]),
@@ -103,7 +104,8 @@ class NativeEngine:
         self._n = 0
         self._T = 0
         self.num_slots = int(self._lib.pocr_num_slots())
-        self._slot_shape = [(0, 0, False, False)] * self.num_slots     # (n, T, want_logits, want_argmax) per slot
+        # per slot: (n, T_max, rows, want_logits, want_argmax, uniform)
+        self._slot_shape = [(0, 0, 0, False, False, True)] * self.num_slots
 
     def _err(self) -> str:
         return (self._lib.pocr_last_error() or b"").decode("utf8", "replace")
@@ -123,9 +125,14 @@ class NativeEngine:
     def frames_for(w_pad: int) -> int:
         return (w_pad // 2) // 2
 
-    def _alloc_out(self, n, T, want_logits, want_argmax):
-        logits = np.empty((n, T, self.spec.num_classes), dtype=np.float32) if want_logits else None
-        amax = np.empty((n, T), dtype=np.int32) if want_argmax else None
+    def _alloc_out(self, n, T, want_logits, want_argmax, rows=None):
+        """Uniform chunk (rows None): logits [n,T,C], argmax [n,T].  Ragged: logits [rows,C], argmax [rows]."""
+        if rows is None:
+            logits = np.empty((n, T, self.spec.num_classes), dtype=np.float32) if want_logits else None
+            amax = np.empty((n, T), dtype=np.int32) if want_argmax else None
+        else:
+            logits = np.empty((rows, self.spec.num_classes), dtype=np.float32) if want_logits else None
+            amax = np.empty((rows,), dtype=np.int32) if want_argmax else None
         labels = np.empty((n, T), dtype=np.int32)
         lens = np.empty((n,), dtype=np.int32)
         return logits, amax, labels, lens
@@ -176,19 +183,36 @@ class NativeEngine:
                                              int(wd.size), int(w_pad), int(pad_left))
         if rc:
             raise RuntimeError("pocr_slot_stage_lines: " + self._err())
-        self._slot_shape[slot] = (int(wd.size), self.frames_for(w_pad), False, False)
+        T = self.frames_for(w_pad)
+        self._slot_shape[slot] = (int(wd.size), T, int(wd.size) * T, False, False, True)
         if slot == 0:
-            self._n, self._T = int(wd.size), self.frames_for(w_pad)
+            self._n, self._T = int(wd.size), T
+
+    def slot_stage_ragged(self, slot: int, pool_u8, offsets, widths, w_pads, pad_left: int):
+        """Lines padded to their own widths w_pads[i] (each line's reference-chunk W_pad)."""
+        pool = np.ascontiguousarray(pool_u8, dtype=np.uint8).reshape(-1)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        wd = np.ascontiguousarray(widths, dtype=np.int32)
+        wp = np.ascontiguousarray(w_pads, dtype=np.int32)
+        if pool.size == 0:
+            pool = np.zeros(1, dtype=np.uint8)
+        rc = self._lib.pocr_slot_stage_ragged(self._h, int(slot), _ptr(pool, _u8p), _ptr(off, _i64p), _ptr(wd, _i32p),
+                                              _ptr(wp, _i32p), int(wd.size), int(pad_left))
+        if rc:
+            raise RuntimeError("pocr_slot_stage_ragged: " + self._err())
+        frames = (wp // 2) // 2
+        self._slot_shape[slot] = (int(wd.size), int(frames.max()), int(frames.sum()), False, False, False)
+        return frames
 
     def slot_launch(self, slot: int, want_logits=True, want_argmax=False):
         if self._lib.pocr_slot_launch(self._h, int(slot), 1 if want_logits else 0, 1 if want_argmax else 0):
             raise RuntimeError("pocr_slot_launch: " + self._err())
-        n, T, _a, _b = self._slot_shape[slot]
-        self._slot_shape[slot] = (n, T, bool(want_logits), bool(want_argmax))
+        n, T, rows, _a, _b, uni = self._slot_shape[slot]
+        self._slot_shape[slot] = (n, T, rows, bool(want_logits), bool(want_argmax), uni)
 
     def slot_collect(self, slot: int):
-        n, T, want_logits, want_argmax = self._slot_shape[slot]
-        logits, amax, labels, lens = self._alloc_out(n, T, want_logits, want_argmax)
+        n, T, rows, want_logits, want_argmax, uni = self._slot_shape[slot]
+        logits, amax, labels, lens = self._alloc_out(n, T, want_logits, want_argmax, None if uni else rows)
         rc = self._lib.pocr_slot_collect(self._h, int(slot), _ptr(logits, _f32p), _ptr(amax, _i32p),
                                          _ptr(labels, _i32p), _ptr(lens, _i32p))
         if rc:
@@ -202,12 +226,12 @@ class NativeEngine:
         if self._lib.pocr_slot_launch_sparse(self._h, int(slot), _ptr(rb, _i32p), _ptr(re_, _i32p), float(threshold),
                                              1 if want_argmax else 0):
             raise RuntimeError("pocr_slot_launch_sparse: " + self._err())
-        n, T, _a, _b = self._slot_shape[slot]
-        self._slot_shape[slot] = (n, T, False, bool(want_argmax))
+        n, T, rows, _a, _b, uni = self._slot_shape[slot]
+        self._slot_shape[slot] = (n, T, rows, False, bool(want_argmax), uni)
 
     def slot_collect_sparse(self, slot: int):
         """-> (data f32 [nnz], indices i32 [nnz], indptr i32 [n, C+1], line_off i64 [n+1], argmax|None, labels, lens)"""
-        n, T, _wl, want_argmax = self._slot_shape[slot]
+        n, T, rows, _wl, want_argmax, uni = self._slot_shape[slot]
         total = C.c_int64(0)
         if self._lib.pocr_slot_sparse_nnz(self._h, int(slot), C.byref(total)):
             raise RuntimeError("pocr_slot_sparse_nnz: " + self._err())
@@ -215,7 +239,7 @@ class NativeEngine:
         indices = np.empty(max(1, total.value), dtype=np.int32)
         indptr = np.empty((n, self.spec.num_classes + 1), dtype=np.int32)
         line_off = np.empty(n + 1, dtype=np.int64)
-        _lg, amax, labels, lens = self._alloc_out(n, T, False, want_argmax)
+        _lg, amax, labels, lens = self._alloc_out(n, T, False, want_argmax, None if uni else rows)
         rc = self._lib.pocr_slot_collect_sparse(self._h, int(slot), _ptr(data, _f32p), _ptr(indices, _i32p),
                                                 _ptr(indptr, _i32p), _ptr(line_off, _i64p), _ptr(amax, _i32p),
                                                 _ptr(labels, _i32p), _ptr(lens, _i32p))

@@ -44,6 +44,8 @@ struct LineDesc {            // one text line of a staged chunk (STAGE_U8_LINES)
     int32_t pad_left;        // x position of the crop inside the padded row
 };
 
+struct PixelTile { int32_t line; int32_t ht_wt; };     // ht_wt = (h-tile << 16) | w-tile
+
 struct ConvArgs {
     const float *x;          // input NHWC [n][H][W][cin]            (STAGE_F32_NHWC)
     const uint8_t *crops;    // crop pool                             (STAGE_U8_LINES)
@@ -61,11 +63,20 @@ struct ConvArgs {
     int32_t cout_valid;      // channels actually stored
     int32_t out_stride;      // floats per output pixel
     int32_t tiles_w, tiles_h, tiles_n;
+    // Ragged batches (lines of one launch padded to DIFFERENT widths, each to its reference chunk's W_pad):
+    // when `tiles` is set, pixel tile p works on line tiles[p].line whose input width is line_w[line] and
+    // whose input / output images start at element offsets in_off[line] / out_off[line]; n, W, Wo and
+    // tiles_w/tiles_h above are then unused and `n_ptiles` is the number of pixel tiles.
+    const PixelTile *tiles;
+    const int32_t *line_w;
+    const int64_t *in_off;
+    const int64_t *out_off;
+    int32_t n_ptiles;
 };
 
 // number of workgroups for a conv launch (must match the block -> tile mapping in the kernel)
 inline size_t conv_grid_blocks(const ConvArgs &a) {
-    const size_t P = (size_t)a.tiles_w * a.tiles_h * a.n;
+    const size_t P = a.tiles ? (size_t)a.n_ptiles : (size_t)a.tiles_w * a.tiles_h * a.n;
     const int tn = a.tiles_n;
     if (tn >= 2 && tn <= 8 && (tn & (tn - 1)) == 0) {
         const size_t groups = 8 / tn;
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
     int nt, ptile;
     {
         const int tn = a.tiles_n;
-        const int P = a.tiles_w * a.tiles_h * a.n;
+        const int P = a.tiles ? a.n_ptiles : a.tiles_w * a.tiles_h * a.n;
         if (tn >= 2 && tn <= 8 && (tn & (tn - 1)) == 0) {
             const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, groups = 8 / tn;
             nt = xcd % tn;
@@ -133,9 +144,22 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
             ptile = b / tn;
         }
     }
-    const int wt = ptile % a.tiles_w;
-    const int ht = (ptile / a.tiles_w) % a.tiles_h;
-    const int img = ptile / (a.tiles_w * a.tiles_h);
+    int wt, ht, img, Win;            // Win: input (= conv output) width of this line at this layer
+    size_t img_base, out_base;       // element offsets of the line's input and output images
+    if (a.tiles) {
+        const PixelTile pt = a.tiles[ptile];
+        img = pt.line; ht = pt.ht_wt >> 16; wt = pt.ht_wt & 0xffff;
+        Win = a.line_w[img];
+        img_base = (size_t)a.in_off[img];
+        out_base = (size_t)a.out_off[img];
+    } else {
+        wt = ptile % a.tiles_w;
+        ht = (ptile / a.tiles_w) % a.tiles_h;
+        img = ptile / (a.tiles_w * a.tiles_h);
+        Win = a.W;
+        img_base = (size_t)img * a.H * a.W * a.cin;
+        out_base = (size_t)img * (a.Ho / POOLH) * (a.Wo / POOLW) * a.out_stride;
+    }
     const int h0 = ht * TH, w0 = wt * TW;
 
     f32x4 acc[MS][NS];
@@ -146,7 +170,6 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
 
     const int nchunks = a.cin / KC;
     const int nsteps = nchunks * NTAPS;
-    const size_t img_base = (size_t)img * a.H * a.W * a.cin;
 
     f32x4 ra[A_LD], rb[B_LD];
 
@@ -161,8 +184,8 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
                 const int hr = p / HW, wc = p % HW;
                 const int hi = h0 - PADH + hr, wi = w0 - PADW + wc;
                 if constexpr (STAGER == STAGE_F32_NHWC) {
-                    if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W)
-                        v = *reinterpret_cast<const f32x4 *>(a.x + img_base + ((size_t)hi * a.W + wi) * a.cin + c0 + cq * 4);
+                    if (hi >= 0 && hi < a.H && wi >= 0 && wi < Win)
+                        v = *reinterpret_cast<const f32x4 *>(a.x + img_base + ((size_t)hi * Win + wi) * a.cin + c0 + cq * 4);
                 } else {
                     // conv1: build the im2col row of pixel (hi, wi) from the u8 crop on the fly.
                     // "channel" k = (ky*3 + kx)*3 + c for k < 27, zero above.  u8 -> f32 through the
@@ -179,7 +202,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
                             const int tap = k / 3, c = k - tap * 3;
                             const int yy = hi + tap / 3 - 1, xx = wi + tap % 3 - 1;
                             const int xc = xx - ld.pad_left;
-                            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && xc >= 0 && xc < ld.width)
+                            if (yy >= 0 && yy < a.H && xx >= 0 && xx < Win && xc >= 0 && xc < ld.width)
                                 val = a.lut[src[((size_t)yy * ld.width + xc) * 3 + c]];
                         }
                         t4[j] = val;
@@ -298,8 +321,8 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
         const int cq = e % CQ, p = e / CQ;
         const int hr = p / HW, wc = p % HW;
         const int hi = h0 - PADH + hr, wi = w0 - PADW + wc;
-        a_ok[r] = e < CQ * NP && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-        a_off[r] = a_ok[r] ? (unsigned)((hi * a.W + wi) * a.cin + cq * 4) : 0u;
+        a_ok[r] = e < CQ * NP && hi >= 0 && hi < a.H && wi >= 0 && wi < Win;
+        a_off[r] = a_ok[r] ? (unsigned)((hi * Win + wi) * a.cin + cq * 4) : 0u;
         a_lds[r] = e < CQ * NP ? cq * NPPAD + p : -1;
     }
     const float *ximg = a.x + img_base;
@@ -420,7 +443,8 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
     }
 
     // ---- epilogue.  D layout: col = lane & 15 (cout), row = (lane >> 4) * 4 + reg (pixel).
-    const int Hout = a.Ho / POOLH, Wout = a.Wo / POOLW;
+    const int Wo = Win;              // 3x3 pad 1, (k x 1) valid and 1x1 convs keep the width
+    const int Wout = Wo / POOLW;
 #pragma unroll
     for (int n = 0; n < NS; ++n) {
         const int co = (nt * (NT / 16) + wave * NS + n) * 16 + li;
@@ -447,18 +471,18 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_igemm_kernel(ConvArgs a) {
                 const int ho = (h0 + th) / POOLH;
                 const int wbase = w0 + mw * 16 + kq * 4;           // conv-output column of reg 0
                 if (!co_ok || h0 + th >= a.Ho) continue;
-                float *yrow = a.y + (((size_t)img * Hout + ho) * Wout) * a.out_stride + co;
+                float *yrow = a.y + out_base + ((size_t)ho * Wout) * a.out_stride + co;
                 if constexpr (POOLW == 2) {
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr) {
                         const int wc = wbase + 2 * rr;
-                        if (wc + 1 < a.Wo) yrow[(size_t)(wc / 2) * a.out_stride] = fmaxf(v[2 * rr], v[2 * rr + 1]);
+                        if (wc + 1 < Wo) yrow[(size_t)(wc / 2) * a.out_stride] = fmaxf(v[2 * rr], v[2 * rr + 1]);
                     }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int wc = wbase + r;
-                        if (wc < a.Wo) yrow[(size_t)wc * a.out_stride] = v[r];
+                        if (wc < Wo) yrow[(size_t)wc * a.out_stride] = v[r];
                     }
                 }
             }

@@ -41,12 +41,15 @@ __global__ __launch_bounds__(256) void frame_argmax_kernel(const float *logits, 
     if (lane == 0) out[frame] = bi;
 }
 
-// best [n][T] -> labels [n][T] (compacted), len [n]
+// best [rows] -> labels [n][stride] (compacted, -1 padded), len [n].  Line i owns rows row_off[i] ..
+// row_off[i] + line_T[i] (NULL arrays: every line has T frames, line i starts at row i * T).
 __global__ __launch_bounds__(64) void ctc_collapse_kernel(const int32_t *best, int32_t *labels, int32_t *len,
-                                                          int T, int blank) {
+                                                          int T_uniform, int blank, const int32_t *line_T,
+                                                          const int32_t *row_off, int stride) {
     const int line = blockIdx.x, lane = threadIdx.x;
-    const int32_t *b = best + (size_t)line * T;
-    int32_t *out = labels + (size_t)line * T;
+    const int T = line_T ? line_T[line] : T_uniform;
+    const int32_t *b = best + (row_off ? (size_t)row_off[line] : (size_t)line * T_uniform);
+    int32_t *out = labels + (size_t)line * stride;
     int count = 0;
     for (int t0 = 0; t0 < T; t0 += 64) {
         const int t = t0 + lane;
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(64) void ctc_collapse_kernel(const int32_t *best, i
         if (keep) out[count + __popcll(m & ((1ull << lane) - 1ull))] = cur;
         count += __popcll(m);
     }
-    for (int t = count + lane; t < T; t += 64) out[t] = -1;      // deterministic tail
+    for (int t = count + lane; t < stride; t += 64) out[t] = -1;      // deterministic tail
     if (lane == 0) len[line] = count;
 }
 

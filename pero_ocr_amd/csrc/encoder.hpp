@@ -22,7 +22,7 @@ namespace pocr {
 // rows x E; one wave per row, E % 64 == 0 not required (strided loop).
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *a, const float *b, const float *gamma,
                                                         const float *beta, const float *pe, float *y, int rows,
-                                                        int E, int T, float eps) {
+                                                        int E, int T, float eps, const int32_t *row_t) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *a, const fl
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
     const float rstd = 1.0f / sqrtf(sq / (float)E + eps);
-    const float *ppe = pe ? pe + (size_t)(row % T) * E : nullptr;
+    // frame index of this row inside its line: row_t[row] for ragged batches, row % T for uniform ones
+    const float *ppe = pe ? pe + (size_t)(row_t ? row_t[row] : row % T) * E : nullptr;
     float *py = y + (size_t)row * E;
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
@@ -67,13 +68,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *a, const fl
 
 // qkv [n][T][3E] (q | k | v, head h = columns h*D .. h*D+D-1 of each part) -> out [n][T][E]
 template <int D>
-__global__ __launch_bounds__(64) void attention_kernel(const float *qkv, float *out, int T, int E, float scale) {
+__global__ __launch_bounds__(64) void attention_kernel(const float *qkv, float *out, int T_uniform, int E, float scale,
+                                                       const int32_t *line_T, const int32_t *row_off) {
     static_assert(D % 16 == 0 && D <= 128, "head dim must be a multiple of 16");
     constexpr int DG = D / 16;
     const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
     const int qb = blockIdx.x, head = blockIdx.y, line = blockIdx.z;
-    const float *base = qkv + (size_t)line * T * 3 * E + head * D;
+    const int T = line_T ? line_T[line] : T_uniform;
+    const size_t row0 = row_off ? (size_t)row_off[line] : (size_t)line * T_uniform;
+    const float *base = qkv + row0 * 3 * E + head * D;
     const int q0 = qb * 16;
+    if (q0 >= T) return;                    // the grid is sized for the longest line
 
     // B operand of S^T = K Q^T: lane (k = g, j = li) holds Q[q0 + li][16*dg + 4*g + 0..3]
     f32x4 qf[DG];
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(64) void attention_kernel(const float *qkv, float *
     // ---- O^T[d = 16*dt + 4g + r][q = li] / l  ->  out[line][q0 + li][head*D + 16*dt + 4g + 0..3]
     if (q0 + li < T) {
         const float inv = 1.0f / l_run;
-        float *op = out + ((size_t)line * T + q0 + li) * E + head * D + 4 * g;
+        float *op = out + (row0 + q0 + li) * E + head * D + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < DG; ++dt) *reinterpret_cast<f32x4 *>(op + 16 * dt) = o[dt] * inv;
     }

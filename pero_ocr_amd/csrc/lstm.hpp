@@ -31,6 +31,12 @@ struct LstmStepArgs {
     float *y;               // [n][T][2H]    layer output, fwd in [0,H), bwd in [H,2H)
     const int32_t *dims;    // optional device pointer to {n, npad}: overrides the two fields below, so that a
                             // captured hipGraph of the T step launches can be replayed for any chunk size
+    // ragged batches: per-line frame counts and first rows (frames of line i are rows row_off[i] ..
+    // row_off[i] + line_T[i] of xproj / y); slice_T[s] = max line_T over the 16 lines of slice s.
+    // NULL -> every line has T frames and line i starts at row i * T.
+    const int32_t *line_T;
+    const int32_t *row_off;
+    const int32_t *slice_T;
     int32_t n, npad, T, H, step;
 };
 
@@ -45,8 +51,8 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
     const int ug = blockIdx.x, slice = blockIdx.y, dir = blockIdx.z;
     if (a.dims) { a.n = a.dims[0]; a.npad = a.dims[1]; }
     if (slice * 16 >= a.npad) return;           // replayed graphs are sized for a bucket of slices
+    if (a.slice_T && a.step >= a.slice_T[slice]) return;      // every line of this slice has finished
     const int H = KPW > 0 ? 64 * KPW : a.H, KGT = H / 16;
-    const int t = dir == 0 ? a.step : a.T - 1 - a.step;
 
     // epilogue operands first: they come from HBM (xproj is streamed, never cached)
     const int u = tid & 15, i = tid >> 4;
@@ -54,8 +60,12 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
     const int unit = ug * 16 + u;
     const size_t sidx = ((size_t)dir * a.npad + line) * H + unit;
     float xg[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
-    if (line < a.n) {
-        const float *xp = a.xproj + ((size_t)line * a.T + t) * (8 * H) + (size_t)dir * 4 * H + unit;
+    const int Ti = line < a.n ? (a.line_T ? a.line_T[line] : a.T) : 0;
+    const bool live = a.step < Ti;                              // shorter lines simply stop updating
+    const int t = dir == 0 ? a.step : Ti - 1 - a.step;         // the backward pass starts at the line's own last frame
+    const size_t row = (a.row_off ? (size_t)a.row_off[min(line, a.n - 1)] : (size_t)line * a.T) + t;
+    if (live) {
+        const float *xp = a.xproj + row * (8 * H) + (size_t)dir * 4 * H + unit;
 #pragma unroll
         for (int g = 0; g < 4; ++g) xg[g] = xp[(size_t)g * H];
         cprev = a.c[sidx];
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
         s += part[(3 * 4 + g) * 256 + src];
         gate[g] = s;
     }
-    if (line < a.n) {
+    if (live) {
         const float gi = sigmoid_f32(gate[0] + xg[0]);
         const float gf = sigmoid_f32(gate[1] + xg[1]);
         const float gg = tanhf(gate[2] + xg[2]);
@@ -120,9 +130,9 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
         const float hn = go * tanhf(cn);
         a.c[sidx] = cn;
         a.h_out[sidx] = hn;
-        a.y[((size_t)line * a.T + t) * (2 * H) + (size_t)dir * H + unit] = hn;
+        a.y[row * (2 * H) + (size_t)dir * H + unit] = hn;
     } else {
-        a.h_out[sidx] = 0.f;    // padding lines of the last slice stay zero
+        a.h_out[sidx] = 0.f;    // padding rows of the last slice and finished lines: value is never used
     }
 }
 

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <functional>
 #include <map>
 #include <tuple>
@@ -85,8 +86,10 @@ std::vector<float> build_wfrag(int ntaps, int cin_pad, int cout16,
 
 template <class Kern>
 int launch_conv(Kern kern, int TH, int TW, int NT, int nthreads, ConvArgs a, hipStream_t st) {
-    a.tiles_w = (a.Wo + TW - 1) / TW;
-    a.tiles_h = (a.Ho + TH - 1) / TH;
+    if (!a.tiles) {
+        a.tiles_w = (a.Wo + TW - 1) / TW;
+        a.tiles_h = (a.Ho + TH - 1) / TH;
+    }
     a.tiles_n = (a.cout16 * 16) / NT;
     const size_t blocks = conv_grid_blocks(a);
     if (blocks == 0) return 0;
@@ -120,6 +123,12 @@ POCR_CONV(gemm128_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_NONE, false, STAGE_F3
 POCR_CONV(gemm64_k,  1, 1, 0, 0, 1, 8, 1, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // rows x 64 cols per WG
 POCR_CONV(gemm128_relu_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // FFN first linear
 const int kConvNT[9] = {64, 64, 128, 128, 128, 128, 128, 256, 256};
+// pixel-tile shape (TH, 16*MW) of conv1..conv9 and of the aggregation conv - the same numbers as in the table above
+const int kConvTH[10] = {4, 4, 4, 4, 10, 10, 10, 5, 5, 1};
+const int kConvTW[10] = {32, 64, 32, 32, 16, 16, 16, 16, 16, 48};
+// input width level of each conv (0: W_pad, 1: W_pad/2, 2: (W_pad/2)/2) and of its output
+const int kConvLvlIn[10] = {0, 0, 1, 1, 2, 2, 2, 2, 2, 2};
+const int kConvLvlOut[10] = {0, 1, 1, 2, 2, 2, 2, 2, 2, 2};
 const int kAggNT = 256, kProjNT = 128, kHeadNT = 64;
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -137,8 +146,24 @@ struct Slot {
     DevBuf crops, lines;
     void *host_in = nullptr;         // pinned staging for the crop pool
     size_t host_in_cap = 0;
-    int n = 0, w_pad = 0;
+    int n = 0, w_pad = 0;            // w_pad = widest padded row of the staged lines
     bool staged = false, in_flight = false, want_logits = false, want_argmax = false;
+    // Geometry of the staged lines.  Every line keeps the padded width of its reference chunk
+    // (line_ocr_engine.py:79-90, 121-123): that width is part of the numerical contract, the grouping
+    // of lines into device launches is not - all kernels work from these per-line tables.
+    DevBuf geom;                     // one device blob, sub-allocated below
+    std::vector<char> geom_host;
+    const int32_t *g_lvl_w[3]{};     // [n] widths at the three levels
+    const int64_t *g_act_off[9]{};   // [n+1] element offset of line i in the output of conv k
+    const int64_t *g_feat_off = nullptr;   // [n+1] row_off * E
+    const int32_t *g_line_T = nullptr;     // [n] frames of line i (= g_lvl_w[2], stable address)
+    const int32_t *g_row_off = nullptr;    // [n+1] first frame (row) of line i in the sequence tensors
+    const int32_t *g_slice_T = nullptr;    // [npad/16] longest line of each 16-line slice
+    const int32_t *g_row_t = nullptr;      // [rows] frame index of every row inside its line
+    const PixelTile *g_tiles[10]{};
+    int g_ntiles[10]{};
+    int64_t act_elems[9]{};          // total elements of every conv output
+    int rows = 0, t_max = 0;         // sum of T_i, max T_i
     // activations
     DevBuf act[9], feat, xproj, hbuf, cbuf, logits, best, labels, lens;
     std::vector<DevBuf> lstm_y, sa_y;
@@ -164,6 +189,14 @@ struct Slot {
     DevBuf lstm_dims;                // device {n, npad} read by the replayed step kernels
     int32_t *lstm_dims_host = nullptr;   // pinned source of that copy
     size_t h_stride = 0;             // floats between the two h ping-pong buffers (capacity-based, stable)
+    const void *graph_geom = nullptr;    // address of `seqgeom` the cached graphs were captured with
+    // Sequence-part tables (frames per line, first row, per-slice maximum) live in their own buffer with a
+    // capacity-based layout, so their addresses - baked into the cached LSTM graphs - stay put while the
+    // number of staged lines varies: [line_T: cap] [row_off: cap + 16] [slice_T: cap / 16 + 16].
+    DevBuf seqgeom;
+    int sg_cap = 0;
+    std::vector<int32_t> sg_host;
+    size_t h_lvl2_off = 0;           // byte offset of the per-line frame counts inside geom_host
     // recorded after the conv backbone of a launch: the next launch (on another slot) starts its own
     // MFMA-bound backbone only then, so backbones run one after the other at full speed and only the
     // latency-bound sequence tail of the previous chunk shares the chip with them
@@ -232,7 +265,7 @@ struct WeightCursor {
 int run_network(pocr_engine *e, Slot &s) {
     const pocr_config &c = e->cfg;
     hipStream_t st = s.stream;          // switches to s.seq_stream after the backbone
-    const int n = s.n, H = c.height, W = s.w_pad;
+    const int n = s.n, H = c.height;
     const bool prof = e->profiling;
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(s.ev[i], st); };
 
@@ -241,13 +274,16 @@ int run_network(pocr_engine *e, Slot &s) {
         Slot &prev = e->slot[e->last_slot];
         if (&prev != &s && prev.conv_done_valid) HIP_TRY(hipStreamWaitEvent(st, prev.conv_done, 0));
     }
-    int h = H, w = W;
+    int h = H;
     for (int i = 0; i < 9; ++i) {
         const ConvLayer &L = kConvPlan[i];
-        const int ho = h / L.ph, wo = w / L.pw;
-        if (s.act[i].reserve((size_t)n * ho * wo * L.cout * sizeof(float))) return 1;
+        if (s.act[i].reserve((size_t)s.act_elems[i] * sizeof(float))) return 1;
         ConvArgs a{};
-        a.n = n; a.H = h; a.W = w; a.Ho = h; a.Wo = w;
+        a.H = h; a.Ho = h;
+        a.tiles = s.g_tiles[i]; a.n_ptiles = s.g_ntiles[i];
+        a.line_w = s.g_lvl_w[kConvLvlIn[i]];
+        a.in_off = i ? s.g_act_off[i - 1] : s.g_act_off[0];      // conv1 reads the u8 crops, not an fp32 image
+        a.out_off = s.g_act_off[i];
         a.cout16 = e->conv_cout16[i]; a.cout_valid = L.cout; a.out_stride = L.cout;
         a.wfrag = e->conv_w[i].as<float>(); a.bias = e->conv_b[i].as<float>();
         a.y = s.act[i].as<float>();
@@ -271,15 +307,17 @@ int run_network(pocr_engine *e, Slot &s) {
             }
         }
         if (rc) return rc;
-        h = ho; w = wo;
-        s.act_h[i] = h; s.act_w[i] = w; s.act_c[i] = L.cout;
+        h /= L.ph;
+        s.act_h[i] = h; s.act_c[i] = L.cout;
     }
-    // ---- aggregation conv: [n][H/8][T][512] -> [n][T][E]
-    const int T = w, E = c.conv_out, AH = h;
+    // ---- aggregation conv: line i [H/8][T_i][512] -> rows row_off[i] .. of feat [rows][E]
+    const int T = s.t_max, E = c.conv_out, AH = h, rows = s.rows;
     {
-        if (s.feat.reserve((size_t)n * T * E * sizeof(float))) return 1;
+        if (s.feat.reserve((size_t)rows * E * sizeof(float))) return 1;
         ConvArgs a{};
-        a.x = s.act[8].as<float>(); a.n = n; a.H = AH; a.W = T; a.Ho = 1; a.Wo = T; a.cin = 512;
+        a.x = s.act[8].as<float>(); a.H = AH; a.Ho = 1; a.cin = 512;
+        a.tiles = s.g_tiles[9]; a.n_ptiles = s.g_ntiles[9];
+        a.line_w = s.g_lvl_w[2]; a.in_off = s.g_act_off[8]; a.out_off = s.g_feat_off;
         a.cout16 = e->agg_cout16; a.cout_valid = E; a.out_stride = E;
         a.wfrag = e->agg_w.as<float>(); a.bias = e->agg_b.as<float>(); a.y = s.feat.as<float>();
         mark(POCR_STAGE_AGG);
@@ -295,7 +333,7 @@ int run_network(pocr_engine *e, Slot &s) {
     mark(POCR_STAGE_LSTM);
     if (c.arch == POCR_ARCH_SA) {
     // ---- self-attention encoder (transformer.py:366-385)
-    const int rows = n * T, FF = c.sa_ff, heads = c.sa_heads, D = E / heads;
+    const int FF = c.sa_ff, heads = c.sa_heads, D = E / heads;
     const size_t xe = (size_t)rows * E * sizeof(float);
     if (s.sa_x.reserve(xe) || s.sa_x1.reserve(xe) || s.sa_att.reserve(xe) || s.sa_tmp.reserve(xe)) return 1;
     if (s.sa_qkv.reserve(3 * xe) || s.sa_ff.reserve((size_t)rows * FF * sizeof(float))) return 1;
@@ -315,7 +353,7 @@ int run_network(pocr_engine *e, Slot &s) {
     }
     auto ln = [&](const float *a_, const float *b_, const DevBuf &gw, const DevBuf &gb, const float *pe_, float *y_) {
         hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a_, b_, gw.as<float>(), gb.as<float>(),
-                           pe_, y_, rows, E, T, 1e-5f);
+                           pe_, y_, rows, E, T, 1e-5f, s.g_row_t);
     };
     auto gemm = [&](const float *x_, int cin_, const DevBuf &w_, const DevBuf &b_, int cout_, float *y_, bool relu) {
         ConvArgs g{};
@@ -331,9 +369,9 @@ int run_network(pocr_engine *e, Slot &s) {
         if (gemm(s.sa_x.as<float>(), E, L.w_in, L.b_in, 3 * E, s.sa_qkv.as<float>(), false)) return 1;
         const dim3 agrid((T + 15) / 16, heads, n);
         const float scale = 1.0f / sqrtf((float)D);
-        if (D == 32) hipLaunchKernelGGL(attention_kernel<32>, agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale);
-        else if (D == 64) hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale);
-        else hipLaunchKernelGGL(attention_kernel<128>, agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale);
+        if (D == 32) hipLaunchKernelGGL(attention_kernel<32>, agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale, s.g_line_T, s.g_row_off);
+        else if (D == 64) hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale, s.g_line_T, s.g_row_off);
+        else hipLaunchKernelGGL(attention_kernel<128>, agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale, s.g_line_T, s.g_row_off);
         if (gemm(s.sa_att.as<float>(), E, L.w_out, L.b_out, E, s.sa_tmp.as<float>(), false)) return 1;
         ln(s.sa_x.as<float>(), s.sa_tmp.as<float>(), L.n1w, L.n1b, nullptr, s.sa_x1.as<float>());
         if (gemm(s.sa_x1.as<float>(), E, L.w1, L.b1, FF, s.sa_ff.as<float>(), true)) return 1;
@@ -350,7 +388,7 @@ int run_network(pocr_engine *e, Slot &s) {
     const int Hh = c.lstm_hidden, npad = round_up(n, 16);
     {   // (re)allocation of any buffer whose address is baked into the cached graphs flushes them
         const void *before[4] = {s.xproj.p, s.hbuf.p, s.cbuf.p, nullptr};
-        if (s.xproj.reserve((size_t)n * T * 8 * Hh * sizeof(float))) return 1;
+        if (s.xproj.reserve((size_t)rows * 8 * Hh * sizeof(float))) return 1;
         if (2 * (size_t)2 * npad * Hh > 2 * s.h_stride || !s.hbuf.p) {
             const size_t cap_pad = (size_t)round_up(npad, 64);
             if (s.hbuf.reserve((size_t)2 * 2 * cap_pad * Hh * sizeof(float))) return 1;
@@ -360,9 +398,10 @@ int run_network(pocr_engine *e, Slot &s) {
         bool moved = before[0] != s.xproj.p || before[1] != s.hbuf.p || before[2] != s.cbuf.p;
         for (int l = 0; l < c.lstm_layers; ++l) {
             const void *yb = s.lstm_y[l].p;
-            if (s.lstm_y[l].reserve((size_t)n * T * 2 * Hh * sizeof(float))) return 1;
+            if (s.lstm_y[l].reserve((size_t)rows * 2 * Hh * sizeof(float))) return 1;
             moved = moved || yb != s.lstm_y[l].p;
         }
+        if (s.seqgeom.p != s.graph_geom) { moved = true; s.graph_geom = s.seqgeom.p; }    // per-line tables moved
         if (moved) {
             for (auto &kv : s.lstm_graphs) (void)hipGraphExecDestroy(kv.second);
             s.lstm_graphs.clear();
@@ -378,6 +417,7 @@ int run_network(pocr_engine *e, Slot &s) {
         la.h_in = s.hbuf.as<float>() + (size_t)(step & 1) * s.h_stride;
         la.h_out = s.hbuf.as<float>() + (size_t)((step + 1) & 1) * s.h_stride;
         la.c = s.cbuf.as<float>(); la.y = s.lstm_y[l].as<float>(); la.dims = dims;
+        la.line_T = s.g_line_T; la.row_off = s.g_row_off; la.slice_T = s.g_slice_T;
         la.n = n; la.npad = npad; la.T = T; la.H = Hh; la.step = step;
         const dim3 grid(Hh / 16, slices, 2);
         switch (Hh) {
@@ -394,7 +434,7 @@ int run_network(pocr_engine *e, Slot &s) {
     HIP_TRY(hipMemcpyAsync(s.lstm_dims.p, s.lstm_dims_host, 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
     for (int l = 0; l < c.lstm_layers; ++l) {
         ConvArgs a{};
-        a.x = layer_in; a.n = 1; a.H = 1; a.W = n * T; a.Ho = 1; a.Wo = n * T; a.cin = din;
+        a.x = layer_in; a.n = 1; a.H = 1; a.W = rows; a.Ho = 1; a.Wo = rows; a.cin = din;
         a.cout16 = e->proj_cout16; a.cout_valid = 8 * Hh; a.out_stride = 8 * Hh;
         a.wfrag = e->proj_w[l].as<float>(); a.bias = e->proj_b[l].as<float>(); a.y = s.xproj.as<float>();
         if (gemm128_k(a, st)) return 1;
@@ -439,9 +479,9 @@ int run_network(pocr_engine *e, Slot &s) {
     // ---- head: [n*T][din] -> logits [n][T][C]
     const int C = c.num_classes;
     {
-        if (s.logits.reserve((size_t)n * T * C * sizeof(float))) return 1;
+        if (s.logits.reserve((size_t)rows * C * sizeof(float))) return 1;
         ConvArgs a{};
-        a.x = layer_in; a.n = 1; a.H = 1; a.W = n * T; a.Ho = 1; a.Wo = n * T; a.cin = din;
+        a.x = layer_in; a.n = 1; a.H = 1; a.W = rows; a.Ho = 1; a.Wo = rows; a.cin = din;
         a.cout16 = e->head_cout16; a.cout_valid = C; a.out_stride = C;
         a.wfrag = e->head_w.as<float>(); a.bias = e->head_b.as<float>(); a.y = s.logits.as<float>();
         mark(POCR_STAGE_HEAD);
@@ -449,15 +489,15 @@ int run_network(pocr_engine *e, Slot &s) {
     }
     // ---- greedy CTC
     {
-        if (s.best.reserve((size_t)n * T * sizeof(int32_t))) return 1;
+        if (s.best.reserve((size_t)rows * sizeof(int32_t))) return 1;
         if (s.labels.reserve((size_t)n * T * sizeof(int32_t))) return 1;
         if (s.lens.reserve((size_t)n * sizeof(int32_t))) return 1;
         mark(POCR_STAGE_CTC);
-        const int frames = n * T;
+        const int frames = rows;
         hipLaunchKernelGGL(frame_argmax_kernel, dim3((frames + 3) / 4), dim3(256), 0, st,
                            s.logits.as<float>(), s.best.as<int32_t>(), frames, C);
         hipLaunchKernelGGL(ctc_collapse_kernel, dim3(n), dim3(64), 0, st, s.best.as<int32_t>(),
-                           s.labels.as<int32_t>(), s.lens.as<int32_t>(), T, C - 1);
+                           s.labels.as<int32_t>(), s.lens.as<int32_t>(), T, C - 1, s.g_line_T, s.g_row_off, T);
         HIP_TRY(hipGetLastError());
         mark(POCR_NUM_STAGES);
     }
@@ -466,10 +506,11 @@ int run_network(pocr_engine *e, Slot &s) {
 
 // async D2H of the chunk's results into the slot's pinned buffer (layout: labels | argmax | lens | logits)
 int enqueue_outputs(pocr_engine *e, Slot &s) {
-    const int n = s.n, T = (s.w_pad / 2) / 2, C = e->cfg.num_classes;
+    // pinned layout: labels [n][T_max] | frame argmax [rows] (room for n*T_max) | lens [n] | logits [rows][C]
+    const int n = s.n, T = s.t_max, C = e->cfg.num_classes, rows = s.rows;
     hipStream_t st = s.seq_stream;
     const size_t nt_bytes = (size_t)n * T * sizeof(int32_t);
-    const size_t lg_bytes = s.want_logits ? (size_t)n * T * C * sizeof(float) : 0;
+    const size_t lg_bytes = s.want_logits ? (size_t)rows * C * sizeof(float) : 0;
     const size_t need = 2 * nt_bytes + (size_t)round_up(n, 4) * sizeof(int32_t) + lg_bytes;
     if (need > s.pinned_cap) {
         if (s.pinned) (void)hipHostFree(s.pinned);
@@ -479,14 +520,14 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
     }
     char *pin = static_cast<char *>(s.pinned);
     HIP_TRY(hipMemcpyAsync(pin, s.labels.p, nt_bytes, hipMemcpyDeviceToHost, st));
-    if (s.want_argmax) HIP_TRY(hipMemcpyAsync(pin + nt_bytes, s.best.p, nt_bytes, hipMemcpyDeviceToHost, st));
+    if (s.want_argmax) HIP_TRY(hipMemcpyAsync(pin + nt_bytes, s.best.p, (size_t)rows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(pin + 2 * nt_bytes, s.lens.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (lg_bytes) HIP_TRY(hipMemcpyAsync(pin + 2 * nt_bytes + (size_t)round_up(n, 4) * sizeof(int32_t), s.logits.p, lg_bytes, hipMemcpyDeviceToHost, st));
     if (s.want_sparse) {
         if (T > SP_MAXT) return fail("sparse logits: T = %d exceeds %d frames", T, SP_MAXT);
         if (C > 256 * SP_COLS) return fail("sparse logits: C = %d exceeds %d classes", C, 256 * SP_COLS);
-        const size_t cap = (size_t)n * T * C;
-        if (s.sp_rowstat.reserve((size_t)n * T * 2 * sizeof(float)) || s.sp_colcount.reserve((size_t)n * C * sizeof(int32_t)) ||
+        const size_t cap = (size_t)rows * C;
+        if (s.sp_rowstat.reserve((size_t)rows * 2 * sizeof(float)) || s.sp_colcount.reserve((size_t)n * C * sizeof(int32_t)) ||
             s.sp_line_nnz.reserve((size_t)n * sizeof(int32_t)) || s.sp_line_off.reserve((size_t)(n + 1) * sizeof(int64_t)) ||
             s.sp_indptr.reserve((size_t)n * (C + 1) * sizeof(int32_t)) || s.sp_data.reserve(cap * sizeof(float)) ||
             s.sp_indices.reserve(cap * sizeof(int32_t)))
@@ -494,11 +535,11 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
         const int32_t *r0 = s.sp_has_rows ? s.sp_rows.as<int32_t>() : nullptr;
         const int32_t *r1 = s.sp_has_rows ? s.sp_rows.as<int32_t>() + n : nullptr;
         hipLaunchKernelGGL(sparse_count_kernel, dim3(n), dim3(256), 0, st, s.logits.as<float>(), r0, r1, s.sp_rowstat.as<float>(),
-                           s.sp_colcount.as<int32_t>(), s.sp_line_nnz.as<int32_t>(), T, C, s.sp_thr);
+                           s.sp_colcount.as<int32_t>(), s.sp_line_nnz.as<int32_t>(), T, C, s.sp_thr, s.g_line_T, s.g_row_off);
         hipLaunchKernelGGL(sparse_scan_kernel, dim3(1), dim3(64), 0, st, s.sp_line_nnz.as<int32_t>(), s.sp_line_off.as<int64_t>(), n);
         hipLaunchKernelGGL(sparse_fill_kernel, dim3(n), dim3(256), 0, st, s.logits.as<float>(), r0, r1, s.sp_rowstat.as<float>(),
                            s.sp_colcount.as<int32_t>(), s.sp_line_off.as<int64_t>(), s.sp_indptr.as<int32_t>(), s.sp_data.as<float>(),
-                           s.sp_indices.as<int32_t>(), T, C, s.sp_thr, (int64_t)cap);
+                           s.sp_indices.as<int32_t>(), T, C, s.sp_thr, (int64_t)cap, s.g_line_T, s.g_row_off);
         HIP_TRY(hipGetLastError());
         const size_t off_bytes = (size_t)(n + 1) * sizeof(int64_t), ip_bytes = (size_t)n * (C + 1) * sizeof(int32_t);
         const size_t need_sp = off_bytes + ip_bytes + cap / 4 * 8;     // room for 25 % density before a re-allocation
@@ -516,7 +557,7 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
 }
 
 int collect_outputs(pocr_engine *e, Slot &s, float *logits_ntc, int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n) {
-    const int n = s.n, T = (s.w_pad / 2) / 2, C = e->cfg.num_classes;
+    const int n = s.n, T = s.t_max, C = e->cfg.num_classes, rows = s.rows;
     HIP_TRY(hipStreamSynchronize(s.seq_stream));
     s.in_flight = false;
     const size_t nt_bytes = (size_t)n * T * sizeof(int32_t);
@@ -524,9 +565,9 @@ int collect_outputs(pocr_engine *e, Slot &s, float *logits_ntc, int32_t *frame_a
     if (logits_ntc && !s.want_logits) return fail("logits were not requested at launch");
     if (frame_argmax_nt && !s.want_argmax) return fail("frame argmax was not requested at launch");
     if (labels_nt) memcpy(labels_nt, pin, nt_bytes);
-    if (frame_argmax_nt) memcpy(frame_argmax_nt, pin + nt_bytes, nt_bytes);
+    if (frame_argmax_nt) memcpy(frame_argmax_nt, pin + nt_bytes, (size_t)rows * sizeof(int32_t));
     if (label_len_n) memcpy(label_len_n, pin + 2 * nt_bytes, (size_t)n * sizeof(int32_t));
-    if (logits_ntc) memcpy(logits_ntc, pin + 2 * nt_bytes + (size_t)round_up(n, 4) * sizeof(int32_t), (size_t)n * T * C * sizeof(float));
+    if (logits_ntc) memcpy(logits_ntc, pin + 2 * nt_bytes + (size_t)round_up(n, 4) * sizeof(int32_t), (size_t)rows * C * sizeof(float));
     if (e->profiling) {
         for (int i = 0; i < POCR_NUM_STAGES; ++i) s.stage_ms[i] = 0.f;
         const int order[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, POCR_STAGE_AGG, POCR_STAGE_LSTM, POCR_STAGE_HEAD, POCR_STAGE_CTC, POCR_NUM_STAGES};
@@ -742,7 +783,7 @@ void pocr_destroy(pocr_engine *e) {
             for (auto &b : *v) b.release();
         for (DevBuf *b : {&s.crops, &s.lines, &s.feat, &s.xproj, &s.hbuf, &s.cbuf, &s.logits, &s.best, &s.labels, &s.lens,
                           &s.sa_x, &s.sa_x1, &s.sa_qkv, &s.sa_att, &s.sa_tmp, &s.sa_ff, &s.sp_rowstat, &s.sp_colcount,
-                          &s.sp_line_nnz, &s.sp_line_off, &s.sp_indptr, &s.sp_data, &s.sp_indices, &s.sp_rows})
+                          &s.sp_line_nnz, &s.sp_line_off, &s.sp_indptr, &s.sp_data, &s.sp_indices, &s.sp_rows, &s.geom, &s.seqgeom})
             b->release();
         if (s.pinned) (void)hipHostFree(s.pinned);
         if (s.sp_pinned) (void)hipHostFree(s.sp_pinned);
@@ -763,25 +804,125 @@ void pocr_destroy(pocr_engine *e) {
 
 int pocr_num_slots(void) { return POCR_NUM_SLOTS; }
 
-int pocr_slot_stage_lines(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
-                          const int32_t *widths, int32_t n, int32_t w_pad, int32_t pad_left) {
+// Builds the per-line geometry tables of a staged set of lines (host) and uploads them in one blob.
+static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n) {
+    const pocr_config &c = e->cfg;
+    const int H = c.height, E = c.conv_out;
+    struct Blob {
+        std::vector<char> &buf;
+        size_t add(const void *src, size_t bytes) {
+            const size_t off = (buf.size() + 15) / 16 * 16;
+            buf.resize(off + bytes);
+            if (bytes) memcpy(buf.data() + off, src, bytes);
+            return off;
+        }
+    } blob{s.geom_host};
+    s.geom_host.clear();
+    std::vector<int32_t> lvl[3];
+    for (auto &v : lvl) v.resize(n);
+    int t_max = 0, w_max = 0;
+    for (int i = 0; i < n; ++i) {
+        lvl[0][i] = w_pads[i]; lvl[1][i] = w_pads[i] / 2; lvl[2][i] = lvl[1][i] / 2;
+        t_max = std::max(t_max, lvl[2][i]); w_max = std::max(w_max, w_pads[i]);
+    }
+    size_t off_lvl[3];
+    for (int k = 0; k < 3; ++k) off_lvl[k] = blob.add(lvl[k].data(), (size_t)n * sizeof(int32_t));
+    s.h_lvl2_off = off_lvl[2];
+    // per conv output: element offsets (prefix sums), and pixel-tile tables
+    size_t off_act[9], off_tiles[10];
+    int hh = H;
+    std::vector<int64_t> offs(n + 1);
+    std::vector<PixelTile> tiles;
+    for (int k = 0; k < 10; ++k) {
+        const int th = kConvTH[k], tw = kConvTW[k];
+        const int h_in = k < 9 ? hh : hh;                       // aggregation conv: one output row
+        const int rows_out = k < 9 ? h_in : 1;
+        tiles.clear();
+        for (int i = 0; i < n; ++i) {
+            const int w_in = lvl[kConvLvlIn[k]][i];
+            const int nh = (rows_out + th - 1) / th, nw = (w_in + tw - 1) / tw;
+            if (nh > 0x7fff || nw > 0xffff) return fail("line %d is too large for the tile table", i);
+            for (int a_ = 0; a_ < nh; ++a_)
+                for (int b_ = 0; b_ < nw; ++b_) tiles.push_back(PixelTile{i, (a_ << 16) | b_});
+        }
+        s.g_ntiles[k] = (int)tiles.size();
+        off_tiles[k] = blob.add(tiles.data(), tiles.size() * sizeof(PixelTile));
+        if (k < 9) {
+            const ConvLayer &L = kConvPlan[k];
+            const int h_out = h_in / L.ph;
+            int64_t acc = 0;
+            for (int i = 0; i < n; ++i) { offs[i] = acc; acc += (int64_t)h_out * lvl[kConvLvlOut[k]][i] * L.cout; }
+            offs[n] = acc;
+            s.act_elems[k] = acc;
+            off_act[k] = blob.add(offs.data(), (size_t)(n + 1) * sizeof(int64_t));
+            hh = h_out;
+        }
+    }
+    // sequence tensors: rows
+    std::vector<int32_t> row_off(n + 1), slice_T((n + 15) / 16, 0), row_t;
+    int rows = 0;
+    for (int i = 0; i < n; ++i) {
+        row_off[i] = rows;
+        rows += lvl[2][i];
+        slice_T[i / 16] = std::max(slice_T[i / 16], lvl[2][i]);
+    }
+    row_off[n] = rows;
+    row_t.resize(rows > 0 ? rows : 1);
+    for (int i = 0; i < n; ++i)
+        for (int t = 0; t < lvl[2][i]; ++t) row_t[row_off[i] + t] = t;
+    for (int i = 0; i <= n; ++i) offs[i] = (int64_t)row_off[i] * E;
+    const size_t off_feat = blob.add(offs.data(), (size_t)(n + 1) * sizeof(int64_t));
+    const size_t off_row = blob.add(row_off.data(), (size_t)(n + 1) * sizeof(int32_t));
+    const size_t off_slice = blob.add(slice_T.data(), slice_T.size() * sizeof(int32_t));
+    const size_t off_rowt = blob.add(row_t.data(), row_t.size() * sizeof(int32_t));
+    {
+        int cap = s.sg_cap > 0 ? s.sg_cap : 64;
+        while (cap < n) cap *= 2;
+        if (cap != s.sg_cap) {
+            s.seqgeom.release();
+            if (s.seqgeom.reserve(((size_t)2 * cap + 16 + cap / 16 + 16) * sizeof(int32_t))) return 1;
+            s.sg_cap = cap;
+        }
+        s.sg_host.assign((size_t)2 * cap + 16 + cap / 16 + 16, 0);
+        memcpy(s.sg_host.data(), lvl[2].data(), (size_t)n * sizeof(int32_t));
+        memcpy(s.sg_host.data() + cap, row_off.data(), (size_t)(n + 1) * sizeof(int32_t));
+        memcpy(s.sg_host.data() + 2 * cap + 16, slice_T.data(), slice_T.size() * sizeof(int32_t));
+    }
+    if (s.geom.reserve(s.geom_host.size())) return 1;
+    const char *d = static_cast<const char *>(s.geom.p);
+    for (int k = 0; k < 3; ++k) s.g_lvl_w[k] = reinterpret_cast<const int32_t *>(d + off_lvl[k]);
+    for (int k = 0; k < 9; ++k) s.g_act_off[k] = reinterpret_cast<const int64_t *>(d + off_act[k]);
+    for (int k = 0; k < 10; ++k) s.g_tiles[k] = reinterpret_cast<const PixelTile *>(d + off_tiles[k]);
+    s.g_feat_off = reinterpret_cast<const int64_t *>(d + off_feat);
+    (void)off_row; (void)off_slice;
+    s.g_line_T = s.seqgeom.as<int32_t>();
+    s.g_row_off = s.seqgeom.as<int32_t>() + s.sg_cap;
+    s.g_slice_T = s.seqgeom.as<int32_t>() + 2 * s.sg_cap + 16;
+    s.g_row_t = reinterpret_cast<const int32_t *>(d + off_rowt);
+    s.rows = rows; s.t_max = t_max; s.w_pad = w_max;
+    return 0;
+}
+
+int pocr_slot_stage_ragged(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
+                           const int32_t *widths, const int32_t *w_pads, int32_t n, int32_t pad_left) {
     if (check_slot(e, slot)) return 1;
     Slot &s = e->slot[slot];
     if (s.in_flight) return fail("slot %d has a launch in flight: collect it first", slot);
     s.staged = false;
     if (n <= 0) return fail("n must be positive (got %d)", n);
-    if (w_pad < 4) return fail("w_pad must be >= 4 (got %d)", w_pad);
     if (pad_left < 0) return fail("pad_left must be >= 0");
-    if (!crops || !crop_offsets || !widths) return fail("NULL input pointer");
+    if (!crops || !crop_offsets || !widths || !w_pads) return fail("NULL input pointer");
     HIP_TRY(hipSetDevice(e->device));
     const int H = e->cfg.height;
     size_t total = 0;
     for (int i = 0; i < n; ++i) {
         if (widths[i] < 0) return fail("line %d has negative width", i);
         if (crop_offsets[i] < 0) return fail("line %d has negative offset", i);
+        if (w_pads[i] < 4) return fail("line %d: w_pad must be >= 4 (got %d)", i, w_pads[i]);
         const size_t end = (size_t)crop_offsets[i] + (size_t)H * widths[i] * 3;
         if (end > total) total = end;
     }
+    if (build_geometry(e, s, w_pads, n)) return 1;
     // pinned staging: [LineDesc table | crop pool]; the H2D copies then run asynchronously on the slot's
     // stream (they overlap the other slot's kernels) and the caller's buffers are free on return
     const size_t desc_bytes = (size_t)round_up(n, 4) * sizeof(LineDesc);
@@ -799,8 +940,19 @@ int pocr_slot_stage_lines(pocr_engine *e, int32_t slot, const uint8_t *crops, co
     if (s.lines.reserve((size_t)n * sizeof(LineDesc))) return 1;
     if (total) HIP_TRY(hipMemcpyAsync(s.crops.p, static_cast<char *>(s.host_in) + desc_bytes, total, hipMemcpyHostToDevice, s.stream));
     HIP_TRY(hipMemcpyAsync(s.lines.p, desc, (size_t)n * sizeof(LineDesc), hipMemcpyHostToDevice, s.stream));
-    s.n = n; s.w_pad = w_pad; s.staged = true; s.have_ms = false;
+    HIP_TRY(hipMemcpyAsync(s.geom.p, s.geom_host.data(), s.geom_host.size(), hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(hipMemcpyAsync(s.seqgeom.p, s.sg_host.data(), s.sg_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(hipStreamSynchronize(s.stream));        // geom_host is pageable: finish the copy before it can change
+    s.n = n; s.staged = true; s.have_ms = false;
     return 0;
+}
+
+int pocr_slot_stage_lines(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
+                          const int32_t *widths, int32_t n, int32_t w_pad, int32_t pad_left) {
+    if (n <= 0) return fail("n must be positive (got %d)", n);
+    if (w_pad < 4) return fail("w_pad must be >= 4 (got %d)", w_pad);
+    std::vector<int32_t> wp(n, w_pad);
+    return pocr_slot_stage_ragged(e, slot, crops, crop_offsets, widths, wp.data(), n, pad_left);
 }
 
 int pocr_slot_launch(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t want_argmax) {
@@ -836,13 +988,13 @@ int pocr_slot_launch_sparse(pocr_engine *e, int32_t slot, const int32_t *row_beg
     if (s.in_flight) return fail("slot %d already has a launch in flight", slot);
     if ((row_begin == nullptr) != (row_end == nullptr)) return fail("row_begin and row_end must both be given or both be NULL");
     HIP_TRY(hipSetDevice(e->device));
-    const int T = (s.w_pad / 2) / 2;
     s.sp_has_rows = row_begin != nullptr;
     if (s.sp_has_rows) {
         std::vector<int32_t> rows(2 * (size_t)s.n);
         for (int i = 0; i < s.n; ++i) {
-            if (row_begin[i] < 0 || row_end[i] > T || row_begin[i] > row_end[i])
-                return fail("line %d: row range [%d, %d) outside [0, %d]", i, row_begin[i], row_end[i], T);
+            const int Ti = (int)(reinterpret_cast<const int32_t *>(s.geom_host.data() + s.h_lvl2_off)[i]);
+            if (row_begin[i] < 0 || row_end[i] > Ti || row_begin[i] > row_end[i])
+                return fail("line %d: row range [%d, %d) outside [0, %d]", i, row_begin[i], row_end[i], Ti);
             rows[i] = row_begin[i]; rows[s.n + i] = row_end[i];
         }
         if (s.sp_rows.reserve(rows.size() * sizeof(int32_t))) return 1;
@@ -933,7 +1085,7 @@ int pocr_ctc_greedy(int device_id, const float *logits_ntc, int32_t n, int32_t T
     if (rc) return done(1);
     if (hipMemcpy(lg.p, logits_ntc, nt * C * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
     hipLaunchKernelGGL(frame_argmax_kernel, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, 0, lg.as<float>(), best.as<int32_t>(), (int)nt, C);
-    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(n), dim3(64), 0, 0, best.as<int32_t>(), lab.as<int32_t>(), len.as<int32_t>(), T, C - 1);
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(n), dim3(64), 0, 0, best.as<int32_t>(), lab.as<int32_t>(), len.as<int32_t>(), T, C - 1, nullptr, nullptr, T);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return done(fail("CTC kernels failed"));
     if (frame_argmax_nt && hipMemcpy(frame_argmax_nt, best.p, nt * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
     if (hipMemcpy(labels_nt, lab.p, nt * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
@@ -971,14 +1123,14 @@ int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t
     Slot &s = e->slot[e->last_slot];
     if (!s.staged) return fail("nothing has been run");
     HIP_TRY(hipSetDevice(e->device));
-    const int n = s.n, T = (s.w_pad / 2) / 2;
+    const size_t rows = (size_t)s.rows;
     const float *src = nullptr;
     size_t sz = 0;
-    if (what >= 0 && what < 9) { src = s.act[what].as<float>(); sz = (size_t)n * s.act_h[what] * s.act_w[what] * s.act_c[what]; }
-    else if (what == 9) { src = s.feat.as<float>(); sz = (size_t)n * T * e->cfg.conv_out; }
+    if (what >= 0 && what < 9) { src = s.act[what].as<float>(); sz = (size_t)s.act_elems[what]; }
+    else if (what == 9) { src = s.feat.as<float>(); sz = rows * e->cfg.conv_out; }
     else if (e->cfg.arch == POCR_ARCH_SA && what == 10) { src = nullptr; return fail("activation 10 (LayerNorm+PE) is not retained"); }
-    else if (e->cfg.arch == POCR_ARCH_SA && what >= 11 && what < 11 + e->cfg.sa_layers) { src = s.sa_y[what - 11].as<float>(); sz = (size_t)n * T * e->cfg.conv_out; }
-    else if (e->cfg.arch == POCR_ARCH_BLSTM && what >= 10 && what < 10 + e->cfg.lstm_layers) { src = s.lstm_y[what - 10].as<float>(); sz = (size_t)n * T * 2 * e->cfg.lstm_hidden; }
+    else if (e->cfg.arch == POCR_ARCH_SA && what >= 11 && what < 11 + e->cfg.sa_layers) { src = s.sa_y[what - 11].as<float>(); sz = rows * e->cfg.conv_out; }
+    else if (e->cfg.arch == POCR_ARCH_BLSTM && what >= 10 && what < 10 + e->cfg.lstm_layers) { src = s.lstm_y[what - 10].as<float>(); sz = rows * 2 * e->cfg.lstm_hidden; }
     else return fail("unknown activation id %d", what);
     if (n_floats) *n_floats = sz;
     const size_t k = cap < sz ? cap : sz;

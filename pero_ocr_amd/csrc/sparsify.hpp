@@ -29,12 +29,15 @@ __device__ __forceinline__ bool sp_keep(float x, float rmax, float rsum, float t
 // logits [n][T][C]; rowstat [n][T][2]; colcount [n][C]; line_nnz [n]
 __global__ __launch_bounds__(256) void sparse_count_kernel(const float *logits, const int32_t *row_begin,
                                                            const int32_t *row_end, float *rowstat, int32_t *colcount,
-                                                           int32_t *line_nnz, int T, int C, float thr) {
+                                                           int32_t *line_nnz, int T_uniform, int C, float thr,
+                                                           const int32_t *line_T, const int32_t *row_off) {
     __shared__ float smax[SP_MAXT], ssum[SP_MAXT];
     __shared__ int wsum[4];
     const int line = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = line_T ? line_T[line] : T_uniform;
+    const size_t row0 = row_off ? (size_t)row_off[line] : (size_t)line * T_uniform;     // first row of this line
     const int r0 = row_begin ? row_begin[line] : 0, r1 = row_end ? row_end[line] : T;
-    const float *x = logits + (size_t)line * T * C;
+    const float *x = logits + row0 * C;
     for (int t = r0 + wave; t < r1; t += 4) {
         const float *row = x + (size_t)t * C;
         float m = -INFINITY;
@@ -47,8 +50,8 @@ __global__ __launch_bounds__(256) void sparse_count_kernel(const float *logits, 
         for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
         if (lane == 0) {
             smax[t] = m; ssum[t] = s;
-            rowstat[((size_t)line * T + t) * 2] = m;
-            rowstat[((size_t)line * T + t) * 2 + 1] = s;
+            rowstat[(row0 + t) * 2] = m;
+            rowstat[(row0 + t) * 2 + 1] = s;
         }
     }
     __syncthreads();
@@ -90,12 +93,15 @@ __global__ void sparse_scan_kernel(const int32_t *line_nnz, int64_t *line_off, i
 __global__ __launch_bounds__(256) void sparse_fill_kernel(const float *logits, const int32_t *row_begin,
                                                           const int32_t *row_end, const float *rowstat,
                                                           const int32_t *colcount, const int64_t *line_off,
-                                                          int32_t *indptr, float *data, int32_t *indices, int T, int C,
-                                                          float thr, int64_t capacity) {
+                                                          int32_t *indptr, float *data, int32_t *indices, int T_uniform, int C,
+                                                          float thr, int64_t capacity, const int32_t *line_T,
+                                                          const int32_t *row_off) {
     __shared__ int part[256];
     const int line = blockIdx.x, tid = threadIdx.x;
+    const int T = line_T ? line_T[line] : T_uniform;
+    const size_t row0 = row_off ? (size_t)row_off[line] : (size_t)line * T_uniform;
     const int r0 = row_begin ? row_begin[line] : 0, r1 = row_end ? row_end[line] : T;
-    const float *x = logits + (size_t)line * T * C;
+    const float *x = logits + row0 * C;
     const int32_t *cc = colcount + (size_t)line * C;
     // exclusive scan over columns: thread i owns the contiguous column block [i*per, (i+1)*per)
     const int per = (C + 255) / 256;
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256) void sparse_fill_kernel(const float *logits, c
         int64_t pos = base + ip[c];
         for (int t = r0; t < r1; ++t) {
             const float v = x[(size_t)t * C + c];
-            const float m = rowstat[((size_t)line * T + t) * 2], s = rowstat[((size_t)line * T + t) * 2 + 1];
+            const float m = rowstat[(row0 + t) * 2], s = rowstat[(row0 + t) * 2 + 1];
             if (sp_keep(v, m, s, thr)) {
                 if (pos < capacity) { data[pos] = v; indices[pos] = t - r0; }
                 ++pos;

@@ -143,7 +143,7 @@ class PytorchEngineLineOCR(BaseEngineLineOCR):
         return labels_to_strings(labels, lens, self.characters), mats
 
     def _slot_frames(self, slot):
-        return self.model._slot_shape[slot][1]
+        return self.model._slot_shape[slot][1]      # T_max of the staged lines
 
     def _recognise_chunk(self, lines, chunk: Chunk, want_logits: bool):
         return self._collect_chunk(self._submit_chunk(lines, chunk, want_logits, 0))
