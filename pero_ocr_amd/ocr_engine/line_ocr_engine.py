@@ -60,6 +60,46 @@ def plan_chunks(widths: Sequence[int], max_input_horizontal_pixels: int, line_pa
     return chunks
 
 
+@dataclass
+class Launch:
+    """A device launch: one or more consecutive reference chunks executed together.  Every line keeps
+    the padded width of ITS chunk (that width is numerics); which chunks share a launch is only an
+    execution choice, so small chunks are merged until a launch carries enough work to fill the GPU."""
+    chunks: List[Chunk]
+
+    @property
+    def line_ids(self) -> List[int]:
+        return [i for c in self.chunks for i in c.line_ids]
+
+    @property
+    def w_pads(self) -> List[int]:
+        return [c.w_pad for c in self.chunks for _ in c.line_ids]
+
+    @property
+    def work(self) -> int:
+        return sum(len(c.line_ids) * c.w_pad for c in self.chunks)
+
+
+LAUNCH_WORK_TARGET = 256 * 576          # padded pixel columns per launch (= one BASELINE config-2 chunk)
+
+
+def plan_launches(chunks: Sequence[Chunk], target: int = LAUNCH_WORK_TARGET) -> List[Launch]:
+    """Greedy merge of consecutive chunks (plan order = descending width) up to `target` work."""
+    out: List[Launch] = []
+    cur: List[Chunk] = []
+    acc = 0
+    for ch in chunks:
+        w = len(ch.line_ids) * ch.w_pad
+        if cur and acc + w > target:
+            out.append(Launch(cur))
+            cur, acc = [], 0
+        cur.append(ch)
+        acc += w
+    if cur:
+        out.append(Launch(cur))
+    return out
+
+
 class BaseEngineLineOCR:
     def __init__(self, json_def, device, batch_size=8, model_type="ctc"):
         with open(json_def, "r", encoding="utf8") as f:
@@ -119,19 +159,19 @@ class BaseEngineLineOCR:
 
         device_sparse = sparse_logits and not no_logits and getattr(self, "supports_device_sparsify", False)
 
-        def scatter(chunk, texts, chunk_logits):
-            for k, i in enumerate(chunk.line_ids):
+        def scatter(line_ids, texts, chunk_logits):
+            """chunk_logits: per-line list (ragged launches, GPU-built csc or dense [T_i, C]) or [n, T, C] array."""
+            for k, i in enumerate(line_ids):
                 transcriptions[i] = texts[k]
             if no_logits:
                 return
             if device_sparse:           # chunk_logits is already a list of csc_matrix (built on the GPU)
-                for k, i in enumerate(chunk.line_ids):
+                for k, i in enumerate(line_ids):
                     w = lines[i].shape[1]
                     coords_out[i] = [None, None] if tight_crop_logits else [pad // sub, (pad + w) // sub]
                     logits_out[i] = chunk_logits[k]
                 return
-            probs = softmax(chunk_logits, axis=2) if sparse_logits else None   # one vectorised pass per chunk
-            for k, i in enumerate(chunk.line_ids):
+            for k, i in enumerate(line_ids):
                 w = lines[i].shape[1]
                 first, last = pad // sub, (pad + w) // sub
                 ll = chunk_logits[k]
@@ -141,34 +181,40 @@ class BaseEngineLineOCR:
                 else:
                     coords_out[i] = [first, last]
                 if sparse_logits:
-                    pp = probs[k][first:last] if tight_crop_logits else probs[k]
-                    ll = sparse.csc_matrix(np.where(pp < SPARSE_PROB_THRESHOLD, np.float32(0), ll))
+                    ll = sparse.csc_matrix(np.where(softmax(ll, axis=1) < SPARSE_PROB_THRESHOLD, np.float32(0), ll))
                 logits_out[i] = ll
 
         # One-deep software pipeline over the chunks: chunk k+1 is enqueued on the other engine slot
         # before chunk k is collected, so its GPU work overlaps chunk k's read-back and the host-side
         # softmax / CSC assembly.  (The reference runs chunk after chunk, line_ocr_engine.py:80-129;
         # the chunks are independent, so the results are the same.)
-        pipelined = hasattr(self, "_submit_chunk")
-        pending = None
-        for k, chunk in enumerate(plan_chunks([l.shape[1] for l in lines], self.max_input_horizontal_pixels, pad)):
+        chunks = plan_chunks([l.shape[1] for l in lines], self.max_input_horizontal_pixels, pad)
+        for chunk in chunks:
             if chunk.max_width + 2 * pad > chunk.w_pad:
                 print(f"WARNING: Line too long for OCR engine. Cropping from {chunk.max_width + 2 * pad} px "
                       f"down to {chunk.w_pad}.")
-            if not pipelined:
-                scatter(chunk, *self._recognise_chunk(lines, chunk, want_logits=not no_logits))
-                continue
+        if not hasattr(self, "_submit_launch"):          # engines without the asynchronous ragged path
+            for chunk in chunks:
+                scatter(chunk.line_ids, *self._recognise_chunk(lines, chunk, want_logits=not no_logits))
+            return transcriptions, logits_out, coords_out
+
+        # One-deep software pipeline over LAUNCHES (merged chunks): launch k+1 is enqueued on the other
+        # engine slot before launch k is collected, so its GPU work overlaps launch k's read-back and the
+        # host-side assembly.  (The reference runs chunk after chunk, line_ocr_engine.py:80-129; lines are
+        # independent given their padded width, so the results are the same.)
+        pending = None
+        for k, launch in enumerate(plan_launches(chunks)):
             rows = None
             if device_sparse:
                 rows = (None, None)
                 if tight_crop_logits:
-                    ws = [lines[i].shape[1] for i in chunk.line_ids]
-                    rows = ([min(pad // sub, chunk.frames)] * len(ws), [min((pad + w) // sub, chunk.frames) for w in ws])
-            handle = self._submit_chunk(lines, chunk, not no_logits, k % 2, rows) if device_sparse else \
-                self._submit_chunk(lines, chunk, not no_logits, k % 2)
+                    frames = [(wp // 2) // 2 for wp in launch.w_pads]
+                    ws = [lines[i].shape[1] for i in launch.line_ids]
+                    rows = ([min(pad // sub, f) for f in frames], [min((pad + w) // sub, f) for w, f in zip(ws, frames)])
+            handle = self._submit_launch(lines, launch, not no_logits, k % 2, rows)
             if pending is not None:
-                scatter(pending[0], *self._collect_chunk(pending[1]))
-            pending = (chunk, handle)
+                scatter(pending[0].line_ids, *self._collect_launch(pending[1]))
+            pending = (launch, handle)
         if pending is not None:
-            scatter(pending[0], *self._collect_chunk(pending[1]))
+            scatter(pending[0].line_ids, *self._collect_launch(pending[1]))
         return transcriptions, logits_out, coords_out

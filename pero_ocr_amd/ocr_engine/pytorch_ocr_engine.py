@@ -106,47 +106,53 @@ class PytorchEngineLineOCR(BaseEngineLineOCR):
         logits, _amax, labels, lens = self.model.run_batch(batch_data, want_logits=True, want_argmax=False)
         return labels_to_strings(labels, lens, self.characters), logits
 
-    def _pack_chunk(self, lines, chunk: Chunk):
-        flat = [np.ascontiguousarray(lines[i], dtype=np.uint8).reshape(-1) for i in chunk.line_ids]
-        widths = np.array([lines[i].shape[1] for i in chunk.line_ids], dtype=np.int32)
+    def _pack_lines(self, lines, line_ids):
+        flat = [np.ascontiguousarray(lines[i], dtype=np.uint8).reshape(-1) for i in line_ids]
+        widths = np.array([lines[i].shape[1] for i in line_ids], dtype=np.int32)
         sizes = np.array([f.size for f in flat], dtype=np.int64)
         offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
         pool = np.concatenate(flat) if flat else np.zeros(0, np.uint8)
         return pool, offsets, widths
 
-    def _submit_chunk(self, lines, chunk: Chunk, want_logits: bool, slot: int, sparse_rows=None):
-        """Ragged, asynchronous: the crops go to the GPU un-padded (the zero padding of
-        line_ocr_engine.py:121-123 happens inside the first kernel's staging) and the call returns
-        as soon as the chunk is enqueued on the slot's stream.  sparse_rows = None: dense logits (if
-        wanted); sparse_rows = (row_begin, row_end) or (None, None): the softmax / p < 1e-4 / CSC step
-        of line_ocr_engine.py:168-171 runs on the GPU and only CSC triplets come back."""
-        pool, offsets, widths = self._pack_chunk(lines, chunk)
-        self.model.slot_stage_lines(slot, pool, offsets, widths, chunk.w_pad, self.line_padding_px)
+    def _submit_launch(self, lines, launch, want_logits: bool, slot: int, sparse_rows=None):
+        """Ragged, asynchronous: the crops of one or more reference chunks go to the GPU un-padded, each
+        line with the padded width of its own chunk (the zero padding of line_ocr_engine.py:121-123
+        happens inside the first kernel's staging); the call returns as soon as the work is enqueued on
+        the slot's streams.  sparse_rows = None: dense logits (if wanted); (row_begin, row_end) or
+        (None, None): the softmax / p < 1e-4 / CSC step of line_ocr_engine.py:168-171 runs on the GPU."""
+        ids = launch.line_ids
+        pool, offsets, widths = self._pack_lines(lines, ids)
+        frames = self.model.slot_stage_ragged(slot, pool, offsets, widths, launch.w_pads, self.line_padding_px)
         if sparse_rows is not None and want_logits:
             self.model.slot_launch_sparse(slot, sparse_rows[0], sparse_rows[1], SPARSE_PROB_THRESHOLD)
-            return ("sparse", slot, sparse_rows)
+            return ("sparse", slot, sparse_rows, frames)
         self.model.slot_launch(slot, want_logits=want_logits, want_argmax=False)
-        return ("dense", slot, None)
+        return ("dense", slot, None, frames)
 
-    def _collect_chunk(self, handle):
-        kind, slot, rows = handle
+    def _collect_launch(self, handle):
+        """-> (strings, per-line logits: list of [T_i, C] views / csc matrices, or None)"""
+        kind, slot, rows, frames = handle
         if kind == "dense":
             logits, _amax, labels, lens = self.model.slot_collect(slot)
-            return labels_to_strings(labels, lens, self.characters), logits
+            per_line = None
+            if logits is not None:
+                ends = np.cumsum(frames)
+                per_line = [logits[e - f:e] for e, f in zip(ends, frames)]
+            return labels_to_strings(labels, lens, self.characters), per_line
         data, indices, indptr, line_off, _amax, labels, lens = self.model.slot_collect_sparse(slot)
         n, C = indptr.shape[0], indptr.shape[1] - 1
         mats = []
         for i in range(n):
             a, b = int(line_off[i]), int(line_off[i + 1])
-            nrows = (int(rows[1][i]) - int(rows[0][i])) if rows[0] is not None else self._slot_frames(slot)
+            nrows = (int(rows[1][i]) - int(rows[0][i])) if rows[0] is not None else int(frames[i])
             mats.append(sparse.csc_matrix((data[a:b], indices[a:b], indptr[i]), shape=(nrows, C)))
         return labels_to_strings(labels, lens, self.characters), mats
 
-    def _slot_frames(self, slot):
-        return self.model._slot_shape[slot][1]      # T_max of the staged lines
-
     def _recognise_chunk(self, lines, chunk: Chunk, want_logits: bool):
-        return self._collect_chunk(self._submit_chunk(lines, chunk, want_logits, 0))
+        """One reference chunk, blocking (the seam BaseEngineLineOCR falls back to)."""
+        from .line_ocr_engine import Launch
+        texts, per_line = self._collect_launch(self._submit_launch(lines, Launch([chunk]), want_logits, 0))
+        return texts, (np.stack(per_line) if per_line is not None else None)
 
     supports_device_sparsify = True
 

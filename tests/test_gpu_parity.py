@@ -505,3 +505,46 @@ def test_engine_lifecycle_and_buffer_growth(small):
         e.close()
     with pytest.raises(RuntimeError):
         _native.NativeEngine(spec, flat[:-1], 0)            # wrong blob size is refused by pocr_create
+
+
+def test_merged_ragged_launch_is_bit_identical_to_per_chunk_runs(golden, tmp_path):
+    """Lines are independent given their padded width, so staging several reference chunks as ONE ragged
+    launch (every line keeps its own chunk's W_pad) must give exactly the bits of running the chunks
+    one by one - logits, per-frame argmax, labels.  This is what lets process_lines merge the small
+    chunks the reference's default batch_size produces without touching the numerical contract."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    from pero_ocr_amd.ocr_engine import line_ocr_engine
+    g = golden("ragged")
+    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=g.batch_size)
+    crops = g.crops()
+    chunks = line_ocr_engine.plan_chunks(g.widths, eng.max_input_horizontal_pixels)
+    assert len(chunks) > 3
+    per_chunk = {}
+    for ch in chunks:                                   # chunk by chunk, uniform staging
+        pool, off, wd = eng._pack_lines(crops, ch.line_ids)
+        eng.model.stage_lines(pool, off, wd, ch.w_pad, eng.line_padding_px)
+        lg, am, lab, ln = eng.model.run_staged(True, True)
+        for k, i in enumerate(ch.line_ids):
+            per_chunk[i] = (lg[k], am[k], lab[k, :ln[k]])
+    launch = line_ocr_engine.Launch(chunks)             # everything in one ragged launch
+    pool, off, wd = eng._pack_lines(crops, launch.line_ids)
+    frames = eng.model.slot_stage_ragged(1, pool, off, wd, launch.w_pads, eng.line_padding_px)
+    eng.model.slot_launch(1, want_logits=True, want_argmax=True)
+    lg, am, lab, ln = eng.model.slot_collect(1)
+    ends = np.cumsum(frames)
+    for k, i in enumerate(launch.line_ids):
+        a, b = ends[k] - frames[k], ends[k]
+        assert np.array_equal(lg[a:b], per_chunk[i][0]), f"line {i}: logits differ"
+        assert np.array_equal(am[a:b], per_chunk[i][1])
+        assert np.array_equal(lab[k, :ln[k]], per_chunk[i][2])
+        assert np.array_equal(am[a:b], g.argmax(i))     # and both equal the reference fixture
+
+
+def test_plan_launches_merges_without_reordering():
+    from pero_ocr_amd.ocr_engine import line_ocr_engine as le
+    widths = synth.make_widths(5, 500)
+    chunks = le.plan_chunks(widths, 3840)
+    launches = le.plan_launches(chunks)
+    assert [c for l in launches for c in l.chunks] == chunks
+    assert all(l.work <= le.LAUNCH_WORK_TARGET or len(l.chunks) == 1 for l in launches)
+    assert len(launches) < len(chunks) / 4
