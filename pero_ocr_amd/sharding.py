@@ -94,9 +94,11 @@ class ShardedLineOCR:
         mine = assign_chunks(chunks, world)[rank]
         labs, lens, ids = [], [], []
         t_max = max([chunks[i].frames for i in mine], default=0)
-        for ci in mine:
+        many = getattr(self.recognise, "many", None)
+        results = many(lines, [chunks[ci] for ci in mine]) if many else None     # merged, pipelined launches
+        for k, ci in enumerate(mine):
             ch = chunks[ci]
-            lab, ln = self.recognise(lines, ch)
+            lab, ln = results[k] if results is not None else self.recognise(lines, ch)
             pad = np.full((lab.shape[0], t_max), -1, dtype=np.int32)
             pad[:, :lab.shape[1]] = lab
             labs.append(pad)
@@ -116,11 +118,35 @@ class ShardedLineOCR:
 def engine_recogniser(engine) -> Callable:
     """Adapter: PytorchEngineLineOCR -> the `recognise` callable (labels only, no logits)."""
     def recognise(lines, chunk: Chunk):
-        flat = [np.ascontiguousarray(lines[i], dtype=np.uint8).reshape(-1) for i in chunk.line_ids]
-        widths = np.array([lines[i].shape[1] for i in chunk.line_ids], dtype=np.int32)
-        sizes = np.array([f.size for f in flat], dtype=np.int64)
-        offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
-        engine.model.stage_lines(np.concatenate(flat), offsets, widths, chunk.w_pad, engine.line_padding_px)
+        pool, offsets, widths = engine._pack_lines(lines, chunk.line_ids)
+        engine.model.stage_lines(pool, offsets, widths, chunk.w_pad, engine.line_padding_px)
         _lg, _am, labels, lens = engine.model.run_staged(want_logits=False, want_argmax=False)
         return labels, lens
+
+    def many(lines, chunks):
+        """All of this rank's chunks: merged into ragged launches and software-pipelined over the
+        engine's two slots (the same path PytorchEngineLineOCR.process_lines uses)."""
+        from .ocr_engine.line_ocr_engine import plan_launches
+        out = {}
+
+        def finish(launch, handle):
+            _kind, slot, _rows, _frames = handle
+            _lg, _am, labels, lens = engine.model.slot_collect(slot)
+            k = 0
+            for ch in launch.chunks:
+                m = len(ch.line_ids)
+                out[id(ch)] = (labels[k:k + m, :ch.frames], lens[k:k + m])
+                k += m
+
+        pending = None
+        for j, launch in enumerate(plan_launches(chunks)):
+            handle = engine._submit_launch(lines, launch, False, j % 2)
+            if pending is not None:
+                finish(*pending)
+            pending = (launch, handle)
+        if pending is not None:
+            finish(*pending)
+        return [out[id(ch)] for ch in chunks]
+
+    recognise.many = many
     return recognise
