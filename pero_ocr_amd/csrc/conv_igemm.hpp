@@ -92,8 +92,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 template <int KH, int KW, int PADH, int PADW, int TH, int MW, int NS, int NWAVE, int KC,
-          int POOLH, int POOLW, int ACT, bool BN, int STAGER, int PIPE = PIPE_PLAIN, int ABL3 = 0>
-__global__ __launch_bounds__(NWAVE * 64, 2) void conv_igemm_kernel(ConvArgs a) {   // 2 waves per SIMD: two workgroups per CU cover each other's stalls
+          int POOLH, int POOLW, int ACT, bool BN, int STAGER, int PIPE = PIPE_PLAIN, int ABL3 = 0, int MINW = 2>
+__global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a) {   // 2 waves per SIMD: two workgroups per CU cover each other's stalls
     constexpr int TW = 16 * MW;
     constexpr int MS = TH * MW;                 // 16-pixel row-tiles per workgroup (every wave holds all of them)
     constexpr int NT = NS * NWAVE * 16;         // output channels per workgroup

@@ -32,6 +32,16 @@ struct Variant { const char *name; void (*fn)(ConvArgs, hipStream_t); int nt; };
         launch(conv_igemm_kernel<3, 3, 1, 1, TH, MW, NS, NW, KC, PH, PW, ACT, BN, STAGE_F32_NHWC, PIPE, ABL>, TH,   \
                16 * MW, NS * NW * 16, NW * 64, a, st);                                                             \
     }
+#define VARW(NAME, TH, MW, NS, NW, PH, PW, ACT, BN, MINW)                                                           \
+    static void NAME(ConvArgs a, hipStream_t st) {                                                                 \
+        launch(conv_igemm_kernel<3, 3, 1, 1, TH, MW, NS, NW, 16, PH, PW, ACT, BN, STAGE_F32_NHWC, PIPE_INTERLEAVED, 0, MINW>, TH, \
+               16 * MW, NS * NW * 16, NW * 64, a, st);                                                             \
+    }
+VARW(h5_w3_nt128, 5, 1, 2, 4, 1, 1, ACT_LEAKY, true, 3)
+VARW(h5_w4_nt64,  5, 1, 1, 4, 1, 1, ACT_LEAKY, true, 4)
+VARW(h5_w3_nt256, 5, 1, 4, 4, 1, 1, ACT_LEAKY, true, 3)
+VARW(h10_w3,      5, 1, 2, 4, 1, 1, ACT_RELU, false, 3)
+VARW(h20_w3,      4, 2, 1, 4, 1, 1, ACT_RELU, false, 3)
 #define P0 PIPE_PLAIN
 #define P3 PIPE_INTERLEAVED
 #define P4 PIPE_DEEP
@@ -91,13 +101,14 @@ int main(int argc, char **argv) {
     if (layer >= 8) vars = {{"plain TH5 MW1 NS4 NW4 KC16 (base)", h5_plain, 256}, {"plain KC32", h5_plain_kc32, 256},
                             {"plain NS2 NW8", h5_plain_nw8, 256}, {"plain MW2 NS2 NT128", h5_plain_mw2, 128},
                             {"interleaved (shipped)", h5_p3, 256}, {"interleaved NT128", h5_p3_nt128, 128},
-                            {"interleaved NT64", h5_p3_nt64, 64}, {"deep prefetch", h5_p4, 256}, {"glds weights", h5_p5, 256}, {"glds weights NT128", h5_p5_nt128, 128}, {"deep prefetch NT128", h5_p4_nt128, 128},
+                            {"interleaved NT64", h5_p3_nt64, 64}, {"interleaved NT128, 3 waves/SIMD", h5_w3_nt128, 128},
+                            {"interleaved NT64, 4 waves/SIMD", h5_w4_nt64, 64}, {"interleaved NT256 forced 3 waves/SIMD", h5_w3_nt256, 256}, {"deep prefetch", h5_p4, 256}, {"glds weights", h5_p5, 256}, {"glds weights NT128", h5_p5_nt128, 128}, {"deep prefetch NT128", h5_p4_nt128, 128},
                             {"ABL no global loads", h5_a1, 256}, {"ABL no LDS writes (loads die too)", h5_a2, 256},
                             {"ABL no loads/writes", h5_a3, 256}, {"ABL no ds_read", h5_a4, 256}, {"ABL no barrier", h5_a8, 256},
                             {"ABL MFMA stream only", h5_a15, 256}, {"ABL loads waited at step end, no writes", h5_a18, 256}};
     else if (layer >= 5) vars = {{"plain TH10 MW1 NS2 NW4 (base)", h10_plain, 128}, {"plain TH5 NS4 NT256", h10_plain_th5, 256},
                             {"interleaved (shipped)", h10_p3, 128}, {"interleaved TH5 NS4 NT256", h10_p3_th5, 256},
-                            {"deep prefetch", h10_p4, 128}, {"glds weights", h10_p5, 128}};
+                            {"deep prefetch", h10_p4, 128}, {"glds weights", h10_p5, 128}, {"interleaved TH5 NS2 NT128, 3 waves/SIMD", h10_w3, 128}};
     else if (layer == 3) vars = {{"plain TH4 MW2 NS2 NW4 (base)", h20_plain, 128}, {"interleaved (shipped)", h20_p3, 128},
                             {"interleaved TH10 MW1", h20_p3_th10, 128}, {"deep prefetch", h20_p4, 128}};
     else if (layer == 2 || layer == 4) vars = {{"plain TH4 MW2 NS2 NW4 NT128 (base)", p22_plain, 128}, {"plain TH4 MW4 NS1 NT64", p22_plain_nt64, 64},
