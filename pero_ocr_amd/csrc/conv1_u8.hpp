@@ -1,0 +1,96 @@
+// conv1_u8.hpp — first layer of the backbone fused with the batch assembly and normalisation:
+//   zero-pad batch assembly      pero_ocr/ocr_engine/line_ocr_engine.py:121-127
+//   uint8 -> float32 / 255.0     pero_ocr/ocr_engine/pytorch_ocr_engine.py:61-62
+//   conv 3->64, 3x3 pad 1, ReLU  first VGG block (pero_ocr/ocr_engine/transformer.py:86-110)
+// The crops stay uint8 and un-padded in HBM (68 KB per 40x576 line instead of 276 KB as fp32); a workgroup
+// stages the (4+2) x (32+2) x 3 halo of its pixel tile into LDS through the 256-entry i/255.0f table
+// (bit-exact with torch's true division), zero where the padded row has no crop pixel, and feeds
+// v_mfma_f32_16x16x4_f32 straight from that halo: the im2col matrix (K = 27, padded to 32) is never
+// built - MFMA operand k = (ky*3 + kx)*3 + c is just a per-lane constant offset into the halo.
+// Output-bound: 5.9 MB of fp32 NHWC per 40x576 line.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "conv_igemm.hpp"
+
+namespace pocr {
+
+struct Conv1Args {
+    const uint8_t *crops;
+    const LineDesc *lines;
+    const float *lut;            // i / 255.0f
+    const float *wfrag;          // [k/16 = 2][cout/16 = 4][lane][4], k = (ky*3+kx)*3 + c, zero for k >= 27
+    const float *bias;           // [64]
+    float *y;                    // ragged NHWC fp32, line i at out_off[i]
+    const PixelTile *tiles;
+    const int32_t *line_w;       // padded width of every line
+    const int64_t *out_off;
+    int32_t H, n_ptiles;
+};
+
+__global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
+    constexpr int TH = 4, TW = 32, HH = TH + 2, HW = TW + 2, NH = HH * HW * 3;
+    __shared__ float halo[NH + 4];                    // [row][col][c]; halo[NH] = 0 backs the k >= 27 padding
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    // XCD-aware order as in conv_igemm_kernel (contiguous tile ranges per XCD: neighbouring tiles share halo bytes)
+    int b = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const PixelTile pt = a.tiles[b];
+    const int img = pt.line, h0 = (pt.ht_wt >> 16) * TH, w0 = (pt.ht_wt & 0xffff) * TW;
+    const int Wp = a.line_w[img];
+    const LineDesc ld = a.lines[img];
+    const uint8_t *src = a.crops + ld.offset;
+    for (int e = tid; e < NH; e += 256) {
+        const int c = e % 3, p = e / 3, wc = p % HW, hr = p / HW;
+        const int hi = h0 - 1 + hr, wi = w0 - 1 + wc, xc = wi - ld.pad_left;
+        float v = 0.f;
+        if (hi >= 0 && hi < a.H && wi >= 0 && wi < Wp && xc >= 0 && xc < ld.width)
+            v = a.lut[src[((size_t)hi * ld.width + xc) * 3 + c]];
+        halo[e] = v;
+    }
+    if (tid < 4) halo[NH + tid] = 0.f;
+    // weights of this wave's 16 output channels and the per-lane halo offsets of its MFMA k slots
+    f32x4 wb[2];
+    int koff[2][4];
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+        wb[kg] = reinterpret_cast<const f32x4 *>(a.wfrag)[(kg * 4 + wave) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 16 * kg + 4 * kq + j;
+            const int tap = k / 3, c = k - 3 * tap;
+            koff[kg][j] = k < 27 ? ((tap / 3) * HW + tap % 3) * 3 + c : -1;
+        }
+    }
+    __syncthreads();
+    const int co = wave * 16 + li;
+    const float bias = a.bias[co];
+    float *yimg = a.y + a.out_off[img];
+#pragma unroll
+    for (int th = 0; th < TH; ++th) {
+#pragma unroll
+        for (int mw = 0; mw < 2; ++mw) {
+            const int base = (th * HW + mw * 16 + li) * 3;     // halo element of tap (0,0), channel 0 for this lane's pixel
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float av = halo[koff[kg][j] >= 0 ? base + koff[kg][j] : NH];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wb[kg][j], acc, 0, 0, 0);
+                }
+            const int ho = h0 + th;
+            if (ho >= a.H) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int wc = w0 + mw * 16 + kq * 4 + r;
+                const float v = acc[r] + bias;
+                if (wc < Wp) yimg[((size_t)ho * Wp + wc) * 64 + co] = v > 0.f ? v : 0.f;
+            }
+        }
+    }
+}
+
+}  // namespace pocr

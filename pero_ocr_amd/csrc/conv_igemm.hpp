@@ -31,14 +31,14 @@ namespace pocr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
-enum { STAGE_F32_NHWC = 0, STAGE_U8_LINES = 1 };
+enum { STAGE_F32_NHWC = 0 };      // the u8 line stager of the first layer lives in conv1_u8.hpp
 // main-loop variants (template parameter PIPE).  ABL3 is an ablation mask used only by tools/conv_bench.hip
 // (1 no global loads, 2 no LDS writes, 4 no ds_reads, 8 no barrier, 16 loads waited for at the step end).
 enum { PIPE_PLAIN = 0, PIPE_INTERLEAVED = 3, PIPE_DEEP = 4, PIPE_GLDS = 5 };
 // PIPE_GLDS = PIPE_INTERLEAVED with the weight tile copied HBM/L2 -> LDS by the load unit itself
 // (global_load_lds_dwordx4: no staging VGPRs, no ds_write; the tile is already lane-linear).
 
-struct LineDesc {            // one text line of a staged chunk (STAGE_U8_LINES)
+struct LineDesc {            // one text line of a staged chunk (read by conv1_u8_kernel)
     int64_t offset;          // byte offset of the crop [H, width, 3] inside the crop pool
     int32_t width;           // crop width in pixels
     int32_t pad_left;        // x position of the crop inside the padded row
@@ -47,10 +47,7 @@ struct LineDesc {            // one text line of a staged chunk (STAGE_U8_LINES)
 struct PixelTile { int32_t line; int32_t ht_wt; };     // ht_wt = (h-tile << 16) | w-tile
 
 struct ConvArgs {
-    const float *x;          // input NHWC [n][H][W][cin]            (STAGE_F32_NHWC)
-    const uint8_t *crops;    // crop pool                             (STAGE_U8_LINES)
-    const LineDesc *lines;   //                                       (STAGE_U8_LINES)
-    const float *lut;        // 256-entry u8 -> f32 table (i / 255.0f) (STAGE_U8_LINES)
+    const float *x;          // input NHWC [n][H][W][cin]
     const float *wfrag;      // fragment-order weights
     const float *bias;       // [cout16*16]
     const float *bn_scale;   // [cout16*16] or null: y = act(conv) * scale + shift
@@ -183,32 +180,8 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a
                 const int cq = e % CQ, p = e / CQ;
                 const int hr = p / HW, wc = p % HW;
                 const int hi = h0 - PADH + hr, wi = w0 - PADW + wc;
-                if constexpr (STAGER == STAGE_F32_NHWC) {
-                    if (hi >= 0 && hi < a.H && wi >= 0 && wi < Win)
-                        v = *reinterpret_cast<const f32x4 *>(a.x + img_base + ((size_t)hi * Win + wi) * a.cin + c0 + cq * 4);
-                } else {
-                    // conv1: build the im2col row of pixel (hi, wi) from the u8 crop on the fly.
-                    // "channel" k = (ky*3 + kx)*3 + c for k < 27, zero above.  u8 -> f32 through the
-                    // i/255.0f table (pytorch_ocr_engine.py:61); the zero padding of the batch
-                    // assembly (line_ocr_engine.py:121-123) and of the conv itself are both 0.0f.
-                    const LineDesc ld = a.lines[img];
-                    const uint8_t *src = a.crops + ld.offset;
-                    float t4[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k = cq * 4 + j;
-                        float val = 0.f;
-                        if (k < 27) {
-                            const int tap = k / 3, c = k - tap * 3;
-                            const int yy = hi + tap / 3 - 1, xx = wi + tap % 3 - 1;
-                            const int xc = xx - ld.pad_left;
-                            if (yy >= 0 && yy < a.H && xx >= 0 && xx < Win && xc >= 0 && xc < ld.width)
-                                val = a.lut[src[((size_t)yy * ld.width + xc) * 3 + c]];
-                        }
-                        t4[j] = val;
-                    }
-                    v = (f32x4){t4[0], t4[1], t4[2], t4[3]};
-                }
+                if (hi >= 0 && hi < a.H && wi >= 0 && wi < Win)
+                    v = *reinterpret_cast<const f32x4 *>(a.x + img_base + ((size_t)hi * Win + wi) * a.cin + c0 + cq * 4);
             }
             ra[r] = v;
         }
@@ -303,7 +276,6 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a
     // one at a time in the shadow of the MFMA stream (a 32-cycle MFMA hides ~5 issue slots)
     // instead of as bursts before the first / after the last MFMA of a step.
     static_assert(KG == 1, "the interleaved pipeline is written for KC == 16");
-    static_assert(STAGER == STAGE_F32_NHWC, "the interleaved pipeline stages fp32 NHWC input");
     constexpr int NMFMA = 4 * MS * NS;
     // issue slots per step: the largest of 16, 12, 10, 8 that divides the MFMA count and leaves
     // separate halves for the loads (first half) and the LDS writes (second half)

@@ -15,6 +15,7 @@
 
 #include "../../include/pocr.h"
 #include "conv_igemm.hpp"
+#include "conv1_u8.hpp"
 #include "ctc.hpp"
 #include "encoder.hpp"
 #include "lstm.hpp"
@@ -107,7 +108,6 @@ int launch_conv(Kern kern, int TH, int TW, int NT, int nthreads, ConvArgs a, hip
                            TH, 16 * MW, NS * NWAVE * 16, NWAVE * 64, a, st);                                        \
     }
 //                 KH KW P  P  TH MW NS NW KC PH PW
-POCR_CONV(conv1_u8,  1, 1, 0, 0, 4, 2, 1, 4, 32, 1, 1, ACT_RELU, false, STAGE_U8_LINES, PIPE_PLAIN)   // 3->64 (im2col K=27->32)
 POCR_CONV(conv2_k,   3, 3, 1, 1, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // 64->64   + pool 2x2
 POCR_CONV(conv3_k,   3, 3, 1, 1, 4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // 64->128
 POCR_CONV(conv4_k,   3, 3, 1, 1, 4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // 128->128 + pool 2x2
@@ -290,9 +290,13 @@ int run_network(pocr_engine *e, Slot &s) {
         mark(i);
         int rc = 0;
         if (i == 0) {
-            a.crops = s.crops.as<uint8_t>(); a.lines = s.lines.as<LineDesc>(); a.lut = e->lut.as<float>();
-            a.cin = 32;
-            rc = conv1_u8(a, st);
+            Conv1Args c1{};
+            c1.crops = s.crops.as<uint8_t>(); c1.lines = s.lines.as<LineDesc>(); c1.lut = e->lut.as<float>();
+            c1.wfrag = e->conv_w[0].as<float>(); c1.bias = e->conv_b[0].as<float>(); c1.y = s.act[0].as<float>();
+            c1.tiles = s.g_tiles[0]; c1.line_w = s.g_lvl_w[0]; c1.out_off = s.g_act_off[0];
+            c1.H = h; c1.n_ptiles = s.g_ntiles[0];
+            if (c1.n_ptiles > 0) hipLaunchKernelGGL(conv1_u8_kernel, dim3(c1.n_ptiles), dim3(256), 0, st, c1);
+            HIP_TRY(hipGetLastError());
         } else {
             a.x = s.act[i - 1].as<float>(); a.cin = L.cin;
             if (i == 8) { a.bn_scale = e->bn_scale.as<float>(); a.bn_shift = e->bn_shift.as<float>(); }
