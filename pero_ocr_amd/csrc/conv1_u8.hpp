@@ -65,8 +65,7 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
         }
     }
     __syncthreads();
-    const int co = wave * 16 + li;
-    const float bias = a.bias[co];
+    const float bias = a.bias[wave * 16 + li];
     float *yimg = a.y + a.out_off[img];
 #pragma unroll
     for (int th = 0; th < TH; ++th) {
@@ -83,12 +82,14 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
                 }
             const int ho = h0 + th;
             if (ho >= a.H) continue;
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int wc = w0 + mw * 16 + kq * 4 + r;
-                const float v = acc[r] + bias;
-                if (wc < Wp) yimg[((size_t)ho * Wp + wc) * 64 + co] = v > 0.f ? v : 0.f;
-            }
+            for (int r = 0; r < 4; ++r) { const float t = acc[r] + bias; v[r] = t > 0.f ? t : 0.f; }
+            quad_transpose(v, lane);                     // now: pixel 4*kq + (li & 3), channels 16*wave + 4*(li >> 2) + 0..3
+            const int wc = w0 + mw * 16 + kq * 4 + (li & 3);
+            if (wc < Wp)
+                *reinterpret_cast<f32x4 *>(yimg + ((size_t)ho * Wp + wc) * 64 + wave * 16 + 4 * (li >> 2)) =
+                    (f32x4){v[0], v[1], v[2], v[3]};
         }
     }
 }

@@ -82,6 +82,23 @@ inline size_t conv_grid_blocks(const ConvArgs &a) {
     return P * tn;
 }
 
+// 4x4 transpose inside each quad of lanes: on entry lane (quad base + b) holds v[r] = M[b][r], on exit
+// v[c] = M[c][b].  Used by the epilogues: the MFMA D layout gives a lane 4 pixels x 1 channel; after the
+// transpose it holds 1 pixel x 4 consecutive channels, i.e. one 16-byte store instead of four 4-byte ones.
+__device__ __forceinline__ void quad_transpose(float (&v)[4], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    {   // exchange across bit 0: register pairs (0,1) and (2,3)
+        const float s0 = b0 ? v[0] : v[1], s1 = b0 ? v[2] : v[3];
+        const float r0 = __shfl_xor(s0, 1, 64), r1 = __shfl_xor(s1, 1, 64);
+        if (b0) { v[0] = r0; v[2] = r1; } else { v[1] = r0; v[3] = r1; }
+    }
+    {   // exchange across bit 1: register pairs (0,2) and (1,3)
+        const float s0 = b1 ? v[0] : v[2], s1 = b1 ? v[1] : v[3];
+        const float r0 = __shfl_xor(s0, 2, 64), r1 = __shfl_xor(s1, 2, 64);
+        if (b1) { v[0] = r0; v[1] = r1; } else { v[2] = r0; v[3] = r1; }
+    }
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == ACT_LEAKY) return v > 0.f ? v : v * 0.01f;
@@ -442,19 +459,27 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a
                 }
                 const int ho = (h0 + th) / POOLH;
                 const int wbase = w0 + mw * 16 + kq * 4;           // conv-output column of reg 0
-                if (!co_ok || h0 + th >= a.Ho) continue;
                 float *yrow = a.y + out_base + ((size_t)ho * Wout) * a.out_stride + co;
                 if constexpr (POOLW == 2) {
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr) {
                         const int wc = wbase + 2 * rr;
-                        if (wc + 1 < Wo) yrow[(size_t)(wc / 2) * a.out_stride] = fmaxf(v[2 * rr], v[2 * rr + 1]);
+                        if (co_ok && h0 + th < a.Ho && wc + 1 < Wo) yrow[(size_t)(wc / 2) * a.out_stride] = fmaxf(v[2 * rr], v[2 * rr + 1]);
                     }
                 } else {
+                    // every lane of the wave takes part in the transpose; rows/channels out of range are masked at the store
+                    quad_transpose(v, lane);         // pixel wbase + (li & 3), channels co - (li & 3) + 0..3
+                    const int wc = wbase + (li & 3);
+                    float *dst = yrow - (li & 3) + (size_t)wc * a.out_stride;
+                    const int c4 = co - (li & 3);
+                    if (wc < Wo && h0 + th < a.Ho) {
+                        if (c4 + 3 < a.cout_valid && (a.out_stride & 3) == 0) {
+                            *reinterpret_cast<f32x4 *>(dst) = (f32x4){v[0], v[1], v[2], v[3]};
+                        } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int wc = wbase + r;
-                        if (wc < Wo) yrow[(size_t)wc * a.out_stride] = v[r];
+                            for (int k = 0; k < 4; ++k)
+                                if (c4 + k < a.cout_valid) dst[k] = v[k];
+                        }
                     }
                 }
             }
