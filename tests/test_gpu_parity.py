@@ -548,3 +548,22 @@ def test_plan_launches_merges_without_reordering():
     assert [c for l in launches for c in l.chunks] == chunks
     assert all(l.work <= le.LAUNCH_WORK_TARGET or len(l.chunks) == 1 for l in launches)
     assert len(launches) < len(chunks) / 4
+
+
+def test_degenerate_inputs(golden, tmp_path):
+    """Empty page, a single 1-pixel line, a float64 'failed crop' (page_parser.py:390-391 hands zeros
+    [H,H,3] float64 to process_lines), all output modes: shapes and types follow the reference contract."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    g = golden("c1")
+    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev())
+    assert eng.process_lines([]) == ([], [], [])
+    one = [synth.make_crop(1, 0, 1)]
+    t, l, c = eng.process_lines(one)
+    assert len(t) == 1 and l[0].shape == ((32 + 64) // 4, len(eng.characters)) and c == [[8, 8]]
+    failed = [np.zeros((40, 40, 3)), synth.make_crop(1, 1, 77)]          # float64 zeros, like a failed crop
+    t, l, c = eng.process_lines(failed, sparse_logits=False)
+    assert isinstance(t[0], str) and l[0].dtype == np.float32 and c[0] == [8, 18]
+    t2, l2, c2 = eng.process_lines([failed[0].astype(np.uint8), failed[1]], sparse_logits=False)
+    assert t2 == t and np.array_equal(np.asarray(l2[0]), np.asarray(l[0]))
+    with pytest.raises(ValueError):
+        eng.process_lines([np.zeros((39, 10, 3), np.uint8)])
