@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define POCR_ABI_VERSION 5
+#define POCR_ABI_VERSION 6
 #define POCR_NUM_SLOTS 2
 
 typedef struct pocr_engine pocr_engine;
@@ -42,11 +42,16 @@ typedef struct pocr_config {
     int32_t sa_layers;     /* POCR_ARCH_SA: encoder layers      (transformer.py:366-376, JSON encoder_layers) */
     int32_t sa_heads;      /* POCR_ARCH_SA: heads, conv_out/heads in {32, 64, 128} */
     int32_t sa_ff;         /* POCR_ARCH_SA: feed-forward width, multiple of 16 */
+    int32_t dec_layers;    /* POCR_ARCH_S2S: decoder layers (transformer.py:13-47, JSON decoder_layers) */
 } pocr_config;
 
 /* Sequence model after the conv backbone: BiLSTM stack, or the self-attention encoder
  * (LineSelfAttentionEncoder, pero_ocr/ocr_engine/transformer.py:366-385 = BASELINE config 4). */
-enum { POCR_ARCH_BLSTM = 0, POCR_ARCH_SA = 1 };
+/* POCR_ARCH_S2S: conv backbone + self-attention encoder + autoregressive transformer decoder = the
+ * reference's TransformerOCR (transformer.py:388-508) as driven by TransformerEngineLineOCR
+ * (pero_ocr/ocr_engine/transformer_ocr_engine.py); num_classes then = symbols + boundary + ignore,
+ * the sa_* fields describe encoder and decoder alike.  Only the pocr_s2s_* calls run such an engine. */
+enum { POCR_ARCH_BLSTM = 0, POCR_ARCH_SA = 1, POCR_ARCH_S2S = 2 };
 
 /* Number of float32 values pocr_create() expects (tensor order = netspec.tensor_table). */
 size_t pocr_num_weight_floats(const pocr_config *cfg);
@@ -139,6 +144,30 @@ int pocr_slot_sparse_nnz(pocr_engine *e, int32_t slot, int64_t *total_nnz);
 int pocr_slot_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t *indices, int32_t *indptr,
                              int64_t *line_off, int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n);
 
+/* ---- sequence-to-sequence recognition (POCR_ARCH_S2S): replaces TransformerEngineLineOCR.run_ocr /
+ * transcribe_batch (pero_ocr/ocr_engine/transformer_ocr_engine.py:32-89) for the batches that
+ * BaseEngineLineOCR.process_lines builds in its "transformer" branches (line_ocr_engine.py:84-85,95-127).
+ *
+ * pocr_s2s_stage: like pocr_slot_stage_ragged with a left offset per line.  Line i is placed at
+ *   x = pad_lefts[i] inside a zero row of w_pads[i] pixels - i.e. line_padding_px plus, for batches
+ *   narrower than 1088 px, the centring offset of transformer_ocr_engine.py:36-40 (w_pads[i] is then 1088).
+ * pocr_s2s_launch: enqueues the encoder (conv backbone, self-attention encoder, key/value projection of
+ *   its output for every decoder layer) and returns.  batch_first [n_batches + 1]: lines
+ *   [batch_first[b], batch_first[b+1]) form reference batch b (all with the same w_pad).  The batch is
+ *   the unit of the decoding loop: it runs until every line of the batch has produced the boundary
+ *   symbol or the step count exceeds w_pad / 4 (:74-80); batches of one launch are decoded side by side.
+ * pocr_s2s_decode: runs the greedy decoding loop (blocking) and reports
+ *   steps [n_batches] : decoding steps of each batch = rows of its logits (:81 torch.stack(logits))
+ *   *s_max            : max over steps[]
+ * pocr_s2s_collect: tokens [n][s_max] int32 = arg-max sample of every step (-1 beyond the line's batch);
+ *   the reference feeds back / keeps the samples of steps 0 .. steps[b]-2 (partial_transcripts[1:], :82-84).
+ *   logits [n][s_max][C] float32 or NULL (requested at pocr_s2s_decode), rows >= steps[b] are zero. */
+int pocr_s2s_stage(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
+                   const int32_t *widths, const int32_t *w_pads, const int32_t *pad_lefts, int32_t n);
+int pocr_s2s_launch(pocr_engine *e, int32_t slot, const int32_t *batch_first, int32_t n_batches);
+int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *steps, int32_t *s_max);
+int pocr_s2s_collect(pocr_engine *e, int32_t slot, int32_t *tokens, float *logits);
+
 /* ---- measurement / test taps (not part of the reference surface) ----
  * Per-stage GPU time of the last pocr_run_* call in milliseconds, measured with HIP
  * events on the engine's stream.  Stage ids: POCR_STAGE_*.  Returns the number of
@@ -163,7 +192,7 @@ int pocr_set_profiling(pocr_engine *e, int32_t enabled);
  * what: 0..8 = output of conv1..conv9 (NHWC, after activation/pool/BN),
  *       9 = aggregation features [n, T, E];
  *       BLSTM: 10+l = BiLSTM layer l output [n, T, 2*hidden];
- *       SA:    10 = LayerNorm + positional encoding [n, T, E], 11+l = encoder layer l output [n, T, E].
+ *       SA / S2S: 10 = LayerNorm + positional encoding [n, T, E], 11+l = encoder layer l output [n, T, E].
  * Writes min(cap, size) floats, stores the full size in *n_floats. */
 int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t *n_floats);
 

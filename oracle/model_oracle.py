@@ -28,7 +28,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from pero_ocr_amd.netspec import ARCH_SA, BN_EPS, CONV_PLAN, LEAKY_SLOPE, LN_EPS, NetSpec
+from pero_ocr_amd.netspec import ARCH_S2S, ARCH_SA, BN_EPS, CONV_PLAN, LEAKY_SLOPE, LN_EPS, NetSpec
 
 
 class OracleNet(nn.Module):
@@ -57,6 +57,10 @@ class OracleNet(nn.Module):
         self.agg.bias.data = torch.from_numpy(weights["agg.bias"].copy())
         self.agg_act = nn.LeakyReLU(LEAKY_SLOPE)
         self.sa = None
+        if spec.arch == ARCH_S2S:            # encoder only; the decoder lives in oracle/s2s_oracle.py
+            self.sa = {k: torch.from_numpy(v.copy()) for k, v in weights.items() if k.startswith("sa")}
+            self.eval()
+            return
         if spec.arch == ARCH_SA:
             self.sa = {k: torch.from_numpy(v.copy()) for k, v in weights.items() if k.startswith("sa")}
             self.head = nn.Linear(spec.conv_out, spec.num_classes)

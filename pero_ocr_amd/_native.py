@@ -14,7 +14,7 @@ import numpy as np
 from .netspec import NetSpec
 
 LIB_NAME = "libpocr_hip.so"
-ABI_VERSION = 5
+ABI_VERSION = 6
 STAGE_NAMES = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv8", "conv9",
                "agg", "lstm", "head", "ctc", "total")
 
@@ -24,15 +24,16 @@ _lib: Optional[C.CDLL] = None
 class PocrConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("height", C.c_int32), ("num_classes", C.c_int32),
                 ("conv_out", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_layers", C.c_int32),
-                ("arch", C.c_int32), ("sa_layers", C.c_int32), ("sa_heads", C.c_int32), ("sa_ff", C.c_int32)]
+                ("arch", C.c_int32), ("sa_layers", C.c_int32), ("sa_heads", C.c_int32), ("sa_ff", C.c_int32),
+                ("dec_layers", C.c_int32)]
 
 
-ARCH_IDS = {"vgg_blstm_ctc": 0, "vgg_sa_ctc": 1}
+ARCH_IDS = {"vgg_blstm_ctc": 0, "vgg_sa_ctc": 1, "vgg_sa_s2s": 2}
 
 
 def make_config(spec: NetSpec) -> "PocrConfig":
     return PocrConfig(ABI_VERSION, spec.height, spec.num_classes, spec.conv_out, spec.lstm_hidden,
-                      spec.lstm_layers, ARCH_IDS[spec.arch], spec.sa_layers, spec.sa_heads, spec.sa_ff)
+                      spec.lstm_layers, ARCH_IDS[spec.arch], spec.sa_layers, spec.sa_heads, spec.sa_ff, spec.dec_layers)
 
 
 # every symbol include/pocr.h declares: name -> (restype, argtypes)
@@ -57,6 +58,10 @@ SYMBOLS = {
     "pocr_slot_launch_sparse": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, C.c_float, C.c_int32]),
     "pocr_slot_sparse_nnz": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "pocr_slot_collect_sparse": (C.c_int, [C.c_void_p, C.c_int32, _f32p, _i32p, _i32p, _i64p, _i32p, _i32p, _i32p]),
+    "pocr_s2s_stage": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, _i32p, _i32p, C.c_int32]),
+    "pocr_s2s_launch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_int32]),
+    "pocr_s2s_decode": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i32p]),
+    "pocr_s2s_collect": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _f32p]),
     "pocr_last_stage_ms": (C.c_int, [C.c_void_p, _f32p, C.c_int32]),
     "pocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "pocr_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -246,6 +251,42 @@ class NativeEngine:
         if rc:
             raise RuntimeError("pocr_slot_collect_sparse: " + self._err())
         return data[:total.value], indices[:total.value], indptr, line_off, amax, labels, lens
+
+    # ---- sequence-to-sequence engine (POCR_ARCH_S2S) -----------------------------------------------
+    def s2s_stage(self, slot: int, pool_u8, offsets, widths, w_pads, pad_lefts):
+        pool = np.ascontiguousarray(pool_u8, dtype=np.uint8).reshape(-1)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        wd = np.ascontiguousarray(widths, dtype=np.int32)
+        wp = np.ascontiguousarray(w_pads, dtype=np.int32)
+        pl = np.ascontiguousarray(pad_lefts, dtype=np.int32)
+        if pool.size == 0:
+            pool = np.zeros(1, dtype=np.uint8)
+        if self._lib.pocr_s2s_stage(self._h, int(slot), _ptr(pool, _u8p), _ptr(off, _i64p), _ptr(wd, _i32p),
+                                    _ptr(wp, _i32p), _ptr(pl, _i32p), int(wd.size)):
+            raise RuntimeError("pocr_s2s_stage: " + self._err())
+        self._s2s_n = getattr(self, "_s2s_n", {})
+        self._s2s_n[slot] = int(wd.size)
+
+    def s2s_launch(self, slot: int, batch_first):
+        """Enqueue the encoder of the staged lines; batch_first [n_batches + 1] = first line of every reference batch."""
+        bf = np.ascontiguousarray(batch_first, dtype=np.int32)
+        if self._lib.pocr_s2s_launch(self._h, int(slot), _ptr(bf, _i32p), int(bf.size - 1)):
+            raise RuntimeError("pocr_s2s_launch: " + self._err())
+        self._s2s_nb = getattr(self, "_s2s_nb", {})
+        self._s2s_nb[slot] = int(bf.size - 1)
+
+    def s2s_decode(self, slot: int, want_logits: bool = True):
+        """Greedy decoding loop (blocking) -> (steps [n_batches], tokens [n, s_max], logits [n, s_max, C] | None)"""
+        nb, n = self._s2s_nb[slot], self._s2s_n[slot]
+        steps = np.zeros(nb, dtype=np.int32)
+        smax = C.c_int32(0)
+        if self._lib.pocr_s2s_decode(self._h, int(slot), 1 if want_logits else 0, _ptr(steps, _i32p), C.byref(smax)):
+            raise RuntimeError("pocr_s2s_decode: " + self._err())
+        tokens = np.empty((n, smax.value), dtype=np.int32)
+        logits = np.empty((n, smax.value, self.spec.num_classes), dtype=np.float32) if want_logits else None
+        if self._lib.pocr_s2s_collect(self._h, int(slot), _ptr(tokens, _i32p), _ptr(logits, _f32p)):
+            raise RuntimeError("pocr_s2s_collect: " + self._err())
+        return steps, tokens, logits
 
     def slot_stage_ms(self, slot: int) -> dict:
         buf = np.zeros(len(STAGE_NAMES), dtype=np.float32)

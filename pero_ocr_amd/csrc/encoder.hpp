@@ -22,7 +22,9 @@ namespace pocr {
 // rows x E; one wave per row, E % 64 == 0 not required (strided loop).
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *a, const float *b, const float *gamma,
                                                         const float *beta, const float *pe, float *y, int rows,
-                                                        int E, int T, float eps, const int32_t *row_t) {
+                                                        int E, int T, float eps, const int32_t *row_t,
+                                                        const int32_t *stop) {
+    if (stop && *stop == 0) return;             // decoder steps enqueued past the end of the last batch (decoder.hpp)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;

@@ -18,6 +18,7 @@
 #include "conv1_u8.hpp"
 #include "ctc.hpp"
 #include "encoder.hpp"
+#include "decoder.hpp"
 #include "lstm.hpp"
 #include "sparsify.hpp"
 
@@ -129,7 +130,7 @@ const int kConvTW[10] = {32, 64, 32, 32, 16, 16, 16, 16, 16, 48};
 // input width level of each conv (0: W_pad, 1: W_pad/2, 2: (W_pad/2)/2) and of its output
 const int kConvLvlIn[10] = {0, 0, 1, 1, 2, 2, 2, 2, 2, 2};
 const int kConvLvlOut[10] = {0, 1, 1, 2, 2, 2, 2, 2, 2, 2};
-const int kAggNT = 256, kProjNT = 128, kHeadNT = 64;
+const int kAggNT = 256, kProjNT = 128, kHeadNT = 64, kSkinnyNT = 64;
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -202,6 +203,17 @@ struct Slot {
     // latency-bound sequence tail of the previous chunk shares the chip with them
     hipEvent_t conv_done = nullptr;
     bool conv_done_valid = false;
+    // sequence-to-sequence decoding (POCR_ARCH_S2S, decoder.hpp)
+    std::vector<DevBuf> s2s_kv, s2s_cache;   // per decoder layer: projected encoder output [rows][2E]; self cache [S_cap][n][3E]
+    DevBuf s2s_x, s2s_x1, s2s_x2, s2s_t, s2s_ctx, s2s_q, s2s_ff, s2s_logits, s2s_tokens, s2s_state, s2s_tables;
+    std::vector<int32_t> s2s_batch_first, s2s_limit, s2s_steps, s2s_wpads;
+    int s2s_batches = 0, s2s_cap = 0, s2s_smax = 0;
+    bool s2s_launched = false, s2s_decoded = false, s2s_want_logits = false;
+    void *s2s_pinned = nullptr;      // [tokens n*S_cap int32 | logits n*s_max*C float]
+    size_t s2s_pinned_cap = 0;
+    int32_t *s2s_flags = nullptr;    // pinned: [remaining per polled block (64) | steps (n_batches)]
+    size_t s2s_flags_cap = 0;
+    hipEvent_t s2s_ev[2]{};
 };
 
 struct pocr_engine {
@@ -216,6 +228,15 @@ struct pocr_engine {
     std::vector<SaLayer> sa;
     DevBuf sa_nw, sa_nb, pe;
     int pe_rows = 0;
+    // decoder (POCR_ARCH_S2S): DecoderLayer weights (transformer.py:388-411); in_proj of the memory attention is
+    // split into its query rows [0, E) and key/value rows [E, 3E) (cached_forward :237-247, :259-268)
+    struct DecLayer {
+        DevBuf ws_in, bs_in, ws_out, bs_out, wc_q, bc_q, wc_kv, bc_kv, wc_out, bc_out, w1, b1, w2, b2;
+        DevBuf n1w, n1b, n2w, n2b, n3w, n3b;
+    };
+    std::vector<DecLayer> dec;
+    DevBuf dec_embed, dec_out_w, dec_out_b;
+    int dec_out_cout16 = 0;
     int conv_cout16[9]{};
     int agg_cout16 = 0, head_cout16 = 0, proj_cout16 = 0;
     Slot slot[POCR_NUM_SLOTS];
@@ -241,7 +262,9 @@ int check_cfg(const pocr_config *c) {
     if (ah != 4 && ah != 5 && ah != 6 && ah != 8) return fail("unsupported height %d (aggregation height %d; built for 32/40/48/64)", c->height, ah);
     if (c->num_classes < 2) return fail("num_classes must be >= 2");
     if (c->conv_out <= 0 || c->conv_out % 16) return fail("conv_out must be a positive multiple of 16");
-    if (c->arch == POCR_ARCH_SA) {
+    if (c->arch == POCR_ARCH_SA || c->arch == POCR_ARCH_S2S) {
+        if (c->arch == POCR_ARCH_S2S && c->dec_layers < 1) return fail("dec_layers must be >= 1");
+        if (c->arch == POCR_ARCH_S2S && c->num_classes < 3) return fail("a seq2seq model needs >= 3 classes (symbol, boundary, ignore)");
         if (c->sa_layers < 1) return fail("sa_layers must be >= 1");
         if (c->sa_heads < 1 || c->conv_out % c->sa_heads) return fail("conv_out must be divisible by sa_heads");
         const int d = c->conv_out / c->sa_heads;
@@ -335,14 +358,15 @@ int run_network(pocr_engine *e, Slot &s) {
     const float *layer_in = s.feat.as<float>();
     int din = E;
     mark(POCR_STAGE_LSTM);
-    if (c.arch == POCR_ARCH_SA) {
+    if (c.arch == POCR_ARCH_SA || c.arch == POCR_ARCH_S2S) {
     // ---- self-attention encoder (transformer.py:366-385)
     const int FF = c.sa_ff, heads = c.sa_heads, D = E / heads;
     const size_t xe = (size_t)rows * E * sizeof(float);
     if (s.sa_x.reserve(xe) || s.sa_x1.reserve(xe) || s.sa_att.reserve(xe) || s.sa_tmp.reserve(xe)) return 1;
     if (s.sa_qkv.reserve(3 * xe) || s.sa_ff.reserve((size_t)rows * FF * sizeof(float))) return 1;
-    if (T > e->pe_rows) {      // sinusoidal table, float32 like PositionalEncoding (transformer.py:316-332)
-        const int rows_pe = round_up(T, 256);
+    const int pe_need = std::max(T, c.arch == POCR_ARCH_S2S ? s.s2s_cap + 8 : 0);      // the decoder adds pe[step]
+    if (pe_need > e->pe_rows) {      // sinusoidal table, float32 like PositionalEncoding (transformer.py:316-332)
+        const int rows_pe = round_up(pe_need, 256);
         std::vector<float> pe((size_t)rows_pe * E);
         for (int k = 0; k < E; k += 2) {
             const float div = expf((float)k * (-logf(10000.0f) / (float)E));
@@ -357,7 +381,7 @@ int run_network(pocr_engine *e, Slot &s) {
     }
     auto ln = [&](const float *a_, const float *b_, const DevBuf &gw, const DevBuf &gb, const float *pe_, float *y_) {
         hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a_, b_, gw.as<float>(), gb.as<float>(),
-                           pe_, y_, rows, E, T, 1e-5f, s.g_row_t);
+                           pe_, y_, rows, E, T, 1e-5f, s.g_row_t, nullptr);
     };
     auto gemm = [&](const float *x_, int cin_, const DevBuf &w_, const DevBuf &b_, int cout_, float *y_, bool relu) {
         ConvArgs g{};
@@ -387,6 +411,16 @@ int run_network(pocr_engine *e, Slot &s) {
     }
     layer_in = s.sa_y[c.sa_layers - 1].as<float>();
     din = E;
+    if (c.arch == POCR_ARCH_S2S) {
+        // keys / values of the encoder output for every decoder layer, computed once per launch
+        // (CustomMultiheadAttention.cached_forward, transformer.py:237-247): [rows][2E] = memory W[E:3E]^T + b[E:3E]
+        for (int l = 0; l < c.dec_layers; ++l) {
+            if (s.s2s_kv[l].reserve(2 * xe)) return 1;
+            if (gemm(layer_in, E, e->dec[l].wc_kv, e->dec[l].bc_kv, 2 * E, s.s2s_kv[l].as<float>(), false)) return 1;
+        }
+        mark(POCR_STAGE_HEAD); mark(POCR_STAGE_CTC); mark(POCR_NUM_STAGES);
+        return 0;
+    }
     } else {
     // ---- BiLSTM stack
     const int Hh = c.lstm_hidden, npad = round_up(n, 16);
@@ -583,6 +617,20 @@ int collect_outputs(pocr_engine *e, Slot &s, float *logits_ntc, int32_t *frame_a
     return 0;
 }
 
+template <bool RELU>
+int launch_skinny(SkinnyArgs a, hipStream_t st) {
+    const int c16 = a.cout16;
+    auto wgs = [&](int rm, int cn) { return ((a.M + 16 * rm - 1) / (16 * rm)) * (c16 / cn); };
+    // the largest tile that still gives every CU a workgroup; small problems take the smallest tile
+    if (c16 % 4 == 0 && wgs(2, 4) >= 256) hipLaunchKernelGGL((skinny_gemm_kernel<2, 4, RELU>), dim3(c16 / 4, (a.M + 31) / 32), dim3(256), 0, st, a);
+    else if (c16 % 2 == 0 && wgs(2, 2) >= 256) hipLaunchKernelGGL((skinny_gemm_kernel<2, 2, RELU>), dim3(c16 / 2, (a.M + 31) / 32), dim3(256), 0, st, a);
+    else if (c16 % 2 == 0 && wgs(1, 2) >= 256) hipLaunchKernelGGL((skinny_gemm_kernel<1, 2, RELU>), dim3(c16 / 2, (a.M + 15) / 16), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<1, 1, RELU>), dim3(c16, (a.M + 15) / 16), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+
 int check_slot(pocr_engine *e, int32_t slot) {
     if (!e) return fail("engine is NULL");
     if (slot < 0 || slot >= POCR_NUM_SLOTS) return fail("slot %d out of range (0..%d)", slot, POCR_NUM_SLOTS - 1);
@@ -608,11 +656,15 @@ size_t pocr_num_weight_floats(const pocr_config *c) {
     for (const ConvLayer &L : kConvPlan) t += (size_t)L.cout * L.cin * 9 + L.cout;
     t += 4 * 512;
     t += (size_t)c->conv_out * 512 * (c->height / 8) + c->conv_out;
-    if (c->arch == POCR_ARCH_SA) {
+    if (c->arch == POCR_ARCH_SA || c->arch == POCR_ARCH_S2S) {
         const size_t E = c->conv_out, FF = c->sa_ff;
         t += 2 * E;
         t += (size_t)c->sa_layers * (3 * E * E + 3 * E + E * E + E + FF * E + FF + E * FF + E + 4 * E);
-        t += (size_t)c->num_classes * E + c->num_classes;
+        if (c->arch == POCR_ARCH_S2S) {
+            t += (size_t)c->dec_layers * (2 * (3 * E * E + 3 * E + E * E + E) + FF * E + FF + E * FF + E + 6 * E);
+            t += (size_t)c->num_classes * E;                           // embedding
+        }
+        t += (size_t)c->num_classes * E + c->num_classes;             // CTC head / decoder output projection
         return t;
     }
     const size_t Hh = c->lstm_hidden;
@@ -658,7 +710,13 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
             if (hipEventCreate(&ev) != hipSuccess) return bail(fail("hipEventCreate failed"));
         if (hipEventCreateWithFlags(&sl.conv_done, hipEventDisableTiming) != hipSuccess) return bail(fail("hipEventCreate failed"));
         sl.lstm_y.resize(cfg->arch == POCR_ARCH_BLSTM ? cfg->lstm_layers : 0);
-        sl.sa_y.resize(cfg->arch == POCR_ARCH_SA ? cfg->sa_layers : 0);
+        sl.sa_y.resize(cfg->arch == POCR_ARCH_SA || cfg->arch == POCR_ARCH_S2S ? cfg->sa_layers : 0);
+        if (cfg->arch == POCR_ARCH_S2S) {
+            sl.s2s_kv.resize(cfg->dec_layers);
+            sl.s2s_cache.resize(cfg->dec_layers);
+            for (auto &ev : sl.s2s_ev)
+                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(fail("hipEventCreate failed"));
+        }
     }
     hipStream_t st = e->stream;
 
@@ -701,18 +759,22 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         if (upload(e->agg_w, frag, st) || upload(e->agg_b, bias, st)) return bail(1);
     }
     int head_in = 2 * cfg->lstm_hidden;
-    if (cfg->arch == POCR_ARCH_SA) {   // self-attention encoder weights
+    if (cfg->arch == POCR_ARCH_SA || cfg->arch == POCR_ARCH_S2S) {   // self-attention encoder weights
         const int E = cfg->conv_out, FF = cfg->sa_ff;
         head_in = E;
         auto vec = [&](size_t n_) { const float *p_ = cur.take(n_); return std::vector<float>(p_, p_ + n_); };
+        // rows [r0, r0 + cout_) of a [*, cin_] matrix at w / b -> fragment order, cout padded to a multiple of nt
+        auto lin_rows = [&](DevBuf &wbuf, DevBuf &bbuf, const float *w, const float *b, int r0, int cout_, int cin_, int nt) {
+            const int c16 = round_up(cout_, nt) / 16;
+            auto frag = build_wfrag(1, cin_, c16, [&](int co, int ci, int) { return w[(size_t)(r0 + co) * cin_ + ci]; }, cin_, cout_);
+            std::vector<float> bias(c16 * 16, 0.f);
+            for (int k = 0; k < cout_; ++k) bias[k] = b[r0 + k];
+            return upload(wbuf, frag, st) || upload(bbuf, bias, st);
+        };
         auto lin = [&](DevBuf &wbuf, DevBuf &bbuf, int cout_, int cin_) {
             const float *w = cur.take((size_t)cout_ * cin_);
             const float *b = cur.take(cout_);
-            const int c16 = round_up(cout_, kProjNT) / 16;
-            auto frag = build_wfrag(1, cin_, c16, [&](int co, int ci, int) { return w[(size_t)co * cin_ + ci]; }, cin_, cout_);
-            std::vector<float> bias(c16 * 16, 0.f);
-            for (int k = 0; k < cout_; ++k) bias[k] = b[k];
-            return upload(wbuf, frag, st) || upload(bbuf, bias, st);
+            return lin_rows(wbuf, bbuf, w, b, 0, cout_, cin_, kProjNT);
         };
         if (upload(e->sa_nw, vec(E), st) || upload(e->sa_nb, vec(E), st)) return bail(1);
         e->sa.resize(cfg->sa_layers);
@@ -720,6 +782,28 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
             pocr_engine::SaLayer &L = e->sa[l];
             if (lin(L.w_in, L.b_in, 3 * E, E) || lin(L.w_out, L.b_out, E, E) || lin(L.w1, L.b1, FF, E) || lin(L.w2, L.b2, E, FF)) return bail(1);
             if (upload(L.n1w, vec(E), st) || upload(L.n1b, vec(E), st) || upload(L.n2w, vec(E), st) || upload(L.n2b, vec(E), st)) return bail(1);
+        }
+        if (cfg->arch == POCR_ARCH_S2S) {   // decoder: skinny-GEMM weights are padded to 64 columns (kSkinnyNT)
+            e->dec.resize(cfg->dec_layers);
+            for (int l = 0; l < cfg->dec_layers; ++l) {
+                pocr_engine::DecLayer &L = e->dec[l];
+                auto skinny = [&](DevBuf &wbuf, DevBuf &bbuf, int cout_, int cin_) {
+                    const float *w = cur.take((size_t)cout_ * cin_);
+                    const float *b = cur.take(cout_);
+                    return lin_rows(wbuf, bbuf, w, b, 0, cout_, cin_, kSkinnyNT);
+                };
+                if (skinny(L.ws_in, L.bs_in, 3 * E, E) || skinny(L.ws_out, L.bs_out, E, E)) return bail(1);
+                {
+                    const float *w = cur.take((size_t)3 * E * E);
+                    const float *b = cur.take(3 * E);
+                    if (lin_rows(L.wc_q, L.bc_q, w, b, 0, E, E, kSkinnyNT)) return bail(1);
+                    if (lin_rows(L.wc_kv, L.bc_kv, w, b, E, 2 * E, E, kProjNT)) return bail(1);     // runs on gemm128_k over all memory rows
+                }
+                if (skinny(L.wc_out, L.bc_out, E, E) || skinny(L.w1, L.b1, FF, E) || skinny(L.w2, L.b2, E, FF)) return bail(1);
+                if (upload(L.n1w, vec(E), st) || upload(L.n1b, vec(E), st) || upload(L.n2w, vec(E), st) || upload(L.n2b, vec(E), st) ||
+                    upload(L.n3w, vec(E), st) || upload(L.n3b, vec(E), st)) return bail(1);
+            }
+            if (upload(e->dec_embed, vec((size_t)cfg->num_classes * E), st)) return bail(1);
         }
     } else {   // BiLSTM layers
         const int Hh = cfg->lstm_hidden, KGT = Hh / 16;
@@ -779,12 +863,22 @@ void pocr_destroy(pocr_engine *e) {
         for (auto &b : *v) b.release();
     for (auto &L : e->sa)
         for (DevBuf *b : {&L.w_in, &L.b_in, &L.w_out, &L.b_out, &L.w1, &L.b1, &L.w2, &L.b2, &L.n1w, &L.n1b, &L.n2w, &L.n2b}) b->release();
+    for (auto &L : e->dec)
+        for (DevBuf *b : {&L.ws_in, &L.bs_in, &L.ws_out, &L.bs_out, &L.wc_q, &L.bc_q, &L.wc_kv, &L.bc_kv, &L.wc_out, &L.bc_out,
+                          &L.w1, &L.b1, &L.w2, &L.b2, &L.n1w, &L.n1b, &L.n2w, &L.n2b, &L.n3w, &L.n3b}) b->release();
+    e->dec_embed.release();
     for (DevBuf *b : {&e->sa_nw, &e->sa_nb, &e->pe, &e->bn_scale, &e->bn_shift, &e->agg_w, &e->agg_b, &e->head_w, &e->head_b, &e->lut})
         b->release();
     for (Slot &s : e->slot) {
         for (auto &b : s.act) b.release();
-        for (auto &v : {&s.lstm_y, &s.sa_y})
+        for (auto &v : {&s.lstm_y, &s.sa_y, &s.s2s_kv, &s.s2s_cache})
             for (auto &b : *v) b.release();
+        for (DevBuf *b : {&s.s2s_x, &s.s2s_x1, &s.s2s_x2, &s.s2s_t, &s.s2s_ctx, &s.s2s_q, &s.s2s_ff, &s.s2s_logits, &s.s2s_tokens,
+                          &s.s2s_state, &s.s2s_tables}) b->release();
+        if (s.s2s_pinned) (void)hipHostFree(s.s2s_pinned);
+        if (s.s2s_flags) (void)hipHostFree(s.s2s_flags);
+        for (auto &ev : s.s2s_ev)
+            if (ev) (void)hipEventDestroy(ev);
         for (DevBuf *b : {&s.crops, &s.lines, &s.feat, &s.xproj, &s.hbuf, &s.cbuf, &s.logits, &s.best, &s.labels, &s.lens,
                           &s.sa_x, &s.sa_x1, &s.sa_qkv, &s.sa_att, &s.sa_tmp, &s.sa_ff, &s.sp_rowstat, &s.sp_colcount,
                           &s.sp_line_nnz, &s.sp_line_off, &s.sp_indptr, &s.sp_data, &s.sp_indices, &s.sp_rows, &s.geom, &s.seqgeom})
@@ -907,8 +1001,9 @@ static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n)
     return 0;
 }
 
-int pocr_slot_stage_ragged(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
-                           const int32_t *widths, const int32_t *w_pads, int32_t n, int32_t pad_left) {
+static int stage_ragged_impl(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
+                             const int32_t *widths, const int32_t *w_pads, int32_t n, int32_t pad_left,
+                             const int32_t *pad_lefts) {
     if (check_slot(e, slot)) return 1;
     Slot &s = e->slot[slot];
     if (s.in_flight) return fail("slot %d has a launch in flight: collect it first", slot);
@@ -938,7 +1033,10 @@ int pocr_slot_stage_ragged(pocr_engine *e, int32_t slot, const uint8_t *crops, c
         s.host_in_cap = need + need / 4;
     }
     LineDesc *desc = static_cast<LineDesc *>(s.host_in);
-    for (int i = 0; i < n; ++i) { desc[i].offset = crop_offsets[i]; desc[i].width = widths[i]; desc[i].pad_left = pad_left; }
+    for (int i = 0; i < n; ++i) {
+        desc[i].offset = crop_offsets[i]; desc[i].width = widths[i];
+        desc[i].pad_left = pad_lefts ? pad_lefts[i] : pad_left;
+    }
     if (total) memcpy(static_cast<char *>(s.host_in) + desc_bytes, crops, total);
     if (s.crops.reserve(total ? total : 1)) return 1;
     if (s.lines.reserve((size_t)n * sizeof(LineDesc))) return 1;
@@ -948,7 +1046,13 @@ int pocr_slot_stage_ragged(pocr_engine *e, int32_t slot, const uint8_t *crops, c
     HIP_TRY(hipMemcpyAsync(s.seqgeom.p, s.sg_host.data(), s.sg_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, s.stream));
     HIP_TRY(hipStreamSynchronize(s.stream));        // geom_host is pageable: finish the copy before it can change
     s.n = n; s.staged = true; s.have_ms = false;
+    s.s2s_launched = s.s2s_decoded = false;
     return 0;
+}
+
+int pocr_slot_stage_ragged(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
+                           const int32_t *widths, const int32_t *w_pads, int32_t n, int32_t pad_left) {
+    return stage_ragged_impl(e, slot, crops, crop_offsets, widths, w_pads, n, pad_left, nullptr);
 }
 
 int pocr_slot_stage_lines(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
@@ -964,6 +1068,7 @@ int pocr_slot_launch(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t 
     Slot &s = e->slot[slot];
     if (!s.staged) return fail("slot %d: no chunk staged", slot);
     if (s.in_flight) return fail("slot %d already has a launch in flight", slot);
+    if (e->cfg.arch == POCR_ARCH_S2S) return fail("sequence-to-sequence engine: use pocr_s2s_launch / pocr_s2s_decode");
     HIP_TRY(hipSetDevice(e->device));
     s.want_logits = want_logits != 0;
     s.want_argmax = want_argmax != 0;
@@ -991,6 +1096,7 @@ int pocr_slot_launch_sparse(pocr_engine *e, int32_t slot, const int32_t *row_beg
     if (!s.staged) return fail("slot %d: no chunk staged", slot);
     if (s.in_flight) return fail("slot %d already has a launch in flight", slot);
     if ((row_begin == nullptr) != (row_end == nullptr)) return fail("row_begin and row_end must both be given or both be NULL");
+    if (e->cfg.arch == POCR_ARCH_S2S) return fail("sequence-to-sequence engine: use pocr_s2s_launch / pocr_s2s_decode");
     HIP_TRY(hipSetDevice(e->device));
     s.sp_has_rows = row_begin != nullptr;
     if (s.sp_has_rows) {
@@ -1046,6 +1152,215 @@ int pocr_slot_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t 
         HIP_TRY(hipMemcpyAsync(indices, s.sp_indices.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, s.seq_stream));
     }
     return collect_outputs(e, s, nullptr, frame_argmax_nt, labels_nt, label_len_n);
+}
+
+
+// ------------------------------------------------------------------ sequence-to-sequence (decoder.hpp)
+
+int pocr_s2s_stage(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
+                   const int32_t *widths, const int32_t *w_pads, const int32_t *pad_lefts, int32_t n) {
+    if (check_slot(e, slot)) return 1;
+    if (e->cfg.arch != POCR_ARCH_S2S) return fail("pocr_s2s_stage needs a POCR_ARCH_S2S engine");
+    if (!pad_lefts) return fail("NULL input pointer");
+    for (int i = 0; i < n; ++i)
+        if (pad_lefts[i] < 0) return fail("line %d: pad_left must be >= 0", i);
+    if (stage_ragged_impl(e, slot, crops, crop_offsets, widths, w_pads, n, 0, pad_lefts)) return 1;
+    e->slot[slot].s2s_wpads.assign(w_pads, w_pads + n);
+    return 0;
+}
+
+int pocr_s2s_launch(pocr_engine *e, int32_t slot, const int32_t *batch_first, int32_t n_batches) {
+    if (check_slot(e, slot)) return 1;
+    Slot &s = e->slot[slot];
+    if (e->cfg.arch != POCR_ARCH_S2S) return fail("pocr_s2s_launch needs a POCR_ARCH_S2S engine");
+    if (!s.staged || (int)s.s2s_wpads.size() != s.n) return fail("slot %d: nothing staged with pocr_s2s_stage", slot);
+    if (s.in_flight) return fail("slot %d already has a launch in flight", slot);
+    if (!batch_first || n_batches < 1) return fail("batch_first / n_batches invalid");
+    if (batch_first[0] != 0 || batch_first[n_batches] != s.n) return fail("batch_first must start at 0 and end at n = %d", s.n);
+    HIP_TRY(hipSetDevice(e->device));
+    s.s2s_batch_first.assign(batch_first, batch_first + n_batches + 1);
+    s.s2s_limit.resize(n_batches);
+    int cap = 0;
+    for (int b = 0; b < n_batches; ++b) {
+        if (batch_first[b + 1] <= batch_first[b]) return fail("batch %d is empty", b);
+        const int wp = s.s2s_wpads[batch_first[b]];
+        for (int i = batch_first[b]; i < batch_first[b + 1]; ++i)
+            if (s.s2s_wpads[i] != wp) return fail("batch %d: all lines of a batch must have the same w_pad", b);
+        s.s2s_limit[b] = wp / 4;                       // inputs.shape[-1] // 4 (transformer_ocr_engine.py:77)
+        cap = std::max(cap, wp / 4 + 1);
+    }
+    if (cap > DEC_MAX_KEYS || s.t_max > DEC_MAX_KEYS) return fail("line too long for the decoder (%d steps / %d frames, limit %d)", cap, s.t_max, DEC_MAX_KEYS);
+    s.s2s_batches = n_batches;
+    s.s2s_cap = cap;
+    if (run_network(e, s)) return 1;                   // encoder + key/value projections, asynchronous
+    s.in_flight = true;
+    s.s2s_launched = true;
+    s.s2s_decoded = false;
+    e->last_slot = slot;
+    return 0;
+}
+
+
+int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *steps, int32_t *s_max) {
+    if (check_slot(e, slot)) return 1;
+    Slot &s = e->slot[slot];
+    if (!s.s2s_launched || !s.in_flight) return fail("slot %d: pocr_s2s_launch first", slot);
+    if (!steps || !s_max) return fail("NULL output pointer");
+    HIP_TRY(hipSetDevice(e->device));
+    const pocr_config &c = e->cfg;
+    const int n = s.n, E = c.conv_out, FF = c.sa_ff, C = c.num_classes, heads = c.sa_heads, D = E / heads;
+    const int L = c.dec_layers, S_cap = s.s2s_cap, nb = s.s2s_batches;
+    hipStream_t st = s.seq_stream;
+    const size_t ne = (size_t)n * E * sizeof(float);
+    for (DevBuf *b : {&s.s2s_x, &s.s2s_x1, &s.s2s_x2, &s.s2s_t, &s.s2s_ctx, &s.s2s_q})
+        if (b->reserve(ne)) return 1;
+    if (s.s2s_ff.reserve((size_t)n * FF * sizeof(float))) return 1;
+    if (s.s2s_logits.reserve((size_t)n * S_cap * C * sizeof(float))) return 1;
+    if (s.s2s_tokens.reserve((size_t)n * S_cap * sizeof(int32_t))) return 1;
+    for (int l = 0; l < L; ++l)
+        if (s.s2s_cache[l].reserve((size_t)S_cap * n * 3 * E * sizeof(float))) return 1;
+    // tables: batch_first [nb+1] | limit [nb] | line_batch [n];  state: alive [n] | batch_done [nb] | steps [nb] | remaining
+    std::vector<int32_t> tab((size_t)nb + 1 + nb + n);
+    memcpy(tab.data(), s.s2s_batch_first.data(), (size_t)(nb + 1) * sizeof(int32_t));
+    memcpy(tab.data() + nb + 1, s.s2s_limit.data(), (size_t)nb * sizeof(int32_t));
+    for (int b = 0; b < nb; ++b)
+        for (int i = s.s2s_batch_first[b]; i < s.s2s_batch_first[b + 1]; ++i) tab[2 * nb + 1 + i] = b;
+    if (s.s2s_tables.reserve(tab.size() * sizeof(int32_t))) return 1;
+    if (s.s2s_state.reserve(((size_t)n + 2 * nb + 1) * sizeof(int32_t))) return 1;
+    HIP_TRY(hipMemcpyAsync(s.s2s_tables.p, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));                 // `tab` is pageable and dies with this scope; also: the encoder is done
+    const int32_t *d_batch_first = s.s2s_tables.as<int32_t>(), *d_limit = d_batch_first + nb + 1, *d_line_batch = d_limit + nb;
+    int32_t *d_alive = s.s2s_state.as<int32_t>(), *d_done = d_alive + n, *d_steps = d_done + nb, *d_remaining = d_steps + nb;
+    constexpr int BLK = 8, MAXBLK = (DEC_MAX_KEYS + BLK) / BLK + 2;
+    const size_t flags_need = ((size_t)MAXBLK + nb) * sizeof(int32_t);
+    if (flags_need > s.s2s_flags_cap) {
+        if (s.s2s_flags) (void)hipHostFree(s.s2s_flags);
+        s.s2s_flags = nullptr; s.s2s_flags_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.s2s_flags), 2 * flags_need, hipHostMallocDefault));
+        s.s2s_flags_cap = 2 * flags_need;
+    }
+    HIP_TRY(hipMemsetAsync(s.s2s_tokens.p, 0xFF, (size_t)n * S_cap * sizeof(int32_t), st));
+    if (want_logits) HIP_TRY(hipMemsetAsync(s.s2s_logits.p, 0, (size_t)n * S_cap * C * sizeof(float), st));
+
+    S2sState stt{};
+    stt.tokens = s.s2s_tokens.as<int32_t>(); stt.alive = d_alive; stt.batch_done = d_done; stt.steps = d_steps;
+    stt.remaining = d_remaining; stt.batch_first = d_batch_first; stt.limit = d_limit;
+    stt.embed = e->dec_embed.as<float>(); stt.pe = e->pe.as<float>(); stt.x = s.s2s_x.as<float>();
+    stt.n = n; stt.n_batches = nb; stt.S_cap = S_cap; stt.C = C; stt.E = E; stt.boundary = C - 2;
+    hipLaunchKernelGGL(s2s_init_kernel, dim3(std::max(1, std::min(1024, (n * E + 255) / 256))), dim3(256), 0, st, stt);
+    HIP_TRY(hipGetLastError());
+
+    auto gemm = [&](const float *x_, int64_t ldx, const DevBuf &w_, const DevBuf &b_, int cout_, int K_, float *y_, int64_t ldy, bool relu) {
+        SkinnyArgs a{};
+        a.x = x_; a.wfrag = w_.as<float>(); a.bias = b_.as<float>(); a.y = y_; a.ldx = ldx; a.ldy = ldy;
+        a.M = n; a.K = K_; a.cout16 = round_up(cout_, kSkinnyNT) / 16; a.cout_valid = cout_; a.stop = d_remaining;
+        return relu ? launch_skinny<true>(a, st) : launch_skinny<false>(a, st);
+    };
+    auto ln = [&](const float *a_, const float *b_, const DevBuf &gw, const DevBuf &gb, float *y_) {
+        hipLaunchKernelGGL(layernorm_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a_, b_, gw.as<float>(), gb.as<float>(),
+                           (const float *)nullptr, y_, n, E, 1, 1e-5f, (const int32_t *)nullptr, (const int32_t *)d_remaining);
+    };
+    auto attend = [&](DecAttnArgs a) {
+        a.out = s.s2s_ctx.as<float>(); a.line_batch = d_line_batch; a.batch_done = d_done; a.stop = d_remaining;
+        a.E = E; a.scale = 1.0f / sqrtf((float)D);
+        const dim3 grid(heads, n);
+        if (D == 32) hipLaunchKernelGGL(dec_attention_kernel<32>, grid, dim3(256), 0, st, a);
+        else if (D == 64) hipLaunchKernelGGL(dec_attention_kernel<64>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(dec_attention_kernel<128>, grid, dim3(256), 0, st, a);
+    };
+    const float scale_unused = 0.f; (void)scale_unused;
+    int blocks = 0;
+    bool finished = false;
+    for (int step = 0; step < S_cap && !finished; ++step) {
+        if (step % BLK == 0 && step >= 2 * BLK) {          // look at the block before the previous one: two blocks stay in flight
+            const int k = step / BLK - 2;
+            HIP_TRY(hipEventSynchronize(s.s2s_ev[k & 1]));
+            if (s.s2s_flags[k] == 0) { finished = true; break; }
+        }
+        float *x = s.s2s_x.as<float>(), *x1 = s.s2s_x1.as<float>(), *x2 = s.s2s_x2.as<float>(), *t = s.s2s_t.as<float>();
+        float *ctx = s.s2s_ctx.as<float>(), *q = s.s2s_q.as<float>(), *ff = s.s2s_ff.as<float>();
+        for (int l = 0; l < L; ++l) {
+            pocr_engine::DecLayer &W = e->dec[l];
+            float *cache = s.s2s_cache[l].as<float>();
+            float *row = cache + (size_t)step * n * 3 * E;          // linear_cache[seq_len - 1] (transformer.py:250)
+            if (gemm(x, E, W.ws_in, W.bs_in, 3 * E, E, row, 3 * E, false)) return 1;
+            {
+                DecAttnArgs a{};
+                a.q = row; a.ldq = 3 * E; a.k = cache + E; a.v = cache + 2 * E;
+                a.pos_stride = (int64_t)n * 3 * E; a.line_stride = 3 * E; a.len = step + 1;
+                attend(a);
+            }
+            if (gemm(ctx, E, W.ws_out, W.bs_out, E, E, t, E, false)) return 1;
+            ln(x, t, W.n1w, W.n1b, x1);
+            if (gemm(x1, E, W.wc_q, W.bc_q, E, E, q, E, false)) return 1;
+            {
+                DecAttnArgs a{};
+                a.q = q; a.ldq = E; a.k = s.s2s_kv[l].as<float>(); a.v = s.s2s_kv[l].as<float>() + E;
+                a.pos_stride = 2 * E; a.row_off = s.g_row_off; a.line_len = s.g_line_T;
+                attend(a);
+            }
+            if (gemm(ctx, E, W.wc_out, W.bc_out, E, E, t, E, false)) return 1;
+            ln(x1, t, W.n2w, W.n2b, x2);
+            if (gemm(x2, E, W.w1, W.b1, FF, E, ff, FF, true)) return 1;
+            if (gemm(ff, FF, W.w2, W.b2, E, FF, t, E, false)) return 1;
+            ln(x2, t, W.n3w, W.n3b, x);
+        }
+        float *lg = s.s2s_logits.as<float>() + (size_t)step * C;
+        if (gemm(s.s2s_x.as<float>(), E, e->head_w, e->head_b, C, E, lg, (int64_t)S_cap * C, false)) return 1;
+        hipLaunchKernelGGL(s2s_sample_kernel, dim3(nb), dim3(256), 0, st, stt, (const float *)lg, (int64_t)S_cap * C, step);
+        HIP_TRY(hipGetLastError());
+        if (step % BLK == BLK - 1) {
+            const int k = step / BLK;
+            HIP_TRY(hipMemcpyAsync(&s.s2s_flags[k], d_remaining, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(s.s2s_ev[k & 1], st));
+            blocks = k + 1;
+        }
+    }
+    (void)blocks;
+    int32_t *h_steps = s.s2s_flags + MAXBLK;
+    HIP_TRY(hipMemcpyAsync(h_steps, d_steps, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_steps + nb, d_remaining, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_steps[nb] != 0) return fail("internal error: %d batches still decoding after %d steps", h_steps[nb], S_cap);
+    int smax = 0;
+    s.s2s_steps.assign(h_steps, h_steps + nb);
+    for (int b = 0; b < nb; ++b) { steps[b] = h_steps[b]; smax = std::max(smax, h_steps[b]); }
+    *s_max = smax;
+    s.s2s_smax = smax;
+    s.s2s_want_logits = want_logits != 0;
+    // results -> pinned: tokens [n][S_cap] | logits [n][smax][C]
+    const size_t tok_bytes = (size_t)n * S_cap * sizeof(int32_t);
+    const size_t lg_bytes = want_logits ? (size_t)n * smax * C * sizeof(float) : 0;
+    if (tok_bytes + lg_bytes > s.s2s_pinned_cap) {
+        if (s.s2s_pinned) (void)hipHostFree(s.s2s_pinned);
+        s.s2s_pinned = nullptr; s.s2s_pinned_cap = 0;
+        const size_t want = (tok_bytes + lg_bytes) * 5 / 4;
+        HIP_TRY(hipHostMalloc(&s.s2s_pinned, want, hipHostMallocDefault));
+        s.s2s_pinned_cap = want;
+    }
+    char *pin = static_cast<char *>(s.s2s_pinned);
+    HIP_TRY(hipMemcpyAsync(pin, s.s2s_tokens.p, tok_bytes, hipMemcpyDeviceToHost, st));
+    if (lg_bytes)
+        HIP_TRY(hipMemcpy2DAsync(pin + tok_bytes, (size_t)smax * C * sizeof(float), s.s2s_logits.p, (size_t)S_cap * C * sizeof(float),
+                                 (size_t)smax * C * sizeof(float), (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    s.s2s_decoded = true;
+    s.in_flight = false;
+    return 0;
+}
+
+int pocr_s2s_collect(pocr_engine *e, int32_t slot, int32_t *tokens, float *logits) {
+    if (check_slot(e, slot)) return 1;
+    Slot &s = e->slot[slot];
+    if (!s.s2s_decoded) return fail("slot %d: pocr_s2s_decode first", slot);
+    if (logits && !s.s2s_want_logits) return fail("logits were not requested at pocr_s2s_decode");
+    const int n = s.n, S_cap = s.s2s_cap, smax = s.s2s_smax, C = e->cfg.num_classes;
+    const char *pin = static_cast<const char *>(s.s2s_pinned);
+    if (tokens)
+        for (int i = 0; i < n; ++i)
+            memcpy(tokens + (size_t)i * smax, pin + (size_t)i * S_cap * sizeof(int32_t), (size_t)smax * sizeof(int32_t));
+    if (logits) memcpy(logits, pin + (size_t)n * S_cap * sizeof(int32_t), (size_t)n * smax * C * sizeof(float));
+    return 0;
 }
 
 int pocr_stage_lines(pocr_engine *e, const uint8_t *crops, const int64_t *crop_offsets, const int32_t *widths,
@@ -1133,7 +1448,7 @@ int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t
     if (what >= 0 && what < 9) { src = s.act[what].as<float>(); sz = (size_t)s.act_elems[what]; }
     else if (what == 9) { src = s.feat.as<float>(); sz = rows * e->cfg.conv_out; }
     else if (e->cfg.arch == POCR_ARCH_SA && what == 10) { src = nullptr; return fail("activation 10 (LayerNorm+PE) is not retained"); }
-    else if (e->cfg.arch == POCR_ARCH_SA && what >= 11 && what < 11 + e->cfg.sa_layers) { src = s.sa_y[what - 11].as<float>(); sz = rows * e->cfg.conv_out; }
+    else if ((e->cfg.arch == POCR_ARCH_SA || e->cfg.arch == POCR_ARCH_S2S) && what >= 11 && what < 11 + e->cfg.sa_layers) { src = s.sa_y[what - 11].as<float>(); sz = rows * e->cfg.conv_out; }
     else if (e->cfg.arch == POCR_ARCH_BLSTM && what >= 10 && what < 10 + e->cfg.lstm_layers) { src = s.lstm_y[what - 10].as<float>(); sz = rows * 2 * e->cfg.lstm_hidden; }
     else return fail("unknown activation id %d", what);
     if (n_floats) *n_floats = sz;

@@ -41,6 +41,8 @@ import numpy as np
 
 ARCH = "vgg_blstm_ctc"
 ARCH_SA = "vgg_sa_ctc"          # same backbone, self-attention encoder instead of the BiLSTM (BASELINE config 4)
+ARCH_S2S = "vgg_sa_s2s"         # backbone + self-attention encoder + autoregressive transformer decoder
+                                # (TransformerOCR, pero_ocr/ocr_engine/transformer.py:388-508)
 LN_EPS = 1e-5
 MAGIC = b"POCRW001"
 LEAKY_SLOPE = 0.01
@@ -75,11 +77,16 @@ class NetSpec:
     sa_layers: int = 2
     sa_heads: int = 8
     sa_ff: int = 2048
+    # "vgg_sa_s2s" only: decoder layers (same width / heads / feed-forward size as the encoder,
+    # transformer.build_net :13-47); num_classes then counts the symbols + sentence boundary + ignore
+    dec_layers: int = 2
 
     def __post_init__(self):
-        if self.arch not in (ARCH, ARCH_SA):
+        if self.arch not in (ARCH, ARCH_SA, ARCH_S2S):
             raise ValueError(f"unknown arch {self.arch!r}")
-        if self.arch == ARCH_SA:
+        if self.arch == ARCH_S2S and self.dec_layers < 1:
+            raise ValueError("dec_layers must be >= 1")
+        if self.arch in (ARCH_SA, ARCH_S2S):
             if self.conv_out % self.sa_heads or (self.conv_out // self.sa_heads) % 16:
                 raise ValueError("conv_out / sa_heads must be a multiple of 16")
             if self.sa_ff % 16 or self.sa_layers < 1:
@@ -102,7 +109,8 @@ class NetSpec:
     def from_json(d: dict) -> "NetSpec":
         return NetSpec(**{k: d[k] for k in
                           ("num_classes", "height", "in_channels", "conv_out",
-                           "lstm_hidden", "lstm_layers", "arch", "sa_layers", "sa_heads", "sa_ff") if k in d})
+                           "lstm_hidden", "lstm_layers", "arch", "sa_layers", "sa_heads", "sa_ff", "dec_layers")
+                          if k in d})
 
 
 def tensor_table(spec: NetSpec) -> List[Tuple[str, Tuple[int, ...], str, int]]:
@@ -121,7 +129,7 @@ def tensor_table(spec: NetSpec) -> List[Tuple[str, Tuple[int, ...], str, int]]:
     ah = spec.agg_height
     t.append(("agg.weight", (spec.conv_out, c_last, ah, 1), "conv_w", c_last * ah))
     t.append(("agg.bias", (spec.conv_out,), "bias", c_last * ah))
-    if spec.arch == ARCH_SA:
+    if spec.arch in (ARCH_SA, ARCH_S2S):
         e, ff = spec.conv_out, spec.sa_ff
         t.append(("sa.norm.weight", (e,), "ln_w", 0))
         t.append(("sa.norm.bias", (e,), "ln_b", 0))
@@ -138,6 +146,26 @@ def tensor_table(spec: NetSpec) -> List[Tuple[str, Tuple[int, ...], str, int]]:
             t.append((f"sa{l}.norm1.bias", (e,), "ln_b", 0))
             t.append((f"sa{l}.norm2.weight", (e,), "ln_w", 0))
             t.append((f"sa{l}.norm2.bias", (e,), "ln_b", 0))
+        if spec.arch == ARCH_S2S:
+            # decoder layer = DecoderLayer (transformer.py:388-463): cached self-attention, attention over the
+            # encoder output, ReLU feed-forward; post-norm.  Then Embedding(C, E) and Linear(E, C) (:497-498).
+            for l in range(spec.dec_layers):
+                for att in ("self", "cross"):
+                    t.append((f"dec{l}.{att}.in_proj.weight", (3 * e, e), "sa_w", e))
+                    t.append((f"dec{l}.{att}.in_proj.bias", (3 * e,), "sa_b", e))
+                    t.append((f"dec{l}.{att}.out_proj.weight", (e, e), "sa_w", e))
+                    t.append((f"dec{l}.{att}.out_proj.bias", (e,), "sa_b", e))
+                t.append((f"dec{l}.lin1.weight", (ff, e), "sa_w", e))
+                t.append((f"dec{l}.lin1.bias", (ff,), "sa_b", e))
+                t.append((f"dec{l}.lin2.weight", (e, ff), "sa_w", ff))
+                t.append((f"dec{l}.lin2.bias", (e,), "sa_b", ff))
+                for k in (1, 2, 3):
+                    t.append((f"dec{l}.norm{k}.weight", (e,), "ln_w", 0))
+                    t.append((f"dec{l}.norm{k}.bias", (e,), "ln_b", 0))
+            t.append(("dec.embed.weight", (spec.num_classes, e), "embed", e))
+            t.append(("dec.out.weight", (spec.num_classes, e), "head_w", e))
+            t.append(("dec.out.bias", (spec.num_classes,), "s2s_b", e))
+            return t
         t.append(("head.weight", (spec.num_classes, e), "head_w", e))
         t.append(("head.bias", (spec.num_classes,), "head_b", e))
         return t
@@ -186,14 +214,25 @@ def uniform01(seed: int, stream: int, n: int) -> np.ndarray:
 
 
 def generate_weights(spec: NetSpec, seed: int, head_gain: float = 20.0,
-                     lstm_gain: float = 3.0, blank_bias: float = 9.0, sa_gain: float = 1.0) -> Dict[str, np.ndarray]:
+                     lstm_gain: float = 3.0, blank_bias: float = 9.0, sa_gain: float = 1.0,
+                     boundary_bias: float = 36.0, embed_gain: float = 0.8, walk_gain: float = 12.0,
+                     walk_stride: int = 7) -> Dict[str, np.ndarray]:
     """Seeded synthetic weights (no real pero checkpoint exists offline).
     He-uniform for conv layers so activations keep their scale through the
     ReLU stack; torch-default U(-1/sqrt(H), 1/sqrt(H)) * lstm_gain for the LSTM;
     head scaled so logits span several units (a 1e-3 logit tolerance and the
-    p<1e-4 sparsification are then meaningful)."""
+    p<1e-4 sparsification are then meaningful).
+
+    "vgg_sa_s2s": an autoregressive decoder with purely random weights falls into a fixed point after a
+    few steps (it repeats one symbol until the length limit), which would exercise nothing.  The output
+    projection therefore gets a deterministic structure on top of a small random part:
+        dec.out.weight[c] = 0.1 * random + walk_gain * embed[pred(c)] / (embed_gain * sqrt(E)),
+    pred(c) = (c - walk_stride) mod (C - 1), so that the most likely next symbol is "previous symbol +
+    walk_stride" and the encoder / attention / feed-forward contributions decide where a line leaves that
+    walk; boundary_bias sets how often such a departure ends the line.  The result is lines that end after
+    a few symbols, lines that run into the reference's length limit, and top-2 margins between 1e-2 and 5."""
     out: Dict[str, np.ndarray] = {}
-    if spec.arch == ARCH_SA:
+    if spec.arch in (ARCH_SA, ARCH_S2S):
         head_gain = head_gain * 0.4        # the encoder output is LayerNorm'ed (unit scale), the LSTM's is in (-1, 1)
         blank_bias = blank_bias * 0.6
     for ti, (name, shape, kind, fan_in) in enumerate(tensor_table(spec)):
@@ -229,9 +268,21 @@ def generate_weights(spec: NetSpec, seed: int, head_gain: float = 20.0,
         elif kind == "head_b":
             v = (2.0 * u - 1.0) * 0.5
             v[-1] = blank_bias          # CTC nets emit blank on most frames
+        elif kind == "embed":
+            v = (2.0 * u - 1.0) * (embed_gain * 3.0 ** 0.5)      # variance embed_gain^2 (nn.Embedding: N(0, 1))
+        elif kind == "s2s_b":
+            v = (2.0 * u - 1.0) * 0.5
+            v[-2] = boundary_bias       # sentence boundary (C-2): random nets must end their lines at some point
+            v[-1] = -30.0               # the "ignore" class (C-1) is never predicted by a trained model
         else:  # pragma: no cover
             raise AssertionError(kind)
         out[name] = v.astype(np.float32).reshape(shape)
+    if spec.arch == ARCH_S2S:
+        c, e = spec.num_classes, spec.conv_out
+        pred = (np.arange(c - 1) - walk_stride) % (c - 1)
+        w = out["dec.out.weight"].astype(np.float64) * 0.1
+        w[:c - 1] += walk_gain * out["dec.embed.weight"][pred].astype(np.float64) / (embed_gain * e ** 0.5)
+        out["dec.out.weight"] = w.astype(np.float32)
     return out
 
 

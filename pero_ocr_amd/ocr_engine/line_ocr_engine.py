@@ -6,9 +6,10 @@ Mirrors the public surface of the reference's BaseEngineLineOCR
 (pero_ocr/ocr_engine/line_ocr_engine.py:16-177): same constructor arguments,
 same attributes (`characters`, `batch_size`, `max_input_horizontal_pixels`,
 `line_px_height`, `line_padding_px`, `embed_id`, `embed_num`, `config`, ...),
-same `process_lines` signature, defaults and return contract.  Only the CTC
-branch is implemented (the transformer split/merge branch :95-119,131-142 is a
-SURVEY.md section 8 "next" row).
+same `process_lines` signature, defaults and return contract.  `process_lines`
+here is the CTC form; the "transformer" branches (:84-85,95-119,131-142,161-162) and
+merge_transcriptions_and_logits / find_best_overlap (:180-211) are used by
+transformer_ocr_engine.TransformerEngineLineOCR, which overrides process_lines.
 
 Chunking is part of the numerical contract: a line's logits
 depend on the padded width of its chunk, so `plan_chunks` reproduces
@@ -117,8 +118,8 @@ class BaseEngineLineOCR:
         if "embed_id" in cfg:
             self.embed_id = "mean" if cfg["embed_id"] == "mean" else int(cfg["embed_id"])
         self.max_line_width = int(cfg["max_line_width"]) if "max_line_width" in cfg else 1e10
-        if model_type != "ctc":
-            raise NotImplementedError("only the CTC engine is implemented on MI355X (model_type='ctc')")
+        if model_type not in ("ctc", "transformer"):
+            raise ValueError(f"unknown model_type {model_type!r}")
         self.model_type = model_type
         self.device = device
         self.batch_size = batch_size
@@ -218,3 +219,48 @@ class BaseEngineLineOCR:
         if pending is not None:
             scatter(pending[0].line_ids, *self._collect_launch(pending[1]))
         return transcriptions, logits_out, coords_out
+
+
+# ---- helpers of the "transformer" branch (over-long lines are recognised in overlapping parts) -------------
+
+def levenshtein_distance(source, target) -> int:
+    """Unit-cost edit distance (the quantity pero_ocr/sequence_alignment.py:4-13 returns for the default
+    costs).  Row-wise DP; the insertion chain of a row is resolved with a running minimum."""
+    tgt = np.asarray(list(target), dtype=object)
+    m = len(tgt)
+    ramp = np.arange(m + 1)
+    dist = ramp.copy()
+    for ch in source:
+        cand = np.empty(m + 1, dtype=np.int64)
+        cand[0] = dist[0] + 1
+        if m:
+            cand[1:] = np.minimum(dist[1:] + 1, dist[:-1] + (tgt != ch))
+        dist = np.minimum.accumulate(cand - ramp) + ramp          # dist[j] = min_k<=j cand[k] + (j - k)
+    return int(dist[-1])
+
+
+def find_best_overlap(text1, text2) -> int:
+    """Length i (1..min(len)) of the suffix of text1 / prefix of text2 with the lowest character error
+    rate; the first such i wins; 0 when no rate is below 1 (line_ocr_engine.py:196-211)."""
+    best_cer, best = 1, 0
+    for i in range(1, min(len(text1), len(text2)) + 1):
+        cer = levenshtein_distance(list(text1[-i:]), list(text2[:i])) / i
+        if cer < best_cer:
+            best_cer, best = cer, i
+    return best
+
+
+def merge_transcriptions_and_logits(transcription_parts, logits_parts):
+    """Joins the parts of one line (line_ocr_engine.py:180-193).  Every part's logits are first cut to
+    the length of its transcription; at each seam half of the best overlap is dropped on either side.
+    The reference writes the left cut as `[:-overlap // 2]`, i.e. [: (-overlap) // 2]: the ceiling half,
+    and an EMPTY left side when no overlap was found (overlap 0) - kept as is."""
+    text = transcription_parts[0]
+    logits = logits_parts[0][:len(text)]
+    for nxt, nxt_logits in zip(transcription_parts[1:], logits_parts[1:]):
+        nxt_logits = nxt_logits[:len(nxt)]
+        overlap = find_best_overlap(text, nxt)
+        left_end = (-overlap) // 2
+        text = text[:left_end] + nxt[overlap // 2:]
+        logits = np.concatenate([logits[:left_end], nxt_logits[overlap // 2:]], axis=0)
+    return text, logits

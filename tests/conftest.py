@@ -39,7 +39,8 @@ class Golden:
 
     def weights(self):
         from pero_ocr_amd import netspec
-        return netspec.generate_weights(self.spec(), self.meta["weight_seed"])
+        extra = {"boundary_bias": self.meta["boundary_bias"]} if "boundary_bias" in self.meta else {}
+        return netspec.generate_weights(self.spec(), self.meta["weight_seed"], **extra)
 
     def crops(self):
         from pero_ocr_amd import synth

@@ -1,0 +1,176 @@
+"""Sequence-to-sequence (transformer) engine, SURVEY.md section 8 row f-3.
+
+CPU part: the oracle restatement against the fixtures written from the reference's own
+TransformerEngineLineOCR run (oracle/gen_golden_s2s.py), and the host logic (batch plan, part
+splitting, merging) against the oracle.  GPU part: the HIP engine through the reference-shaped
+TransformerEngineLineOCR against the same fixtures.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from pero_ocr_amd import netspec
+from pero_ocr_amd.ocr_engine import line_ocr_engine as host
+from pero_ocr_amd.ocr_engine import transformer_ocr_engine as tengine
+from oracle import s2s_oracle
+
+from conftest import gpu_available
+
+LOGIT_TOL = 1e-3            # north_star: logits within 1e-3 (fp32)
+SAFE_MARGIN = 2e-4          # a reference top-2 margin below this may legitimately flip under fp32 re-association
+
+
+# ------------------------------------------------------------------------------------------- CPU
+
+def test_edit_distance_and_overlap_match_oracle():
+    rnd = random.Random(5)
+    for _ in range(400):
+        a = "".join(rnd.choice("abcd") for _ in range(rnd.randint(0, 14)))
+        b = "".join(rnd.choice("abcd") for _ in range(rnd.randint(0, 14)))
+        assert host.levenshtein_distance(list(a), list(b)) == s2s_oracle.edit_distance(a, b)
+        assert host.find_best_overlap(a, b) == s2s_oracle.best_overlap(a, b)
+    assert host.levenshtein_distance("kitten", "sitting") == 3
+    assert host.find_best_overlap("hello wor", "o world") == 5      # "o wor" == "o wor"
+
+
+def test_merge_known_answers():
+    lg = lambda t: np.arange(len(t) * 2, dtype=np.float32).reshape(len(t), 2)
+    # overlap 5 ("o wor"): left keeps [:-3], right drops its first 2
+    text, logits = host.merge_transcriptions_and_logits(["hello wor", "o world"], [lg("hello wor"), lg("o world")])
+    assert text == "hello world" and logits.shape == (len(text), 2)
+    # no overlap below CER 1 -> overlap 0 -> the reference's [: -0 // 2] = [:0] drops the whole left side
+    text, logits = host.merge_transcriptions_and_logits(["abc", "xyz"], [lg("abc"), lg("xyz")])
+    assert text == "xyz" and logits.shape == (3, 2)
+    # logits of a single part are cut to the length of its transcription
+    text, logits = host.merge_transcriptions_and_logits(["ab"], [np.zeros((7, 3), np.float32)])
+    assert text == "ab" and logits.shape == (2, 3)
+    for parts in (["abcab", "cabca", "bcabc"], ["", "abc"], ["abc", ""], ["aaaa", "aaaa"]):
+        ls = [lg(p) for p in parts]
+        t1, l1 = host.merge_transcriptions_and_logits(parts, ls)
+        t2, l2 = s2s_oracle.merge_parts(parts, ls)
+        assert t1 == t2 and np.array_equal(l1, l2)
+
+
+def test_split_spans():
+    assert tengine.split_spans(1024, 1024) == [(0, 1024)]
+    assert tengine.split_spans(1025, 1024) == [(0, 1024), (768, 1025)]
+    assert tengine.split_spans(2100, 1024) == [(0, 1024), (768, 1792), (1536, 2100)]
+    assert tengine.split_spans(5, 1e10) == [(0, 5)]
+    for w in (1, 700, 1024, 1025, 1792, 1793, 4000):
+        assert tengine.split_spans(w, 1024) == s2s_oracle.split_line(w, 1024)
+
+
+@pytest.mark.parametrize("name", ["s2s_ragged", "s2s_c32"])
+def test_batch_plan_matches_reference_run(golden, name):
+    g = golden(name)
+    batches = tengine.plan_batches(g.widths, 480 * g.batch_size, g.max_line_width)
+    assert [[b.line_ids, b.max_width, b.spans] for b in batches] == g.plan
+    for b in batches:
+        assert b.w_pad >= 1088 and b.w_pad % 4 == 0
+        assert b.pad_left == 32 + (1088 - b.w_batch) // 2 if b.w_batch < 1088 else b.pad_left == 32
+
+
+def check_against_golden(g, texts, logits, coords, steps=None):
+    assert texts == g.transcriptions
+    assert coords == g.logit_coords
+    worst = 0.0
+    for i in range(g.n):
+        ref_rows, ref = g.arrays[f"rows_{i}"], g.arrays[f"dense_{i}"]
+        got = np.asarray(logits[i].todense()) if hasattr(logits[i], "todense") else np.asarray(logits[i])
+        assert got.shape == (len(g.transcriptions[i]), len(g.characters))
+        if got.shape[0] == 0:
+            continue
+        assert np.array_equal(np.argmax(got, axis=1), g.arrays[f"argmax_{i}"].astype(np.int64))
+        worst = max(worst, float(np.max(np.abs(got[ref_rows] - ref))))
+        l2 = float(np.sqrt(np.sum(got.astype(np.float64) ** 2)))
+        assert abs(l2 - float(g.arrays[f"l2_{i}"][0])) <= 1e-4 * max(1.0, l2)
+    assert worst < LOGIT_TOL, worst
+    return worst
+
+
+def test_oracle_reproduces_reference_s2s_ragged(golden):
+    g = golden("s2s_ragged")
+    assert g.min_top2_margin > SAFE_MARGIN
+    model = s2s_oracle.OracleS2S(g.spec(), g.weights())
+    texts, logits, coords, extras = s2s_oracle.process_lines(model, g.crops(), g.characters, g.height,
+                                                             480 * g.batch_size, g.max_line_width)
+    check_against_golden(g, texts, logits, coords)
+    assert extras["steps"] == g.steps
+    lens = [len(t) for t in texts]
+    assert min(lens) <= 8 and max(lens) > 272           # early finishers, limit hitters and merged over-long lines
+
+
+def test_weight_table_s2s_roundtrip(tmp_path):
+    spec = netspec.NetSpec(num_classes=13, arch=netspec.ARCH_S2S, dec_layers=1, sa_layers=1, sa_ff=64, conv_out=64, sa_heads=2)
+    w = netspec.generate_weights(spec, 3)
+    assert w["dec.out.bias"][-2] == np.float32(36.0) and w["dec.embed.weight"].shape == (13, 64)
+    path = str(tmp_path / "m.pocrw")
+    netspec.save_blob(path, spec, w)
+    spec2, w2 = netspec.load_blob(path)
+    assert spec2 == spec and all(np.array_equal(w[k], w2[k]) for k in w)
+
+
+# ------------------------------------------------------------------------------------------- GPU
+
+def make_engine(g, tmp_path, batch_size=None):
+    cfg = {"line_px_height": g.height, "line_vertical_scale": 1.0, "checkpoint": "absent.pocrw",
+           "characters": g.characters[:-2], "net_name": g.net_name, "max_line_width": g.max_line_width,
+           "net": {"weight_seed": g.weight_seed, "boundary_bias": g.boundary_bias}}
+    path = os.path.join(str(tmp_path), f"{g.name}.json")
+    with open(path, "w", encoding="utf8") as f:
+        json.dump(cfg, f)
+    import torch
+    return tengine.TransformerEngineLineOCR(path, torch.device("cuda:0"), batch_size=batch_size or g.batch_size)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["s2s_ragged", "s2s_c32"])
+def test_gpu_s2s_golden(golden, tmp_path, name):
+    assert gpu_available(), "GPU test on a box without a HIP device"
+    g = golden(name)
+    eng = make_engine(g, tmp_path)
+    assert eng.characters == g.characters and eng.sentence_boundary_ind == len(g.characters) - 2
+    crops = g.crops()
+    texts, logits, coords = eng.process_lines([c.copy() for c in crops], sparse_logits=False)
+    worst = check_against_golden(g, texts, logits, coords)
+    print(f"[{name}] max |dlogit| vs reference rows = {worst:.2e}")
+    t2, l2, c2 = eng.process_lines(crops)
+    assert t2 == texts and c2 == coords
+    assert [int(m.nnz) for m in l2] == g.nnz_sparse
+    t3, l3, c3 = eng.process_lines(crops, no_logits=True)
+    assert t3 == texts and all(x is None for x in l3) and all(x is None for x in c3)
+    with pytest.raises(AttributeError):
+        eng.process_lines(crops[:2], tight_crop_logits=True)
+
+
+@pytest.mark.gpu
+def test_gpu_s2s_run_ocr_seam_and_launch_independence(golden, tmp_path):
+    """run_ocr on a hand-assembled batch equals the oracle; recognising the batches of a page one by one
+    gives bit-identical results to the merged launches process_lines uses."""
+    g = golden("s2s_ragged")
+    eng = make_engine(g, tmp_path)
+    crops = g.crops()
+    model = s2s_oracle.OracleS2S(g.spec(), g.weights())
+    ids = [1, 5, 7]                                       # 17, 1 and 96 px wide
+    batch = np.zeros((len(ids), g.height, 96 + 64, 3), np.uint8)
+    for row, i in zip(batch, ids):
+        row[:, 32:32 + crops[i].shape[1]] = crops[i]
+    t_ref, l_ref = model.run_ocr(batch, g.characters)
+    t_gpu, l_gpu = eng.run_ocr(batch)
+    assert t_gpu == t_ref and l_gpu.shape == l_ref.shape
+    keep = max(len(t) for t in t_ref) + 1
+    assert float(np.max(np.abs(l_gpu[:, :keep] - l_ref[:, :keep]))) < LOGIT_TOL
+    # per-batch launches vs merged launches
+    merged = eng.process_lines(crops, sparse_logits=False)
+    old = tengine.LAUNCH_MAX_LINES
+    try:
+        tengine.LAUNCH_MAX_LINES = 1
+        single = eng.process_lines(crops, sparse_logits=False)
+    finally:
+        tengine.LAUNCH_MAX_LINES = old
+    assert merged[0] == single[0] and merged[2] == single[2]
+    for a, b in zip(merged[1], single[1]):
+        assert np.array_equal(a, b)
