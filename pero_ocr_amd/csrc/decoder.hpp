@@ -39,7 +39,9 @@ struct SkinnyArgs {
 
 template <int RM, int CN, bool RELU>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
-    if (a.stop && *a.stop == 0) return;
+    // the stop flag is fetched together with the first operands and tested after the K loop: one memory
+    // round trip less on the critical path of every decoding step
+    const int go = a.stop ? *a.stop : 1;
     __shared__ float part[4 * RM * CN * 256];            // [wave][fragment][lane][reg]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
                 for (int c = 0; c < CN; ++c)
                     acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][j], bv[c][j], acc[r][c], 0, 0, 0);
     }
+    if (go == 0) return;
 #pragma unroll
     for (int r = 0; r < RM; ++r)
 #pragma unroll
@@ -126,7 +129,7 @@ struct DecAttnArgs {
     int64_t ldq, pos_stride, line_stride;
     const int32_t *row_off;  // memory attention: line_base = row_off[i] * pos_stride; NULL: line_base = i * line_stride
     const int32_t *line_len; // keys per line (memory attention); NULL: `len` for every line
-    const int32_t *line_batch, *batch_done;      // lines of finished batches are skipped
+    const int32_t *line_done;                    // lines of finished batches are skipped
     const int32_t *stop;
     int32_t len, E;
     float scale;
@@ -135,9 +138,8 @@ struct DecAttnArgs {
 template <int D>
 __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnArgs a) {
     static_assert(D == 32 || D == 64 || D == 128, "head dim");
-    if (a.stop && *a.stop == 0) return;
     const int head = blockIdx.x, line = blockIdx.y;
-    if (a.batch_done[a.line_batch[line]]) return;
+    const int go = a.stop ? *a.stop : 1, done = a.line_done[line];      // fetched alongside q
     __shared__ float qs[D];
     __shared__ float sc[DEC_MAX_KEYS];
     __shared__ float red[8];
@@ -145,7 +147,9 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = a.line_len ? a.line_len[line] : a.len;
     const size_t base = (a.row_off ? (size_t)a.row_off[line] * a.pos_stride : (size_t)line * a.line_stride) + (size_t)head * D;
-    if (tid < D) qs[tid] = a.q[(size_t)line * a.ldq + head * D + tid] * a.scale;     // q * d^-1/2 first (transformer.py:268)
+    const float qv0 = tid < D ? a.q[(size_t)line * a.ldq + head * D + tid] : 0.f;
+    if (go == 0 || done) return;
+    if (tid < D) qs[tid] = qv0 * a.scale;                                             // q * d^-1/2 first (transformer.py:268)
     __syncthreads();
     float m = -INFINITY;
     for (int p = tid; p < S; p += 256) {
@@ -220,6 +224,7 @@ struct S2sState {
     int32_t *tokens;          // [n][S_cap] sample of every step
     int32_t *alive;           // [n]   line has not produced the boundary symbol yet (transformer_ocr_engine.py:72-73)
     int32_t *batch_done;      // [n_batches]
+    int32_t *line_done;       // [n]   the line's batch is finished
     int32_t *steps;           // [n_batches] decoding steps the reference's loop runs for this batch (= rows of its logits)
     int32_t *remaining;       // unfinished batches
     const int32_t *batch_first;   // [n_batches + 1] first line of every batch
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(256) void s2s_init_kernel(S2sState st) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) *st.remaining = st.n_batches;
     if (i < st.n_batches) { st.batch_done[i] = 0; st.steps[i] = 0; }
-    if (i < st.n) st.alive[i] = 1;
+    if (i < st.n) { st.alive[i] = 1; st.line_done[i] = 0; }
     for (size_t k = i; k < (size_t)st.n * st.E; k += (size_t)gridDim.x * 256) {
         const int e = (int)(k % st.E);
         st.x[k] = st.embed[(size_t)st.boundary * st.E + e] + st.pe[e];       // start token = boundary symbol, position 0
@@ -277,9 +282,10 @@ __global__ __launch_bounds__(256) void s2s_sample_kernel(S2sState st, const floa
     }
     if (lane == 0) any_alive[wave] = any;
     __syncthreads();
-    if (tid == 0) {
-        const bool alive = any_alive[0] | any_alive[1] | any_alive[2] | any_alive[3];
-        if (!alive || s + 1 > st.limit[b]) {          // transformer_ocr_engine.py:74-80 (len(partial_transcripts) = s + 1)
+    const bool alive = any_alive[0] | any_alive[1] | any_alive[2] | any_alive[3];
+    if (!alive || s + 1 > st.limit[b]) {              // transformer_ocr_engine.py:74-80 (len(partial_transcripts) = s + 1)
+        for (int line = st.batch_first[b] + tid; line < st.batch_first[b + 1]; line += 256) st.line_done[line] = 1;
+        if (tid == 0) {
             st.batch_done[b] = 1;
             st.steps[b] = s + 1;
             atomicSub(st.remaining, 1);

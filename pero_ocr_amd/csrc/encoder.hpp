@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *a, const fl
                                                         const float *beta, const float *pe, float *y, int rows,
                                                         int E, int T, float eps, const int32_t *row_t,
                                                         const int32_t *stop) {
-    if (stop && *stop == 0) return;             // decoder steps enqueued past the end of the last batch (decoder.hpp)
+    const int go = stop ? *stop : 1;            // decoder steps enqueued past the end of the last batch (decoder.hpp);
+                                                // tested after the row has been requested
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *a, const fl
         v[k] = x;
         sum += x;
     }
+    if (go == 0) return;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
     const float mean = sum / (float)E;

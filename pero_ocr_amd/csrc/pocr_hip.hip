@@ -1226,11 +1226,12 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
     for (int b = 0; b < nb; ++b)
         for (int i = s.s2s_batch_first[b]; i < s.s2s_batch_first[b + 1]; ++i) tab[2 * nb + 1 + i] = b;
     if (s.s2s_tables.reserve(tab.size() * sizeof(int32_t))) return 1;
-    if (s.s2s_state.reserve(((size_t)n + 2 * nb + 1) * sizeof(int32_t))) return 1;
+    if (s.s2s_state.reserve(((size_t)2 * n + 2 * nb + 1) * sizeof(int32_t))) return 1;
     HIP_TRY(hipMemcpyAsync(s.s2s_tables.p, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));                 // `tab` is pageable and dies with this scope; also: the encoder is done
-    const int32_t *d_batch_first = s.s2s_tables.as<int32_t>(), *d_limit = d_batch_first + nb + 1, *d_line_batch = d_limit + nb;
+    const int32_t *d_batch_first = s.s2s_tables.as<int32_t>(), *d_limit = d_batch_first + nb + 1;
     int32_t *d_alive = s.s2s_state.as<int32_t>(), *d_done = d_alive + n, *d_steps = d_done + nb, *d_remaining = d_steps + nb;
+    int32_t *d_line_done = d_remaining + 1;
     constexpr int BLK = 8, MAXBLK = (DEC_MAX_KEYS + BLK) / BLK + 2;
     const size_t flags_need = ((size_t)MAXBLK + nb) * sizeof(int32_t);
     if (flags_need > s.s2s_flags_cap) {
@@ -1244,6 +1245,7 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
 
     S2sState stt{};
     stt.tokens = s.s2s_tokens.as<int32_t>(); stt.alive = d_alive; stt.batch_done = d_done; stt.steps = d_steps;
+    stt.line_done = d_line_done;
     stt.remaining = d_remaining; stt.batch_first = d_batch_first; stt.limit = d_limit;
     stt.embed = e->dec_embed.as<float>(); stt.pe = e->pe.as<float>(); stt.x = s.s2s_x.as<float>();
     stt.n = n; stt.n_batches = nb; stt.S_cap = S_cap; stt.C = C; stt.E = E; stt.boundary = C - 2;
@@ -1261,7 +1263,7 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
                            (const float *)nullptr, y_, n, E, 1, 1e-5f, (const int32_t *)nullptr, (const int32_t *)d_remaining);
     };
     auto attend = [&](DecAttnArgs a) {
-        a.out = s.s2s_ctx.as<float>(); a.line_batch = d_line_batch; a.batch_done = d_done; a.stop = d_remaining;
+        a.out = s.s2s_ctx.as<float>(); a.line_done = d_line_done; a.stop = d_remaining;
         a.E = E; a.scale = 1.0f / sqrtf((float)D);
         const dim3 grid(heads, n);
         if (D == 32) hipLaunchKernelGGL(dec_attention_kernel<32>, grid, dim3(256), 0, st, a);

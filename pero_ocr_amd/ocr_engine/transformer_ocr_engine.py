@@ -35,8 +35,8 @@ from .pytorch_ocr_engine import _device_index
 from .softmax import softmax
 
 MIN_INPUT_WIDTH = 1088           # transformer_ocr_engine.py:36-40: narrower batches are centred in 1088 columns
-LAUNCH_MAX_LINES = 192           # device lines decoded side by side in one launch
-LAUNCH_MAX_COLUMNS = 256 * 576   # padded pixel columns per launch (encoder work)
+LAUNCH_MAX_LINES = 256           # device lines decoded side by side in one launch: a decoding step is latency-bound,
+LAUNCH_MAX_COLUMNS = 256 * 1088  # so wide launches amortise it (measured 2.3k / 2.7k / 2.9k lines/s for 64 / 128 / 256)
 
 
 class _Batch:

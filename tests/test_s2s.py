@@ -113,6 +113,47 @@ def test_weight_table_s2s_roundtrip(tmp_path):
     assert spec2 == spec and all(np.array_equal(w[k], w2[k]) for k in w)
 
 
+def test_export_transformer_state_dict():
+    """tools/export_weights.py --transformer: the reference's TransformerOCR parameter names -> blob order."""
+    import importlib.util
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sp = importlib.util.spec_from_file_location("export_weights", os.path.join(here, "tools", "export_weights.py"))
+    mod = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(mod)
+    spec = netspec.NetSpec(num_classes=13, arch=netspec.ARCH_S2S, dec_layers=2, sa_layers=1, sa_ff=64, conv_out=64, sa_heads=2)
+    w = netspec.generate_weights(spec, 11)
+    state = {}
+    conv_slots = [0, 2, 5, 7, 10, 12, 14]                  # VGG16 .features indices of the first seven convs
+    for i in range(1, 10):
+        pre = (f"encoder_frontend.blocks_2d.blocks_2d.{conv_slots[i - 1]}." if i <= 7 else
+               f"encoder_frontend.blocks_2d.blocks_2d.19.{(i - 8) * 2}.")
+        state[pre + "weight"], state[pre + "bias"] = w[f"conv{i}.weight"], w[f"conv{i}.bias"]
+    bn = "encoder_frontend.blocks_2d.blocks_2d.20."
+    state[bn + "weight"], state[bn + "bias"], state[bn + "running_mean"], state[bn + "running_var"] = \
+        w["bn.gamma"], w["bn.beta"], w["bn.mean"], w["bn.var"]
+    state[bn + "num_batches_tracked"] = np.zeros((), np.int64)
+    state["encoder_frontend.aggregation_conv.0.weight"], state["encoder_frontend.aggregation_conv.0.bias"] = w["agg.weight"], w["agg.bias"]
+    state["encoder.input_norm.weight"], state["encoder.input_norm.bias"] = w["sa.norm.weight"], w["sa.norm.bias"]
+    names = (("lin1", "linear1"), ("lin2", "linear2"), ("norm1", "norm1"), ("norm2", "norm2"), ("norm3", "norm3"))
+    p = "encoder.trans_encoder.layers.0."
+    state[p + "self_attn.in_proj_weight"], state[p + "self_attn.in_proj_bias"] = w["sa0.in_proj.weight"], w["sa0.in_proj.bias"]
+    state[p + "self_attn.out_proj.weight"], state[p + "self_attn.out_proj.bias"] = w["sa0.out_proj.weight"], w["sa0.out_proj.bias"]
+    for ours, theirs in names[:4]:
+        state[p + theirs + ".weight"], state[p + theirs + ".bias"] = w[f"sa0.{ours}.weight"], w[f"sa0.{ours}.bias"]
+    for l in range(2):
+        p = f"trans_decoder.layers.{l}."
+        for ours, theirs in (("self", "self_attn"), ("cross", "multihead_attn")):
+            state[p + theirs + ".in_proj_weight"], state[p + theirs + ".in_proj_bias"] = w[f"dec{l}.{ours}.in_proj.weight"], w[f"dec{l}.{ours}.in_proj.bias"]
+            state[p + theirs + ".out_proj.weight"], state[p + theirs + ".out_proj.bias"] = w[f"dec{l}.{ours}.out_proj.weight"], w[f"dec{l}.{ours}.out_proj.bias"]
+        for ours, theirs in names:
+            state[p + theirs + ".weight"], state[p + theirs + ".bias"] = w[f"dec{l}.{ours}.weight"], w[f"dec{l}.{ours}.bias"]
+    state["dec_embeder.weight"] = w["dec.embed.weight"]
+    state["dec_out_proj.weight"], state["dec_out_proj.bias"] = w["dec.out.weight"], w["dec.out.bias"]
+    spec2, w2 = mod.transformer_state_to_weights(state, height=40, heads=2)
+    assert spec2 == spec
+    assert np.array_equal(netspec.pack_weights(spec2, w2), netspec.pack_weights(spec, w))
+
+
 # ------------------------------------------------------------------------------------------- GPU
 
 def make_engine(g, tmp_path, batch_size=None):
