@@ -35,10 +35,20 @@ struct SkinnyArgs {
     int64_t ldx, ldy;
     int32_t M, K, cout16, cout_valid;
     const int32_t *stop;
+    // LayerNorm prologue (template LNE > 0, K == LNE): the GEMM input is x = LN(ln_a + ln_b) * gamma + beta,
+    // computed by every workgroup for its own 16 rows into LDS (x is ignored); the workgroups of the first
+    // column tile also store it to ln_out, where later kernels pick it up as their residual input.
+    // Replaces the norm1 / norm2 / norm3 calls of DecoderLayer.infer (transformer.py:431, 443, 446).
+    const float *ln_a, *ln_b, *gamma, *beta;
+    float *ln_out;
+    float eps;
 };
 
-template <int RM, int CN, bool RELU>
+template <int RM, int CN, bool RELU, int LNE = 0>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
+    static_assert(LNE == 0 || RM == 1, "the LayerNorm prologue works on one 16-row tile");
+    constexpr int XP = LNE + 4;                          // LDS row pitch of the normalised rows
+    __shared__ float xs[LNE > 0 ? 16 * XP : 4];
     // the stop flag is fetched together with the first operands and tested after the K loop: one memory
     // round trip less on the critical path of every decoding step
     const int go = a.stop ? *a.stop : 1;
@@ -55,6 +65,36 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     const float *xr[RM];
 #pragma unroll
     for (int r = 0; r < RM; ++r) xr[r] = a.x + (size_t)min(row0 + 16 * r + li, a.M - 1) * a.ldx + 4 * kq;
+    if constexpr (LNE > 0) {
+        // one wave per row, same arithmetic as layernorm_kernel (encoder.hpp)
+        constexpr int NV = LNE / 64;
+        for (int rr = wave; rr < 16; rr += 4) {
+            const int row = min(row0 + rr, a.M - 1);
+            const float *pa = a.ln_a + (size_t)row * LNE, *pb = a.ln_b + (size_t)row * LNE;
+            float v[NV], sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { v[k] = pa[lane + 64 * k] + pb[lane + 64 * k]; sum += v[k]; }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+            const float mean = sum / (float)LNE;
+            float sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { const float dlt = v[k] - mean; sq += dlt * dlt; }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+            const float rstd = 1.0f / sqrtf(sq / (float)LNE + a.eps);
+            const bool store = blockIdx.x == 0 && row0 + rr < a.M && go != 0;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int e = lane + 64 * k;
+                const float o = (v[k] - mean) * rstd * a.gamma[e] + a.beta[e];
+                xs[rr * XP + e] = o;
+                if (store) a.ln_out[(size_t)(row0 + rr) * LNE + e] = o;
+            }
+        }
+        __syncthreads();
+        xr[0] = xs + li * XP + 4 * kq;                   // A fragments now come from LDS
+    }
     const f32x4 *wf = reinterpret_cast<const f32x4 *>(a.wfrag) + lane;
     // two k-groups per iteration: all loads of both groups are issued before the first MFMA
     int kg = wave;

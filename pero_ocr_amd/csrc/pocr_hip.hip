@@ -631,6 +631,18 @@ int launch_skinny(SkinnyArgs a, hipStream_t st) {
 }
 
 
+// skinny GEMM whose input is LayerNorm(ln_a + ln_b): E = 256 or 512 have fused instances
+template <bool RELU, int LNE>
+int launch_skinny_ln(SkinnyArgs a, hipStream_t st) {
+    const int c16 = a.cout16;
+    const int rows = (a.M + 15) / 16;
+    if (c16 % 4 == 0 && rows * (c16 / 4) >= 256) hipLaunchKernelGGL((skinny_gemm_kernel<1, 4, RELU, LNE>), dim3(c16 / 4, rows), dim3(256), 0, st, a);
+    else if (c16 % 2 == 0 && rows * (c16 / 2) >= 256) hipLaunchKernelGGL((skinny_gemm_kernel<1, 2, RELU, LNE>), dim3(c16 / 2, rows), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<1, 1, RELU, LNE>), dim3(c16, rows), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int check_slot(pocr_engine *e, int32_t slot) {
     if (!e) return fail("engine is NULL");
     if (slot < 0 || slot >= POCR_NUM_SLOTS) return fail("slot %d out of range (0..%d)", slot, POCR_NUM_SLOTS - 1);
@@ -1270,7 +1282,7 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
         else if (D == 64) hipLaunchKernelGGL(dec_attention_kernel<64>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(dec_attention_kernel<128>, grid, dim3(256), 0, st, a);
     };
-    const float scale_unused = 0.f; (void)scale_unused;
+    const bool fuse_ln = (E == 512 || E == 256) && getenv("POCR_S2S_NO_LN_FUSION") == nullptr;
     int blocks = 0;
     bool finished = false;
     for (int step = 0; step < S_cap && !finished; ++step) {
@@ -1281,11 +1293,29 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
         }
         float *x = s.s2s_x.as<float>(), *x1 = s.s2s_x1.as<float>(), *x2 = s.s2s_x2.as<float>(), *t = s.s2s_t.as<float>();
         float *ctx = s.s2s_ctx.as<float>(), *q = s.s2s_q.as<float>(), *ff = s.s2s_ff.as<float>();
+        // LN(x_in + t) feeding a GEMM: fused into the GEMM's prologue when an instance exists, else LayerNorm kernel + GEMM
+        auto ln_gemm = [&](const float *res, const DevBuf &gw, const DevBuf &gb, float *normed, const DevBuf &w_, const DevBuf &b_,
+                           int cout_, float *y_, int64_t ldy, bool relu) -> int {
+            if (fuse_ln) {
+                SkinnyArgs a{};
+                a.x = normed; a.wfrag = w_.as<float>(); a.bias = b_.as<float>(); a.y = y_; a.ldx = E; a.ldy = ldy;
+                a.M = n; a.K = E; a.cout16 = round_up(cout_, kSkinnyNT) / 16; a.cout_valid = cout_; a.stop = d_remaining;
+                a.ln_a = res; a.ln_b = t; a.gamma = gw.as<float>(); a.beta = gb.as<float>(); a.ln_out = normed; a.eps = 1e-5f;
+                if (E == 512) return relu ? launch_skinny_ln<true, 512>(a, st) : launch_skinny_ln<false, 512>(a, st);
+                return relu ? launch_skinny_ln<true, 256>(a, st) : launch_skinny_ln<false, 256>(a, st);
+            }
+            ln(res, t, gw, gb, normed);
+            return gemm(normed, E, w_, b_, cout_, E, y_, ldy, relu);
+        };
         for (int l = 0; l < L; ++l) {
             pocr_engine::DecLayer &W = e->dec[l];
             float *cache = s.s2s_cache[l].as<float>();
             float *row = cache + (size_t)step * n * 3 * E;          // linear_cache[seq_len - 1] (transformer.py:250)
-            if (gemm(x, E, W.ws_in, W.bs_in, 3 * E, E, row, 3 * E, false)) return 1;
+            if (l == 0) {
+                if (gemm(x, E, W.ws_in, W.bs_in, 3 * E, E, row, 3 * E, false)) return 1;
+            } else {                                                 // x = norm3 of the layer below (x2 + t)
+                if (ln_gemm(x2, e->dec[l - 1].n3w, e->dec[l - 1].n3b, x, W.ws_in, W.bs_in, 3 * E, row, 3 * E, false)) return 1;
+            }
             {
                 DecAttnArgs a{};
                 a.q = row; a.ldq = 3 * E; a.k = cache + E; a.v = cache + 2 * E;
@@ -1293,8 +1323,7 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
                 attend(a);
             }
             if (gemm(ctx, E, W.ws_out, W.bs_out, E, E, t, E, false)) return 1;
-            ln(x, t, W.n1w, W.n1b, x1);
-            if (gemm(x1, E, W.wc_q, W.bc_q, E, E, q, E, false)) return 1;
+            if (ln_gemm(x, W.n1w, W.n1b, x1, W.wc_q, W.bc_q, E, q, E, false)) return 1;          // x1 = norm1(x + t); q = x1 Wq
             {
                 DecAttnArgs a{};
                 a.q = q; a.ldq = E; a.k = s.s2s_kv[l].as<float>(); a.v = s.s2s_kv[l].as<float>() + E;
@@ -1302,13 +1331,12 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
                 attend(a);
             }
             if (gemm(ctx, E, W.wc_out, W.bc_out, E, E, t, E, false)) return 1;
-            ln(x1, t, W.n2w, W.n2b, x2);
-            if (gemm(x2, E, W.w1, W.b1, FF, E, ff, FF, true)) return 1;
+            if (ln_gemm(x1, W.n2w, W.n2b, x2, W.w1, W.b1, FF, ff, FF, true)) return 1;          // x2 = norm2(x1 + t); ff = relu(x2 W1)
             if (gemm(ff, FF, W.w2, W.b2, E, FF, t, E, false)) return 1;
-            ln(x2, t, W.n3w, W.n3b, x);
         }
         float *lg = s.s2s_logits.as<float>() + (size_t)step * C;
-        if (gemm(s.s2s_x.as<float>(), E, e->head_w, e->head_b, C, E, lg, (int64_t)S_cap * C, false)) return 1;
+        // x = norm3(x2 + t) of the last layer; logits = x W_out
+        if (ln_gemm(x2, e->dec[L - 1].n3w, e->dec[L - 1].n3b, x, e->head_w, e->head_b, C, lg, (int64_t)S_cap * C, false)) return 1;
         hipLaunchKernelGGL(s2s_sample_kernel, dim3(nb), dim3(256), 0, st, stt, (const float *)lg, (int64_t)S_cap * C, step);
         HIP_TRY(hipGetLastError());
         if (step % BLK == BLK - 1) {

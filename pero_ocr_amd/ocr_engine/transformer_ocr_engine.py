@@ -192,9 +192,6 @@ class TransformerEngineLineOCR(BaseEngineLineOCR):
     # ---- public API --------------------------------------------------------------------------------------
     def process_lines(self, lines, sparse_logits=True, tight_crop_logits=False, no_logits=False):
         n = len(lines)
-        transcriptions: List[Optional[str]] = [None] * n
-        logits_out: List[object] = [None] * n
-        coords_out: List[Optional[list]] = [None] * n
         for i, line in enumerate(lines):
             if line.ndim != 3 or line.shape[0] != self.line_px_height or line.shape[2] != 3:
                 raise ValueError(f"line {i}: expected a [{self.line_px_height}, w, 3] crop, got {line.shape}")
@@ -208,7 +205,15 @@ class TransformerEngineLineOCR(BaseEngineLineOCR):
             if b.max_width + 2 * pad > b.w_batch:
                 print(f"WARNING: Line too long for OCR engine. Cropping from {b.max_width + 2 * pad} px "
                       f"down to {b.w_batch}.")
+        transcriptions: List[Optional[str]] = [None] * n
+        logits_out: List[object] = [None] * n
+        coords_out: List[Optional[list]] = [None] * n
+        self.recognise_batches(lines, batches, transcriptions, logits_out, coords_out, sparse_logits, no_logits)
+        return transcriptions, logits_out, coords_out
 
+    def recognise_batches(self, lines, batches, transcriptions, logits_out, coords_out, sparse_logits=True, no_logits=False):
+        """Runs the given reference batches (all of a page, or one rank's share: sharding.ShardedSeq2SeqOCR) and
+        fills the three output lists at the positions of their lines."""
         def submit(slot, group):
             images, w_pads, lefts, first = [], [], [], [0]
             for b in group:
@@ -246,4 +251,3 @@ class TransformerEngineLineOCR(BaseEngineLineOCR):
             pending = (k % 2, group, first)
         if pending is not None:
             finish(*pending)
-        return transcriptions, logits_out, coords_out

@@ -23,8 +23,12 @@ def assign_chunks(chunks: Sequence[Chunk], world_size: int) -> List[List[int]]:
     """Longest-processing-time-first on cost = lines * padded width (conv work is linear in
     both).  Returns, per rank, the indices of its chunks (ascending).  Deterministic: every
     rank computes the same assignment from the same widths."""
-    cost = [len(c.line_ids) * c.w_pad for c in chunks]
-    order = sorted(range(len(chunks)), key=lambda i: (-cost[i], i))
+    return assign_by_cost([len(c.line_ids) * c.w_pad for c in chunks], world_size)
+
+
+def assign_by_cost(cost: Sequence[int], world_size: int) -> List[List[int]]:
+    """LPT: heaviest unit first, each to the currently least loaded rank (ties: lower rank)."""
+    order = sorted(range(len(cost)), key=lambda i: (-cost[i], i))
     load = [0] * world_size
     mine: List[List[int]] = [[] for _ in range(world_size)]
     for i in order:
@@ -149,4 +153,52 @@ def engine_recogniser(engine) -> Callable:
         return [out[id(ch)] for ch in chunks]
 
     recognise.many = many
+    return recognise
+
+
+class ShardedSeq2SeqOCR:
+    """The same scheme for the transformer (sequence-to-sequence) engine: the unit is the reference batch of
+    process_lines' "transformer" branch (line_ocr_engine.py:79-119) - a line's result depends on its batch's
+    padded width and the decoding loop runs per batch, so whole batches are dealt to ranks (cost = parts x
+    padded width).  Transcriptions are exchanged as code points with the all-gather above.
+
+    `recognise(lines, batches) -> {line id: transcription}` runs one rank's batches
+    (TransformerEngineLineOCR via `seq2seq_recogniser`; a stand-in in the gloo CPU tests)."""
+
+    def __init__(self, recognise: Callable, max_input_horizontal_pixels: int, max_line_width, line_padding_px: int = 32,
+                 gather_device=None):
+        self.recognise = recognise
+        self.max_input_horizontal_pixels = max_input_horizontal_pixels
+        self.max_line_width = max_line_width
+        self.line_padding_px = line_padding_px
+        self.gather_device = gather_device
+
+    def process_lines(self, lines) -> List[str]:
+        from .ocr_engine.transformer_ocr_engine import plan_batches
+        dist = _dist()
+        rank, world = dist.get_rank(), dist.get_world_size()
+        batches = plan_batches([l.shape[1] for l in lines], self.max_input_horizontal_pixels, self.max_line_width,
+                               self.line_padding_px)
+        mine = assign_by_cost([len(b.parts) * b.w_pad for b in batches], world)[rank]
+        texts = self.recognise(lines, [batches[i] for i in mine]) if mine else {}
+        ids = sorted(texts)
+        t_max = max([len(texts[i]) for i in ids], default=0)
+        lab = np.full((len(ids), t_max), -1, dtype=np.int32)
+        for k, i in enumerate(ids):
+            lab[k, :len(texts[i])] = [ord(ch) for ch in texts[i]]
+        lens = np.array([len(texts[i]) for i in ids], dtype=np.int32)
+        gl, gn, gi = allgather_labels(lab, lens, np.array(ids, dtype=np.int32), self.gather_device)
+        out: List[Optional[str]] = [None] * len(lines)
+        for row, ln, i in zip(gl, gn, gi):
+            out[int(i)] = "".join(chr(int(c)) for c in row[:ln])
+        return out
+
+
+def seq2seq_recogniser(engine) -> Callable:
+    """Adapter: TransformerEngineLineOCR -> the `recognise` callable (transcriptions only)."""
+    def recognise(lines, batches):
+        n = len(lines)
+        texts, lg, co = [None] * n, [None] * n, [None] * n
+        engine.recognise_batches(lines, batches, texts, lg, co, sparse_logits=False, no_logits=True)
+        return {i: texts[i] for b in batches for i in b.line_ids}
     return recognise

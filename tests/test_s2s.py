@@ -215,3 +215,31 @@ def test_gpu_s2s_run_ocr_seam_and_launch_independence(golden, tmp_path):
     assert merged[0] == single[0] and merged[2] == single[2]
     for a, b in zip(merged[1], single[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_gpu_s2s_shard_adapter_and_degenerate_inputs(golden, tmp_path):
+    g = golden("s2s_ragged")
+    eng = make_engine(g, tmp_path)
+    crops = g.crops()
+    from pero_ocr_amd import sharding
+    rec = sharding.seq2seq_recogniser(eng)
+    batches = tengine.plan_batches(g.widths, eng.max_input_horizontal_pixels, eng.max_line_width)
+    mine = sharding.assign_by_cost([len(b.parts) * b.w_pad for b in batches], 2)
+    got = {}
+    for share in mine:                                    # the two ranks' shares, run one after the other
+        got.update(rec(crops, [batches[i] for i in share]))
+    assert [got[i] for i in range(g.n)] == g.transcriptions
+    # degenerate inputs
+    assert eng.process_lines([]) == ([], [], [])
+    with pytest.raises(ValueError):
+        eng.process_lines([np.zeros((g.height + 1, 20, 3), np.uint8)])
+    with pytest.raises(ZeroDivisionError):               # the reference divides by ceil32(0) (line_ocr_engine.py:87)
+        eng.process_lines([np.zeros((g.height, 0, 3), np.uint8)])
+    # a failed crop (float64 zeros, page_parser.py:390-391) behaves like its uint8 cast
+    a = eng.process_lines([np.zeros((g.height, g.height, 3))], sparse_logits=False)
+    b = eng.process_lines([np.zeros((g.height, g.height, 3), np.uint8)], sparse_logits=False)
+    assert a[0] == b[0] and np.array_equal(a[1][0], b[1][0])
+    # the CTC entry points refuse a sequence-to-sequence engine
+    with pytest.raises(RuntimeError):
+        eng.net.run_batch(np.zeros((1, g.height, 64, 3), np.uint8))

@@ -39,6 +39,16 @@ def _fake_recognise(lines, chunk):
     return labs, lens
 
 
+def _fake_s2s(lines, batches):
+    """Stand-in for the GPU call of the seq2seq engine: text = f(crop bytes, batch geometry, number of parts)."""
+    out = {}
+    for b in batches:
+        for i, span in zip(b.line_ids, b.spans):
+            k = int(lines[i][3, :, 1].sum()) % 23
+            out[i] = "".join(chr(0x61 + (k + j) % 26) for j in range(k)) + f"|{b.w_pad}|{span}|\u017e"
+    return out
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, REPO)
     import torch.distributed as dist
@@ -52,7 +62,10 @@ def _worker(rank, world, port, out_dir):
         texts = eng.process_lines(lines)
         # a rank with no chunks at all (more ranks than chunks) must still take part
         few = sharding.ShardedLineOCR(_fake_recognise, chars, 480 * 64).process_lines(lines[:3])
+        # sequence-to-sequence engine: whole reference batches per rank, transcriptions gathered as code points
+        s2s = sharding.ShardedSeq2SeqOCR(_fake_s2s, 480 * 4, 1024).process_lines(lines)
         np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array(texts + few, dtype=object), allow_pickle=True)
+        np.save(os.path.join(out_dir, f"s{rank}.npy"), np.array(s2s, dtype=object), allow_pickle=True)
     finally:
         dist.destroy_process_group()
 
@@ -78,3 +91,9 @@ def test_gloo_world2_allgather_labels(tmp_path):
         for k, i in enumerate(ch.line_ids):
             expect[i] = "".join(chars[c] for c in labs[k, :lens[k]])
     assert r0[:len(lines)] == expect
+    # seq2seq sharding: both ranks hold every transcription, equal to the single-process result
+    from pero_ocr_amd.ocr_engine.transformer_ocr_engine import plan_batches
+    s0 = np.load(tmp_path / "s0.npy", allow_pickle=True).tolist()
+    s1 = np.load(tmp_path / "s1.npy", allow_pickle=True).tolist()
+    single = _fake_s2s(lines, plan_batches(widths, 480 * 4, 1024))
+    assert s0 == s1 == [single[i] for i in range(len(lines))]
