@@ -23,10 +23,12 @@ class PageOCR:
         use_cpu = str(config.get("USE_CPU", "no")).lower() in ("1", "yes", "true", "on")
         if use_cpu:
             raise RuntimeError("USE_CPU is set: pero_ocr_amd has no CPU path")
-        if config.get("METHOD", "") == "pytorch_ocr-transformer":
-            raise NotImplementedError("the seq2seq transformer engine is not part of this build (SURVEY.md 8f-3)")
         self.device = device
-        self.ocr_engine = PytorchEngineLineOCR(json_file, self.device)
+        if config.get("METHOD", "") == "pytorch_ocr-transformer":          # page_parser.py:413-414
+            from ..ocr_engine.transformer_ocr_engine import TransformerEngineLineOCR
+            self.ocr_engine = TransformerEngineLineOCR(json_file, self.device)
+        else:
+            self.ocr_engine = PytorchEngineLineOCR(json_file, self.device)
 
     def process_page(self, img, page_layout):
         lines = list(page_layout.lines_iterator())

@@ -4,6 +4,9 @@
 Bars (BASELINE.json north_star): decoded strings and per-frame argmax identical to the
 reference PyTorch-CPU path, logits within 1e-3 (fp32).
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -567,3 +570,50 @@ def test_degenerate_inputs(golden, tmp_path):
     assert t2 == t and np.array_equal(np.asarray(l2[0]), np.asarray(l[0]))
     with pytest.raises(ValueError):
         eng.process_lines([np.zeros((39, 10, 3), np.uint8)])
+
+
+@pytest.mark.gpu
+def test_page_ocr_caller_contract(golden, tmp_path):
+    """Row a-12: the PageOCR counterpart (pero_ocr/document_ocr/page_parser.py:406-434) - one process_lines call
+    per page, four fields written on every line, engine chosen by [OCR] METHOD."""
+    from pero_ocr_amd.document_ocr.page_ocr import PageOCR
+
+    class Line:
+        def __init__(self, i, crop):
+            self.id, self.crop = f"l{i}", crop
+            self.transcription = self.logits = self.characters = self.logit_coords = None
+
+    class Layout:
+        def __init__(self, crops):
+            self.lines = [Line(i, c) for i, c in enumerate(crops)]
+
+        def lines_iterator(self):
+            return iter(self.lines)
+
+    g = golden("c1")
+    ocr = PageOCR({"OCR_JSON": os.path.basename(g.write_engine_json(tmp_path))}, Dev(), config_path=str(tmp_path))
+    assert ocr.provides_ctc_logits
+    page = ocr.process_page(None, Layout(g.crops()))
+    assert [l.transcription for l in page.lines] == g.transcriptions
+    assert [l.logit_coords for l in page.lines] == g.logit_coords
+    assert all(l.characters == g.characters for l in page.lines)
+    assert all(abs(int(l.logits.nnz) - k) <= max(2, k // 200) for l, k in zip(page.lines, g.nnz_sparse))
+    broken = Layout(g.crops()[:2])
+    broken.lines[1].crop = None
+    with pytest.raises(Exception, match="Missing crop in line l1"):
+        ocr.process_page(None, broken)
+    with pytest.raises(RuntimeError):
+        PageOCR({"OCR_JSON": g.write_engine_json(tmp_path), "USE_CPU": "yes"}, Dev())
+    # METHOD = pytorch_ocr-transformer selects the sequence-to-sequence engine
+    s = golden("s2s_ragged")
+    cfg = {"line_px_height": s.height, "line_vertical_scale": 1.0, "checkpoint": "absent.pocrw",
+           "characters": s.characters[:-2], "net_name": s.net_name, "max_line_width": s.max_line_width,
+           "net": {"weight_seed": s.weight_seed, "boundary_bias": s.boundary_bias}}
+    path = os.path.join(str(tmp_path), "s2s.json")
+    with open(path, "w", encoding="utf8") as f:
+        json.dump(cfg, f)
+    ocr2 = PageOCR({"OCR_JSON": path, "METHOD": "pytorch_ocr-transformer"}, Dev())
+    assert not ocr2.provides_ctc_logits
+    page2 = ocr2.process_page(None, Layout(s.crops()))
+    assert [l.transcription for l in page2.lines] == s.transcriptions
+    assert [l.logit_coords for l in page2.lines] == s.logit_coords
