@@ -167,6 +167,13 @@ int pocr_s2s_stage(pocr_engine *e, int32_t slot, const uint8_t *crops, const int
 int pocr_s2s_launch(pocr_engine *e, int32_t slot, const int32_t *batch_first, int32_t n_batches);
 int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *steps, int32_t *s_max);
 int pocr_s2s_collect(pocr_engine *e, int32_t slot, int32_t *tokens, float *logits);
+/* Sparse decoder logits: the softmax / p < threshold -> 0 / csc_matrix step of line_ocr_engine.py:168-171 on the
+ * device, after pocr_s2s_decode (the logits stay resident; they need not have been requested).  Line i keeps its
+ * rows [0, row_end[i]) - the reference cuts a line's logits to len(transcription) rows before sparsifying
+ * (:183, :134-142) - so the caller first derives the lengths from the tokens.  Outputs as for
+ * pocr_slot_collect_sparse: line_off [n+1], indptr [n][C+1], data / indices [total_nnz]. */
+int pocr_s2s_sparse(pocr_engine *e, int32_t slot, const int32_t *row_end, float threshold, int64_t *total_nnz);
+int pocr_s2s_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t *indices, int32_t *indptr, int64_t *line_off);
 
 /* ---- measurement / test taps (not part of the reference surface) ----
  * Per-stage GPU time of the last pocr_run_* call in milliseconds, measured with HIP

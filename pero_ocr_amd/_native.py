@@ -62,6 +62,8 @@ SYMBOLS = {
     "pocr_s2s_launch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_int32]),
     "pocr_s2s_decode": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i32p]),
     "pocr_s2s_collect": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _f32p]),
+    "pocr_s2s_sparse": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_float, C.POINTER(C.c_int64)]),
+    "pocr_s2s_collect_sparse": (C.c_int, [C.c_void_p, C.c_int32, _f32p, _i32p, _i32p, _i64p]),
     "pocr_last_stage_ms": (C.c_int, [C.c_void_p, _f32p, C.c_int32]),
     "pocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "pocr_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -287,6 +289,23 @@ class NativeEngine:
         if self._lib.pocr_s2s_collect(self._h, int(slot), _ptr(tokens, _i32p), _ptr(logits, _f32p)):
             raise RuntimeError("pocr_s2s_collect: " + self._err())
         return steps, tokens, logits
+
+    def s2s_sparse(self, slot: int, row_end, threshold: float = 1e-4):
+        """CSC triplets of the resident decoder logits, rows [0, row_end[i]) of device line i.
+        -> (data [nnz], indices [nnz], indptr [n, C+1], line_off [n+1])"""
+        n = self._s2s_n[slot]
+        re_ = np.ascontiguousarray(row_end, dtype=np.int32)
+        total = C.c_int64(0)
+        if self._lib.pocr_s2s_sparse(self._h, int(slot), _ptr(re_, _i32p), float(threshold), C.byref(total)):
+            raise RuntimeError("pocr_s2s_sparse: " + self._err())
+        data = np.empty(max(1, total.value), dtype=np.float32)
+        indices = np.empty(max(1, total.value), dtype=np.int32)
+        indptr = np.empty((n, self.spec.num_classes + 1), dtype=np.int32)
+        line_off = np.empty(n + 1, dtype=np.int64)
+        if self._lib.pocr_s2s_collect_sparse(self._h, int(slot), _ptr(data, _f32p), _ptr(indices, _i32p), _ptr(indptr, _i32p),
+                                             _ptr(line_off, _i64p)):
+            raise RuntimeError("pocr_s2s_collect_sparse: " + self._err())
+        return data[:total.value], indices[:total.value], indptr, line_off
 
     def slot_stage_ms(self, slot: int) -> dict:
         buf = np.zeros(len(STAGE_NAMES), dtype=np.float32)

@@ -1393,6 +1393,83 @@ int pocr_s2s_collect(pocr_engine *e, int32_t slot, int32_t *tokens, float *logit
     return 0;
 }
 
+
+int pocr_s2s_sparse(pocr_engine *e, int32_t slot, const int32_t *row_end, float threshold, int64_t *total_nnz) {
+    if (check_slot(e, slot)) return 1;
+    Slot &s = e->slot[slot];
+    if (!s.s2s_decoded) return fail("slot %d: pocr_s2s_decode first", slot);
+    if (!row_end || !total_nnz) return fail("NULL pointer");
+    HIP_TRY(hipSetDevice(e->device));
+    const int n = s.n, S_cap = s.s2s_cap, C = e->cfg.num_classes;
+    if (S_cap > SP_MAXT) return fail("sparse logits: %d steps exceed %d", S_cap, SP_MAXT);
+    if (C > 256 * SP_COLS) return fail("sparse logits: C = %d exceeds %d classes", C, 256 * SP_COLS);
+    size_t cap = 0;
+    for (int i = 0; i < n; ++i) {
+        if (row_end[i] < 0 || row_end[i] > S_cap) return fail("line %d: row_end %d outside [0, %d]", i, row_end[i], S_cap);
+        cap += (size_t)row_end[i] * C;
+    }
+    hipStream_t st = s.seq_stream;
+    if (s.sp_rowstat.reserve((size_t)n * S_cap * 2 * sizeof(float)) || s.sp_colcount.reserve((size_t)n * C * sizeof(int32_t)) ||
+        s.sp_line_nnz.reserve((size_t)n * sizeof(int32_t)) || s.sp_line_off.reserve((size_t)(n + 1) * sizeof(int64_t)) ||
+        s.sp_indptr.reserve((size_t)n * (C + 1) * sizeof(int32_t)) || s.sp_data.reserve(std::max<size_t>(cap, 1) * sizeof(float)) ||
+        s.sp_indices.reserve(std::max<size_t>(cap, 1) * sizeof(int32_t)) || s.sp_rows.reserve((size_t)n * sizeof(int32_t)))
+        return 1;
+    const size_t off_bytes = (size_t)(n + 1) * sizeof(int64_t), ip_bytes = (size_t)n * (C + 1) * sizeof(int32_t);
+    const size_t need_sp = off_bytes + ip_bytes + (size_t)n * sizeof(int32_t) + cap * 8;
+    if (need_sp > s.sp_pinned_cap) {
+        if (s.sp_pinned) (void)hipHostFree(s.sp_pinned);
+        s.sp_pinned = nullptr; s.sp_pinned_cap = 0;
+        HIP_TRY(hipHostMalloc(&s.sp_pinned, need_sp + need_sp / 4, hipHostMallocDefault));
+        s.sp_pinned_cap = need_sp + need_sp / 4;
+    }
+    char *sp = static_cast<char *>(s.sp_pinned);
+    int32_t *h_rows = reinterpret_cast<int32_t *>(sp + off_bytes + ip_bytes);
+    memcpy(h_rows, row_end, (size_t)n * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(s.sp_rows.p, h_rows, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    const int32_t *r1 = s.sp_rows.as<int32_t>();
+    // decoder logits: line i owns rows [i * S_cap, (i + 1) * S_cap); rows [0, row_end[i]) are compacted
+    hipLaunchKernelGGL(sparse_count_kernel, dim3(n), dim3(256), 0, st, s.s2s_logits.as<float>(), (const int32_t *)nullptr, r1,
+                       s.sp_rowstat.as<float>(), s.sp_colcount.as<int32_t>(), s.sp_line_nnz.as<int32_t>(), S_cap, C, threshold,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr);
+    hipLaunchKernelGGL(sparse_scan_kernel, dim3(1), dim3(64), 0, st, s.sp_line_nnz.as<int32_t>(), s.sp_line_off.as<int64_t>(), n);
+    hipLaunchKernelGGL(sparse_fill_kernel, dim3(n), dim3(256), 0, st, s.s2s_logits.as<float>(), (const int32_t *)nullptr, r1,
+                       s.sp_rowstat.as<float>(), s.sp_colcount.as<int32_t>(), s.sp_line_off.as<int64_t>(), s.sp_indptr.as<int32_t>(),
+                       s.sp_data.as<float>(), s.sp_indices.as<int32_t>(), S_cap, C, threshold, (int64_t)std::max<size_t>(cap, 1),
+                       (const int32_t *)nullptr, (const int32_t *)nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(sp, s.sp_line_off.p, off_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(sp + off_bytes, s.sp_indptr.p, ip_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int64_t total = reinterpret_cast<const int64_t *>(sp)[n];
+    char *trip = sp + off_bytes + ip_bytes + (size_t)n * sizeof(int32_t);
+    if (total > 0) {
+        HIP_TRY(hipMemcpyAsync(trip, s.sp_data.p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(trip + (size_t)total * sizeof(float), s.sp_indices.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    *total_nnz = total;
+    return 0;
+}
+
+int pocr_s2s_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t *indices, int32_t *indptr, int64_t *line_off) {
+    if (check_slot(e, slot)) return 1;
+    Slot &s = e->slot[slot];
+    if (!s.s2s_decoded || !s.sp_pinned) return fail("slot %d: pocr_s2s_sparse first", slot);
+    if (!data || !indices || !indptr || !line_off) return fail("NULL output pointer");
+    const int n = s.n, C = e->cfg.num_classes;
+    const size_t off_bytes = (size_t)(n + 1) * sizeof(int64_t), ip_bytes = (size_t)n * (C + 1) * sizeof(int32_t);
+    const char *sp = static_cast<const char *>(s.sp_pinned);
+    const int64_t total = reinterpret_cast<const int64_t *>(sp)[n];
+    memcpy(line_off, sp, off_bytes);
+    memcpy(indptr, sp + off_bytes, ip_bytes);
+    const char *trip = sp + off_bytes + ip_bytes + (size_t)n * sizeof(int32_t);
+    if (total > 0) {
+        memcpy(data, trip, (size_t)total * sizeof(float));
+        memcpy(indices, trip + (size_t)total * sizeof(float), (size_t)total * sizeof(int32_t));
+    }
+    return 0;
+}
+
 int pocr_stage_lines(pocr_engine *e, const uint8_t *crops, const int64_t *crop_offsets, const int32_t *widths,
                      int32_t n, int32_t w_pad, int32_t pad_left) {
     if (pocr_slot_stage_lines(e, 0, crops, crop_offsets, widths, n, w_pad, pad_left)) return 1;

@@ -255,12 +255,20 @@ def merge_transcriptions_and_logits(transcription_parts, logits_parts):
     the length of its transcription; at each seam half of the best overlap is dropped on either side.
     The reference writes the left cut as `[:-overlap // 2]`, i.e. [: (-overlap) // 2]: the ceiling half,
     and an EMPTY left side when no overlap was found (overlap 0) - kept as is."""
+    def stack(a, b):
+        if sparse.issparse(a) or sparse.issparse(b):          # parts already sparsified on the GPU (row-wise operation)
+            return sparse.vstack([a, b], format="csc")
+        return np.concatenate([a, b], axis=0)
+
+    def head(m, k):
+        return m if m.shape[0] == k else m[:k]
+
     text = transcription_parts[0]
-    logits = logits_parts[0][:len(text)]
+    logits = head(logits_parts[0], len(text))
     for nxt, nxt_logits in zip(transcription_parts[1:], logits_parts[1:]):
-        nxt_logits = nxt_logits[:len(nxt)]
+        nxt_logits = head(nxt_logits, len(nxt))
         overlap = find_best_overlap(text, nxt)
         left_end = (-overlap) // 2
         text = text[:left_end] + nxt[overlap // 2:]
-        logits = np.concatenate([logits[:left_end], nxt_logits[overlap // 2:]], axis=0)
+        logits = stack(logits[:left_end], nxt_logits[overlap // 2:])
     return text, logits

@@ -135,6 +135,8 @@ class TransformerEngineLineOCR(BaseEngineLineOCR):
         self.net_spec = spec
         self.net = _native.NativeEngine(spec, netspec.pack_weights(spec, weights), _device_index(self.device))
 
+    supports_device_sparsify = True
+
     # ---- label post-processing (transformer_ocr_engine.py:91-111) ---------------------------------------
     def postprocess_decoded(self, transcripts, ignore_ind, sentence_boundary_ind) -> List[np.ndarray]:
         out = []
@@ -159,15 +161,25 @@ class TransformerEngineLineOCR(BaseEngineLineOCR):
         self.net.s2s_stage(slot, pool, offsets, widths, w_pads, pad_lefts)
         self.net.s2s_launch(slot, batch_first)
 
-    def _finish(self, slot: int, batch_first, want_logits: bool):
-        """-> per batch: (label arrays per device line, logits [lines, steps_b, C] | None)"""
-        steps, tokens, logits = self.net.s2s_decode(slot, want_logits=want_logits)
-        out = []
+    def _finish(self, slot: int, batch_first, want_logits: bool, device_sparse: bool = False):
+        """-> per batch: (label arrays per device line, logits).  logits: [lines, steps_b, C] array, None, or
+        (device_sparse) a list of csc_matrix [len(transcription_i), C] built on the GPU (pocr_s2s_sparse)."""
+        steps, tokens, logits = self.net.s2s_decode(slot, want_logits=want_logits and not device_sparse)
+        out, all_labels = [], []
         for b in range(len(batch_first) - 1):
             lo, hi, sb = int(batch_first[b]), int(batch_first[b + 1]), int(steps[b])
             kept = tokens[lo:hi, :max(sb - 1, 0)]         # partial_transcripts[1:] (:82-84): the last sample is never appended
             labels = self.postprocess_decoded(kept, self.ignore_ind, self.sentence_boundary_ind)
+            all_labels += labels
             out.append((labels, logits[lo:hi, :sb] if logits is not None else None))
+        if device_sparse and want_logits:
+            # rows kept per line = len(transcription) (merge_transcriptions_and_logits cuts the logits there, :183)
+            rows = [len("".join(self.characters[int(c)] for c in lab)) for lab in all_labels]
+            data, indices, indptr, line_off = self.net.s2s_sparse(slot, rows, SPARSE_PROB_THRESHOLD)
+            C_ = indptr.shape[1] - 1
+            mats = [sparse.csc_matrix((data[int(line_off[i]):int(line_off[i + 1])], indices[int(line_off[i]):int(line_off[i + 1])],
+                                       indptr[i]), shape=(rows[i], C_)) for i in range(len(rows))]
+            out = [(labels, mats[int(batch_first[b]):int(batch_first[b + 1])]) for b, (labels, _l) in enumerate(out)]
         return out
 
     def transcribe_batch(self, inputs, is_cached=True):
@@ -225,19 +237,22 @@ class TransformerEngineLineOCR(BaseEngineLineOCR):
             self._submit(slot, images, w_pads, lefts, first)
             return first
 
+        device_sparse = sparse_logits and not no_logits and self.supports_device_sparsify
+
         def finish(slot, group, first):
-            for b, (labels, logits) in zip(group, self._finish(slot, first, not no_logits)):
+            for b, (labels, logits) in zip(group, self._finish(slot, first, not no_logits, device_sparse)):
                 texts = self.decode(labels)
                 k = 0
                 for i, span in zip(b.line_ids, b.spans):
                     part_logits = logits[k:k + span] if logits is not None else [np.zeros((len(t), 0), np.float32) for t in texts[k:k + span]]
+                    # (sparsification is row-wise, so CSC parts built on the GPU merge to the same matrix)
                     text, merged = merge_transcriptions_and_logits(texts[k:k + span], part_logits)
                     k += span
                     transcriptions[i] = text
                     if no_logits:
                         continue
                     coords_out[i] = [0, len(text)]
-                    if sparse_logits:
+                    if sparse_logits and not device_sparse:
                         merged = sparse.csc_matrix(np.where(softmax(merged, axis=1) < SPARSE_PROB_THRESHOLD, np.float32(0), merged))
                     logits_out[i] = merged
 

@@ -180,7 +180,12 @@ def test_gpu_s2s_golden(golden, tmp_path, name):
     print(f"[{name}] max |dlogit| vs reference rows = {worst:.2e}")
     t2, l2, c2 = eng.process_lines(crops)
     assert t2 == texts and c2 == coords
-    assert [int(m.nnz) for m in l2] == g.nnz_sparse
+    for i in range(g.n):                                   # CSC built on the GPU == sparsified dense logits
+        assert l2[i].format == "csc" and l2[i].dtype == np.float32 and l2[i].shape == np.asarray(logits[i]).shape
+        assert abs(int(l2[i].nnz) - g.nnz_sparse[i]) <= max(2, g.nnz_sparse[i] // 200)
+        d = np.asarray(l2[i].todense())
+        keep = d != 0
+        assert np.array_equal(d[keep], np.asarray(logits[i])[keep])
     t3, l3, c3 = eng.process_lines(crops, no_logits=True)
     assert t3 == texts and all(x is None for x in l3) and all(x is None for x in c3)
     with pytest.raises(AttributeError):
