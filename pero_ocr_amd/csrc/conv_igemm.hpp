@@ -34,9 +34,13 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
 enum { STAGE_F32_NHWC = 0 };      // the u8 line stager of the first layer lives in conv1_u8.hpp
 // main-loop variants (template parameter PIPE).  ABL3 is an ablation mask used only by tools/conv_bench.hip
 // (1 no global loads, 2 no LDS writes, 4 no ds_reads, 8 no barrier, 16 loads waited for at the step end).
-enum { PIPE_PLAIN = 0, PIPE_INTERLEAVED = 3, PIPE_DEEP = 4, PIPE_GLDS = 5 };
+enum { PIPE_PLAIN = 0, PIPE_INTERLEAVED = 3, PIPE_DEEP = 4, PIPE_GLDS = 5, PIPE_BREG = 6 };
 // PIPE_GLDS = PIPE_INTERLEAVED with the weight tile copied HBM/L2 -> LDS by the load unit itself
 // (global_load_lds_dwordx4: no staging VGPRs, no ds_write; the tile is already lane-linear).
+// PIPE_BREG: the weights never touch LDS.  In fragment order a wave's B operands of one step are NS 16-byte
+// loads per lane of data no other wave needs, so they go straight from L2 into registers, requested two
+// steps ahead (three register sets, statically rotated: needs KH*KW % 3 == 0).  Only the input halo tile
+// is shared through LDS, which leaves ONE barrier per 16-channel chunk instead of one per tap.
 
 struct LineDesc {            // one text line of a staged chunk (read by conv1_u8_kernel)
     int64_t offset;          // byte offset of the crop [H, width, 3] inside the crop pool
@@ -281,6 +285,84 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a
         __syncthreads();
         if (newA) abuf ^= 1;
         tap = ntap; chunk = nchunk;
+    }
+    } else if constexpr (PIPE == PIPE_BREG) {
+    // ------------------------------------------------------------------ weights in registers, one barrier per chunk
+    static_assert(KG == 1, "written for KC == 16");
+    static_assert(NTAPS % 3 == 0, "three weight register sets rotate statically over the unrolled taps");
+    constexpr int NMFMA = 4 * MS * NS;
+    constexpr int NSLOT = (NMFMA % 16 == 0 && NS + A_LD <= 8) ? 16 : (NMFMA % 12 == 0 && NS + A_LD <= 6) ? 12
+                        : (NMFMA % 10 == 0 && NS + A_LD <= 5) ? 10 : 8;
+    constexpr int STRIDE = NMFMA / NSLOT;
+    static_assert(NMFMA % NSLOT == 0 && NS + A_LD <= NSLOT / 2 && A_LD <= NSLOT / 2, "slot plan does not fit");
+    unsigned a_off[A_LD];
+    bool a_ok[A_LD];
+    int a_lds[A_LD];
+#pragma unroll
+    for (int r = 0; r < A_LD; ++r) {
+        const int e = tid + r * NTHR;
+        const int cq = e % CQ, p = e / CQ;
+        const int hr = p / HW, wc = p % HW;
+        const int hi = h0 - PADH + hr, wi = w0 - PADW + wc;
+        a_ok[r] = e < CQ * NP && hi >= 0 && hi < a.H && wi >= 0 && wi < Win;
+        a_off[r] = a_ok[r] ? (unsigned)((hi * Win + wi) * a.cin + cq * 4) : 0u;
+        a_lds[r] = e < CQ * NP ? cq * NPPAD + p : -1;
+    }
+    const float *ximg = a.x + img_base;
+    // this lane's column of fragments: tile(tap, chunk)[n * 64] is the B operand of fragment n
+    const f32x4 *wf4 = reinterpret_cast<const f32x4 *>(a.wfrag) + ((size_t)nt * (NT / 16) + wave * NS) * 64 + lane;
+    const size_t tap_stride = (size_t)(a.cin / 16) * a.cout16 * 64;
+    const size_t chunk_stride = (size_t)a.cout16 * 64;
+    auto ldA = [&](int r, int chunk_) {
+        ra[r] = a_ok[r] ? *reinterpret_cast<const f32x4 *>(ximg + chunk_ * KC + a_off[r]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto stA = [&](int r, int buf) { if (a_lds[r] >= 0) ldsA[buf * A_F4 + a_lds[r]] = ra[r]; };
+    f32x4 bq[3][NS];
+#pragma unroll
+    for (int r = 0; r < A_LD; ++r) ldA(r, 0);
+#pragma unroll
+    for (int n = 0; n < NS; ++n) bq[0][n] = wf4[n * 64];
+    if (nsteps > 1) {
+#pragma unroll
+        for (int n = 0; n < NS; ++n) bq[1][n] = (wf4 + tap_stride)[n * 64];
+    }
+#pragma unroll
+    for (int r = 0; r < A_LD; ++r) stA(r, 0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int abuf = chunk & 1;
+        const bool next_chunk = chunk + 1 < nchunks;
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            const bool last = tap == NTAPS - 1;
+            constexpr int dummy = 0; (void)dummy;
+            const int cur = tap % 3, fill = (tap + 2) % 3;
+            const int tap2 = (tap + 2) % NTAPS, adv2 = (tap + 2) / NTAPS;
+            const bool more2 = chunk + adv2 < nchunks;
+            const f32x4 *tile2 = wf4 + (size_t)tap2 * tap_stride + (size_t)(chunk + adv2) * chunk_stride;
+            const bool ldA_now = tap == 0 && next_chunk;
+            const bool stA_now = last && next_chunk;
+            const int dy = tap / KW, dx = tap % KW;
+            const f32x4 *Ab = ldsA + abuf * A_F4 + dy * HW + dx + li + kq * NPPAD;
+            f32x4 af[MS];
+#pragma unroll
+            for (int m = 0; m < MS; ++m) af[m] = Ab[(m / MW) * HW + (m % MW) * 16];
+#pragma unroll
+            for (int q = 0; q < NMFMA; ++q) {
+                const int j = q / (MS * NS), m = (q / NS) % MS, n = q % NS;
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bq[cur][n][j], acc[m][n], 0, 0, 0);
+                if ((q + 1) % STRIDE == 0) {
+                    const int slot = (q + 1) / STRIDE - 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (slot < NS) { if (more2) bq[fill][slot] = tile2[slot * 64]; }
+                    else if (slot < NS + A_LD) { if (ldA_now) ldA(slot - NS, chunk + 1); }
+                    const int sslot = slot - (NSLOT - A_LD);
+                    if (sslot >= 0) { if (stA_now) stA(sslot, abuf ^ 1); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (last) __syncthreads();      // the next halo tile is published; nobody reads this one any more
+        }
     }
     } else {
     static_assert(PIPE == PIPE_INTERLEAVED || PIPE == PIPE_DEEP || PIPE == PIPE_GLDS, "unknown pipeline id");

@@ -115,7 +115,7 @@ POCR_CONV(conv4_k,   3, 3, 1, 1, 4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, STAGE_F3
 POCR_CONV(conv56_k,  3, 3, 1, 1, 10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)  // ->256
 POCR_CONV(conv7_k,   3, 3, 1, 1, 10, 1, 2, 4, 16, 2, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)  // 256->256 + pool 2x1
 POCR_CONV(conv8_k,   3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)  // 256->512
-POCR_CONV(conv9_k,   3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // 512->512 + BN
+POCR_CONV(conv9_k,   3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, STAGE_F32_NHWC, PIPE_DEEP)          // 512->512 + BN; weight tile requested two steps ahead (+2 %)
 POCR_CONV(agg4_k,    4, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)
 POCR_CONV(agg5_k,    5, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)
 POCR_CONV(agg6_k,    6, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_PLAIN)

@@ -46,6 +46,7 @@ VARW(h20_w3,      4, 2, 1, 4, 1, 1, ACT_RELU, false, 3)
 #define P3 PIPE_INTERLEAVED
 #define P4 PIPE_DEEP
 #define P5 PIPE_GLDS
+#define P6 PIPE_BREG
 // conv8/9-shaped (H = 5)
 VARP(h5_plain,      5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P0, 0)
 VARP(h5_plain_kc32, 5, 1, 4, 4, 32, 1, 1, ACT_LEAKY, true, P0, 0)
@@ -58,6 +59,8 @@ VARP(h5_p4,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P4, 0)
 VARP(h5_p5,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P5, 0)
 VARP(h5_p5_nt128,   5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, P5, 0)
 VARP(h5_p4_nt128,   5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, P4, 0)
+VARP(h5_p6,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P6, 0)
+VARP(h5_p6_nt128,   5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, P6, 0)
 VARP(h5_a1,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P3, 1)
 VARP(h5_a2,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P3, 2)
 VARP(h5_a3,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P3, 3)
@@ -72,11 +75,14 @@ VARP(h10_p3,        10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P3, 0)
 VARP(h10_p3_th5,    5, 1, 4, 4, 16, 1, 1, ACT_RELU, false, P3, 0)
 VARP(h10_p4,        10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P4, 0)
 VARP(h10_p5,        10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P5, 0)
+VARP(h10_p6,        10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P6, 0)
+VARP(h10_p6_th5,    5, 1, 4, 4, 16, 1, 1, ACT_RELU, false, P6, 0)
 // conv3-shaped (H = 20, no pool) and conv2/4 (pool 2x2)
 VARP(h20_plain,     4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, P0, 0)
 VARP(h20_p3,        4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, P3, 0)
 VARP(h20_p3_th10,   10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P3, 0)
 VARP(h20_p4,        4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, P4, 0)
+VARP(h20_p6,        4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, P6, 0)
 VARP(p22_plain,     4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P0, 0)
 VARP(p22_plain_nt64, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, P0, 0)
 VARP(p22_p3,        4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P3, 0)
@@ -85,6 +91,8 @@ VARP(p22_p3_th10,   10, 1, 2, 4, 16, 2, 2, ACT_RELU, false, P3, 0)
 VARP(p22_p4,        4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P4, 0)
 VARP(p22_p5,        4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P5, 0)
 VARP(p22_p5_nt64,   4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, P5, 0)
+VARP(p22_p6,        4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P6, 0)
+VARP(p22_p6_nt64,   4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, P6, 0)
 VARP(p22_p4_nt64,   4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, P4, 0)
 
 int main(int argc, char **argv) {
@@ -103,18 +111,20 @@ int main(int argc, char **argv) {
                             {"interleaved (shipped)", h5_p3, 256}, {"interleaved NT128", h5_p3_nt128, 128},
                             {"interleaved NT64", h5_p3_nt64, 64}, {"interleaved NT128, 3 waves/SIMD", h5_w3_nt128, 128},
                             {"interleaved NT64, 4 waves/SIMD", h5_w4_nt64, 64}, {"interleaved NT256 forced 3 waves/SIMD", h5_w3_nt256, 256}, {"deep prefetch", h5_p4, 256}, {"glds weights", h5_p5, 256}, {"glds weights NT128", h5_p5_nt128, 128}, {"deep prefetch NT128", h5_p4_nt128, 128},
+                            {"weights in registers (BREG)", h5_p6, 256}, {"BREG NT128", h5_p6_nt128, 128},
                             {"ABL no global loads", h5_a1, 256}, {"ABL no LDS writes (loads die too)", h5_a2, 256},
                             {"ABL no loads/writes", h5_a3, 256}, {"ABL no ds_read", h5_a4, 256}, {"ABL no barrier", h5_a8, 256},
                             {"ABL MFMA stream only", h5_a15, 256}, {"ABL loads waited at step end, no writes", h5_a18, 256}};
     else if (layer >= 5) vars = {{"plain TH10 MW1 NS2 NW4 (base)", h10_plain, 128}, {"plain TH5 NS4 NT256", h10_plain_th5, 256},
                             {"interleaved (shipped)", h10_p3, 128}, {"interleaved TH5 NS4 NT256", h10_p3_th5, 256},
-                            {"deep prefetch", h10_p4, 128}, {"glds weights", h10_p5, 128}, {"interleaved TH5 NS2 NT128, 3 waves/SIMD", h10_w3, 128}};
+                            {"deep prefetch", h10_p4, 128}, {"glds weights", h10_p5, 128}, {"weights in registers (BREG)", h10_p6, 128}, {"BREG TH5 NS4 NT256", h10_p6_th5, 256}, {"interleaved TH5 NS2 NT128, 3 waves/SIMD", h10_w3, 128}};
     else if (layer == 3) vars = {{"plain TH4 MW2 NS2 NW4 (base)", h20_plain, 128}, {"interleaved (shipped)", h20_p3, 128},
-                            {"interleaved TH10 MW1", h20_p3_th10, 128}, {"deep prefetch", h20_p4, 128}};
+                            {"interleaved TH10 MW1", h20_p3_th10, 128}, {"deep prefetch", h20_p4, 128}, {"weights in registers (BREG)", h20_p6, 128}};
     else if (layer == 2 || layer == 4) vars = {{"plain TH4 MW2 NS2 NW4 NT128 (base)", p22_plain, 128}, {"plain TH4 MW4 NS1 NT64", p22_plain_nt64, 64},
                             {"interleaved NT128 (conv4 shipped)", p22_p3, 128}, {"interleaved NT64 (conv2 shipped)", p22_p3_nt64, 64},
                             {"interleaved TH10 MW1", p22_p3_th10, 128}, {"deep prefetch NT128", p22_p4, 128},
-                            {"deep prefetch NT64", p22_p4_nt64, 64}, {"glds NT128", p22_p5, 128}, {"glds NT64", p22_p5_nt64, 64}};
+                            {"deep prefetch NT64", p22_p4_nt64, 64}, {"glds NT128", p22_p5, 128}, {"glds NT64", p22_p5_nt64, 64},
+                            {"BREG NT128", p22_p6, 128}, {"BREG NT64", p22_p6_nt64, 64}};
     else { printf("layer %d not covered\n", layer); return 1; }
 
     const size_t xin = (size_t)n * s.H * s.W * s.cin;
