@@ -178,6 +178,7 @@ struct Slot {
     float sp_thr = 1e-4f;
     DevBuf sp_rowstat, sp_colcount, sp_line_nnz, sp_line_off, sp_indptr, sp_data, sp_indices, sp_rows;
     bool sp_has_rows = false;
+    size_t sp_spec = 0;              // entries copied back speculatively at launch time
     void *sp_pinned = nullptr;       // [line_off (n+1) int64 | indptr n*(C+1) int32] then data | indices at collect time
     size_t sp_pinned_cap = 0;
     // profiling
@@ -241,6 +242,7 @@ struct pocr_engine {
     int agg_cout16 = 0, head_cout16 = 0, proj_cout16 = 0;
     Slot slot[POCR_NUM_SLOTS];
     int last_slot = 0;               // slot of the most recent launch (stage timings / debug taps)
+    size_t sp_prev_total = 0;        // kept entries of the most recent sparse launch (sizes the next speculative copy)
     bool use_graphs = true;          // replay the LSTM recurrence from captured hipGraphs (POCR_NO_GRAPHS=1 disables)
     bool profiling = false;
 };
@@ -580,16 +582,26 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
                            s.sp_indices.as<int32_t>(), T, C, s.sp_thr, (int64_t)cap, s.g_line_T, s.g_row_off);
         HIP_TRY(hipGetLastError());
         const size_t off_bytes = (size_t)(n + 1) * sizeof(int64_t), ip_bytes = (size_t)n * (C + 1) * sizeof(int32_t);
-        const size_t need_sp = off_bytes + ip_bytes + cap / 4 * 8;     // room for 25 % density before a re-allocation
+        // The number of kept entries is known only on the device, but a copy enqueued at collect time would
+        // queue up behind the NEXT launch's conv kernels (measured: 31 ms per launch).  So the triplets are
+        // copied back speculatively now, in stream order: 1.25x the previous launch's count (first launch:
+        // 1/3 density); collect tops up the rest in the rare case that was not enough.
+        size_t spec = e->sp_prev_total ? e->sp_prev_total + e->sp_prev_total / 4 : cap / 3;
+        spec = std::min(spec, cap);
+        const size_t trip_base = (off_bytes + ip_bytes + 15) / 16 * 16;
+        const size_t need_sp = trip_base + spec * 8;
         if (need_sp > s.sp_pinned_cap) {
             if (s.sp_pinned) (void)hipHostFree(s.sp_pinned);
             s.sp_pinned = nullptr; s.sp_pinned_cap = 0;
-            HIP_TRY(hipHostMalloc(&s.sp_pinned, need_sp, hipHostMallocDefault));
-            s.sp_pinned_cap = need_sp;
+            HIP_TRY(hipHostMalloc(&s.sp_pinned, need_sp + need_sp / 4, hipHostMallocDefault));
+            s.sp_pinned_cap = need_sp + need_sp / 4;
         }
         char *sp = static_cast<char *>(s.sp_pinned);
         HIP_TRY(hipMemcpyAsync(sp, s.sp_line_off.p, off_bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(sp + off_bytes, s.sp_indptr.p, ip_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(sp + trip_base, s.sp_data.p, spec * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(sp + trip_base + spec * sizeof(float), s.sp_indices.p, spec * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        s.sp_spec = spec;
     }
     return 0;
 }
@@ -1159,10 +1171,17 @@ int pocr_slot_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t 
     const int64_t total = reinterpret_cast<const int64_t *>(sp)[n];
     memcpy(line_off, sp, off_bytes);
     memcpy(indptr, sp + off_bytes, ip_bytes);
-    if (total > 0) {     // the triplets: exact size is known only now
-        HIP_TRY(hipMemcpyAsync(data, s.sp_data.p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, s.seq_stream));
-        HIP_TRY(hipMemcpyAsync(indices, s.sp_indices.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, s.seq_stream));
+    if (total > 0) {
+        const size_t trip_base = (off_bytes + ip_bytes + 15) / 16 * 16, have = std::min<size_t>(s.sp_spec, (size_t)total);
+        const char *pin = static_cast<const char *>(s.sp_pinned) + trip_base;
+        memcpy(data, pin, have * sizeof(float));
+        memcpy(indices, pin + s.sp_spec * sizeof(float), have * sizeof(int32_t));
+        if ((size_t)total > have) {      // the speculative copy was too short: fetch the tail now
+            HIP_TRY(hipMemcpyAsync(data + have, s.sp_data.as<float>() + have, ((size_t)total - have) * sizeof(float), hipMemcpyDeviceToHost, s.seq_stream));
+            HIP_TRY(hipMemcpyAsync(indices + have, s.sp_indices.as<int32_t>() + have, ((size_t)total - have) * sizeof(int32_t), hipMemcpyDeviceToHost, s.seq_stream));
+        }
     }
+    e->sp_prev_total = (size_t)total;
     return collect_outputs(e, s, nullptr, frame_argmax_nt, labels_nt, label_len_n);
 }
 

@@ -259,8 +259,12 @@ class TransformerEngineLineOCR(BaseEngineLineOCR):
         # one-deep pipeline over launches: the encoder of launch k+1 is enqueued on the other slot before the
         # (blocking) decoding loop of launch k runs
         pending = None
+        serial = os.environ.get("POCR_S2S_SERIAL") == "1"        # measurement switch: no overlap between launches
         for k, group in enumerate(plan_launches(batches)):
             first = submit(k % 2, group)
+            if serial:
+                finish(k % 2, group, first)
+                continue
             if pending is not None:
                 finish(*pending)
             pending = (k % 2, group, first)
