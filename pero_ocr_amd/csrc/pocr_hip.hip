@@ -109,12 +109,12 @@ int launch_conv(Kern kern, int TH, int TW, int NT, int nthreads, ConvArgs a, hip
                            TH, 16 * MW, NS * NWAVE * 16, NWAVE * 64, a, st);                                        \
     }
 //                 KH KW P  P  TH MW NS NW KC PH PW
-POCR_CONV(conv2_k,   3, 3, 1, 1, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // 64->64   + pool 2x2
+POCR_CONV(conv2_k,   3, 3, 1, 1, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, STAGE_F32_NHWC, PIPE_DEEP)          // 64->64   + pool 2x2
 POCR_CONV(conv3_k,   3, 3, 1, 1, 4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // 64->128
 POCR_CONV(conv4_k,   3, 3, 1, 1, 4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // 128->128 + pool 2x2
-POCR_CONV(conv56_k,  3, 3, 1, 1, 10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)  // ->256
+POCR_CONV(conv56_k,  3, 3, 1, 1, 10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_DEEP)         // ->256
 POCR_CONV(conv7_k,   3, 3, 1, 1, 10, 1, 2, 4, 16, 2, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)  // 256->256 + pool 2x1
-POCR_CONV(conv8_k,   3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)  // 256->512
+POCR_CONV(conv8_k,   3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_DEEP)         // 256->512
 POCR_CONV(conv9_k,   3, 3, 1, 1, 5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, STAGE_F32_NHWC, PIPE_DEEP)          // 512->512 + BN; weight tile requested two steps ahead (+2 %)
 POCR_CONV(agg4_k,    4, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)
 POCR_CONV(agg5_k,    5, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)
