@@ -100,6 +100,14 @@ int pocr_run_staged(pocr_engine *e, float *logits_ntc, int32_t *frame_argmax_nt,
 int pocr_ctc_greedy(int device_id, const float *logits_ntc, int32_t n, int32_t T, int32_t C,
                     int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n);
 
+/* ---- stand-alone sparsification on the GPU of caller-supplied logits: replaces, for every line,
+ *   probs = softmax(logits, axis=1); logits[probs < threshold] = 0; scipy.sparse.csc_matrix(logits)
+ * (line_ocr_engine.py:168-171; the reference's own known-answer test: test/test_document_ocr/test_layout.py:10-26).
+ * logits_ntc float32 [n, T, C].  Outputs: line_off int64 [n+1], indptr int32 [n][C+1], and the kept values / row
+ * indices of all lines back to back in data / indices (capacity entries each; n*T*C always suffices).  No engine needed. */
+int pocr_sparsify(int device_id, const float *logits_ntc, int32_t n, int32_t T, int32_t C, float threshold,
+                  float *data, int32_t *indices, int64_t capacity, int32_t *indptr, int64_t *line_off);
+
 /* ---- pipelined chunks (no reference counterpart: the reference runs its chunks strictly one
  * after the other, line_ocr_engine.py:80-129).  An engine has POCR_NUM_SLOTS independent slots, each
  * with its own HIP stream and activation buffers.  stage -> launch -> collect per slot; launch returns

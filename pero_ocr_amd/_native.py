@@ -49,6 +49,7 @@ SYMBOLS = {
     "pocr_stage_lines": (C.c_int, [C.c_void_p, _u8p, _i64p, _i32p, C.c_int32, C.c_int32, C.c_int32]),
     "pocr_run_staged": (C.c_int, [C.c_void_p, _f32p, _i32p, _i32p, _i32p]),
     "pocr_ctc_greedy": (C.c_int, [C.c_int, _f32p, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _i32p]),
+    "pocr_sparsify": (C.c_int, [C.c_int, _f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, _f32p, _i32p, C.c_int64, _i32p, _i64p]),
     "pocr_num_slots": (C.c_int, []),
     "pocr_slot_stage_lines": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, C.c_int32, C.c_int32, C.c_int32]),
     "pocr_slot_stage_ragged": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, _i32p, C.c_int32, C.c_int32]),
@@ -341,6 +342,22 @@ def ctc_greedy(logits_ntc: np.ndarray, device_id: int = 0):
     if lib.pocr_ctc_greedy(int(device_id), _ptr(x, _f32p), n, T, Cc, _ptr(amax, _i32p), _ptr(labels, _i32p), _ptr(lens, _i32p)):
         raise RuntimeError("pocr_ctc_greedy: " + (lib.pocr_last_error() or b"").decode("utf8", "replace"))
     return amax, labels, lens
+
+
+def sparsify(logits_ntc: np.ndarray, threshold: float = 1e-4, device_id: int = 0):
+    """float32 [n, T, C] -> list of n scipy csc_matrix [T, C]: softmax, p < threshold -> 0, CSC - on the GPU."""
+    from scipy import sparse
+    lib = load()
+    x = np.ascontiguousarray(logits_ntc, dtype=np.float32)
+    n, T, Cc = x.shape
+    cap = max(1, x.size)
+    data, indices = np.empty(cap, np.float32), np.empty(cap, np.int32)
+    indptr, line_off = np.empty((n, Cc + 1), np.int32), np.empty(n + 1, np.int64)
+    if lib.pocr_sparsify(int(device_id), _ptr(x, _f32p), n, T, Cc, float(threshold), _ptr(data, _f32p), _ptr(indices, _i32p), cap,
+                         _ptr(indptr, _i32p), _ptr(line_off, _i64p)):
+        raise RuntimeError("pocr_sparsify: " + (lib.pocr_last_error() or b"").decode("utf8", "replace"))
+    return [sparse.csc_matrix((data[line_off[i]:line_off[i + 1]].copy(), indices[line_off[i]:line_off[i + 1]].copy(), indptr[i]),
+                              shape=(T, Cc)) for i in range(n)]
 
 
 def device_count() -> int:

@@ -1538,6 +1538,42 @@ int pocr_ctc_greedy(int device_id, const float *logits_ntc, int32_t n, int32_t T
     return done(0);
 }
 
+int pocr_sparsify(int device_id, const float *logits_ntc, int32_t n, int32_t T, int32_t C, float threshold,
+                  float *data, int32_t *indices, int64_t capacity, int32_t *indptr, int64_t *line_off) {
+    if (!logits_ntc || !data || !indices || !indptr || !line_off) return fail("NULL pointer");
+    if (n <= 0 || T <= 0 || C < 1) return fail("need n > 0, T > 0, C >= 1 (got %d, %d, %d)", n, T, C);
+    if (T > SP_MAXT) return fail("sparse logits: T = %d exceeds %d frames", T, SP_MAXT);
+    if (C > 256 * SP_COLS) return fail("sparse logits: C = %d exceeds %d classes", C, 256 * SP_COLS);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available: this library has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail("device_id %d out of range (%d devices)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    DevBuf lg, rowstat, colcount, nnz, off, ip, dd, di;
+    const size_t cap = (size_t)n * T * C;
+    int rc = lg.reserve(cap * sizeof(float)) || rowstat.reserve((size_t)n * T * 2 * sizeof(float)) || colcount.reserve((size_t)n * C * sizeof(int32_t)) ||
+             nnz.reserve((size_t)n * sizeof(int32_t)) || off.reserve((size_t)(n + 1) * sizeof(int64_t)) ||
+             ip.reserve((size_t)n * (C + 1) * sizeof(int32_t)) || dd.reserve(cap * sizeof(float)) || di.reserve(cap * sizeof(int32_t));
+    auto done = [&](int r) { for (DevBuf *b : {&lg, &rowstat, &colcount, &nnz, &off, &ip, &dd, &di}) b->release(); return r; };
+    if (rc) return done(1);
+    if (hipMemcpy(lg.p, logits_ntc, cap * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
+    hipLaunchKernelGGL(sparse_count_kernel, dim3(n), dim3(256), 0, 0, lg.as<float>(), (const int32_t *)nullptr, (const int32_t *)nullptr,
+                       rowstat.as<float>(), colcount.as<int32_t>(), nnz.as<int32_t>(), T, C, threshold, (const int32_t *)nullptr, (const int32_t *)nullptr);
+    hipLaunchKernelGGL(sparse_scan_kernel, dim3(1), dim3(64), 0, 0, nnz.as<int32_t>(), off.as<int64_t>(), n);
+    hipLaunchKernelGGL(sparse_fill_kernel, dim3(n), dim3(256), 0, 0, lg.as<float>(), (const int32_t *)nullptr, (const int32_t *)nullptr,
+                       rowstat.as<float>(), colcount.as<int32_t>(), off.as<int64_t>(), ip.as<int32_t>(), dd.as<float>(), di.as<int32_t>(), T, C,
+                       threshold, (int64_t)cap, (const int32_t *)nullptr, (const int32_t *)nullptr);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return done(fail("sparsify kernels failed"));
+    if (hipMemcpy(line_off, off.p, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    if (hipMemcpy(indptr, ip.p, (size_t)n * (C + 1) * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    const int64_t total = line_off[n];
+    if (total > capacity) return done(fail("%lld entries kept, caller's buffers hold %lld", (long long)total, (long long)capacity));
+    if (total > 0) {
+        if (hipMemcpy(data, dd.p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+        if (hipMemcpy(indices, di.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    }
+    return done(0);
+}
+
 int pocr_set_profiling(pocr_engine *e, int32_t enabled) {
     if (!e) return fail("engine is NULL");
     e->profiling = enabled != 0;

@@ -617,3 +617,26 @@ def test_page_ocr_caller_contract(golden, tmp_path):
     page2 = ocr2.process_page(None, Layout(s.crops()))
     assert [l.transcription for l in page2.lines] == s.transcriptions
     assert [l.logit_coords for l in page2.lines] == s.logit_coords
+
+
+@pytest.mark.gpu
+def test_gpu_sparsify_known_answer_and_round_trip():
+    """The reference's own known-answer test for the sparse logits (test/test_document_ocr/test_layout.py:10-26):
+    softmax, p < 1e-4 -> 0, CSC; TextLine.get_dense_logits(-50) restores the dense matrix with the fill value."""
+    from pero_ocr_amd.ocr_engine.softmax import softmax
+    logits = np.array([[1.0, -20.0, -19.0], [0.1, 0.1, -21.0]], dtype=np.float32)
+    (m,) = _native.sparsify(logits[None])
+    dense = m.toarray()
+    dense[dense == 0] = -50.0                               # TextLine.get_dense_logits (pero_ocr/core/layout.py:65-68)
+    assert np.array_equal(dense, np.array([[1.0, -50.0, -50.0], [0.1, 0.1, -50.0]], dtype=np.float32))
+    # random logits: same kept set as the host formula, values untouched, rows sorted inside every column
+    rng = np.random.RandomState(3)
+    x = (rng.randn(5, 37, 101) * 4).astype(np.float32)
+    x[0, 3, 7] = 0.0                                        # an exact zero is never stored (csc_matrix drops it)
+    x[1, :, :] = 0.0                                        # uniform rows: p = 1/101 > threshold, but the values are 0
+    for i, m in enumerate(_native.sparsify(x)):
+        want = np.where(softmax(x[i], axis=1) < 1e-4, np.float32(0), x[i])
+        got = m.toarray()
+        edge = np.abs(softmax(x[i], axis=1) - 1e-4) < 2e-6   # float rounding may flip entries sitting on the threshold
+        assert np.array_equal(got[~edge], want[~edge])
+        assert m.has_sorted_indices and m.dtype == np.float32

@@ -42,6 +42,11 @@ VARW(h5_w4_nt64,  5, 1, 1, 4, 1, 1, ACT_LEAKY, true, 4)
 VARW(h5_w3_nt256, 5, 1, 4, 4, 1, 1, ACT_LEAKY, true, 3)
 VARW(h10_w3,      5, 1, 2, 4, 1, 1, ACT_RELU, false, 3)
 VARW(h20_w3,      4, 2, 1, 4, 1, 1, ACT_RELU, false, 3)
+VARW(h20_w3_ns2,  4, 2, 2, 4, 1, 1, ACT_RELU, false, 3)
+VARW(p22_w3_nt64, 4, 4, 1, 4, 2, 2, ACT_RELU, false, 3)
+VARW(p22_w3_nt128, 4, 2, 2, 4, 2, 2, ACT_RELU, false, 3)
+VARW(p22_w3_mw2_nt64, 4, 2, 1, 4, 2, 2, ACT_RELU, false, 3)
+VARW(p22_w4_mw2_nt64, 4, 2, 1, 4, 2, 2, ACT_RELU, false, 4)
 #define P0 PIPE_PLAIN
 #define P3 PIPE_INTERLEAVED
 #define P4 PIPE_DEEP
@@ -119,12 +124,15 @@ int main(int argc, char **argv) {
                             {"interleaved (shipped)", h10_p3, 128}, {"interleaved TH5 NS4 NT256", h10_p3_th5, 256},
                             {"deep prefetch", h10_p4, 128}, {"glds weights", h10_p5, 128}, {"weights in registers (BREG)", h10_p6, 128}, {"BREG TH5 NS4 NT256", h10_p6_th5, 256}, {"interleaved TH5 NS2 NT128, 3 waves/SIMD", h10_w3, 128}};
     else if (layer == 3) vars = {{"plain TH4 MW2 NS2 NW4 (base)", h20_plain, 128}, {"interleaved (shipped)", h20_p3, 128},
-                            {"interleaved TH10 MW1", h20_p3_th10, 128}, {"deep prefetch", h20_p4, 128}, {"weights in registers (BREG)", h20_p6, 128}};
+                            {"interleaved TH10 MW1", h20_p3_th10, 128}, {"deep prefetch", h20_p4, 128}, {"weights in registers (BREG)", h20_p6, 128},
+                            {"interleaved, 3 waves/SIMD", h20_w3_ns2, 128}, {"interleaved NS1 NT64, 3 waves/SIMD", h20_w3, 64}};
     else if (layer == 2 || layer == 4) vars = {{"plain TH4 MW2 NS2 NW4 NT128 (base)", p22_plain, 128}, {"plain TH4 MW4 NS1 NT64", p22_plain_nt64, 64},
                             {"interleaved NT128 (conv4 shipped)", p22_p3, 128}, {"interleaved NT64 (conv2 shipped)", p22_p3_nt64, 64},
                             {"interleaved TH10 MW1", p22_p3_th10, 128}, {"deep prefetch NT128", p22_p4, 128},
                             {"deep prefetch NT64", p22_p4_nt64, 64}, {"glds NT128", p22_p5, 128}, {"glds NT64", p22_p5_nt64, 64},
-                            {"BREG NT128", p22_p6, 128}, {"BREG NT64", p22_p6_nt64, 64}};
+                            {"BREG NT128", p22_p6, 128}, {"BREG NT64", p22_p6_nt64, 64},
+                            {"interleaved NT64, 3 waves/SIMD", p22_w3_nt64, 64}, {"interleaved NT128, 3 waves/SIMD", p22_w3_nt128, 128},
+                            {"interleaved MW2 NT64, 3 waves/SIMD", p22_w3_mw2_nt64, 64}, {"interleaved MW2 NT64, 4 waves/SIMD", p22_w4_mw2_nt64, 64}};
     else { printf("layer %d not covered\n", layer); return 1; }
 
     const size_t xin = (size_t)n * s.H * s.W * s.cin;
