@@ -100,6 +100,13 @@ int pocr_run_staged(pocr_engine *e, float *logits_ntc, int32_t *frame_argmax_nt,
 int pocr_ctc_greedy(int device_id, const float *logits_ntc, int32_t n, int32_t T, int32_t C,
                     int32_t *frame_argmax_nt, int32_t *labels_nt, int32_t *label_len_n);
 
+/* Transcription confidence of every line of the last COLLECTED sparse launch of `slot`, computed on the device from
+ * the same kept set: what PageParser.compute_line_confidence / get_prob (pero_ocr/document_ocr/page_parser.py:485-496,
+ * 437-450) return for the line's sparse logits read back through TextLine.get_dense_logits (core/layout.py:65-68,
+ * dropped entries = -80): per frame the winner's probability, per run of equal winners its maximum, per line the
+ * minimum over runs.  confidence_n: float32 [n]. */
+int pocr_slot_confidence(pocr_engine *e, int32_t slot, float *confidence_n);
+
 /* ---- stand-alone sparsification on the GPU of caller-supplied logits: replaces, for every line,
  *   probs = softmax(logits, axis=1); logits[probs < threshold] = 0; scipy.sparse.csc_matrix(logits)
  * (line_ocr_engine.py:168-171; the reference's own known-answer test: test/test_document_ocr/test_layout.py:10-26).

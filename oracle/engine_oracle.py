@@ -10,6 +10,9 @@ numpy restatement of the reference's host-side algorithm around the network:
   softmax           pero_ocr/ocr_engine/softmax.py:4-46
   sparsify          line_ocr_engine.py:168-171
   process_lines     line_ocr_engine.py:57-177 (CTC branch)
+  line_confidence   pero_ocr/document_ocr/page_parser.py:485-496 (compute_line_confidence), :437-450 (get_prob),
+                    pero_ocr/core/layout.py:65-68 (get_dense_logits); pinned by tests/golden/c1_confidence.json,
+                    which oracle/gen_golden_conf.py wrote by executing the reference's own functions
 
 Pinned by: tests/golden/* (outputs of the imported reference, written by
 oracle/gen_golden.py) and the CTC known-answer cases of
@@ -126,3 +129,22 @@ def process_lines(forward_nct: Callable[[np.ndarray], np.ndarray], lines: Sequen
                 ll = sparsify(ll)
             logits_out[i] = ll
     return texts, logits_out, coords, {"frame_argmax": argmax_out, "plan": plan}
+
+
+def line_confidence(line_logits: sparse.spmatrix, zero_logit_value: float = -80) -> float:
+    """Transcription confidence of one line from its SPARSE logits: dropped entries count as -80, the
+    per-frame winners are grouped into runs of equal class, a run is worth its highest probability and the
+    line is worth its worst run."""
+    dense = line_logits.toarray()
+    dense[dense == 0] = zero_logit_value
+    log_probs = dense - np.logaddexp.reduce(dense, axis=1)[:, None]
+    ids = np.argmax(log_probs, axis=1)
+    probs = np.exp(np.max(log_probs, axis=1))
+    worst, run_best, run_id = 1, 1, -1
+    for i, p in zip(ids, probs):
+        if i != run_id:
+            worst = min(worst, run_best)
+            run_id, run_best = i, p
+        else:
+            run_best = max(run_best, p)
+    return min(worst, run_best)

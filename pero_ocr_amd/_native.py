@@ -65,6 +65,7 @@ SYMBOLS = {
     "pocr_s2s_collect": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _f32p]),
     "pocr_s2s_sparse": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_float, C.POINTER(C.c_int64)]),
     "pocr_s2s_collect_sparse": (C.c_int, [C.c_void_p, C.c_int32, _f32p, _i32p, _i32p, _i64p]),
+    "pocr_slot_confidence": (C.c_int, [C.c_void_p, C.c_int32, _f32p]),
     "pocr_last_stage_ms": (C.c_int, [C.c_void_p, _f32p, C.c_int32]),
     "pocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "pocr_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -307,6 +308,13 @@ class NativeEngine:
                                              _ptr(line_off, _i64p)):
             raise RuntimeError("pocr_s2s_collect_sparse: " + self._err())
         return data[:total.value], indices[:total.value], indptr, line_off
+
+    def slot_confidence(self, slot: int) -> np.ndarray:
+        """Per-line transcription confidences of the sparse launch just collected from `slot` (float32 [n])."""
+        out = np.empty(self._slot_shape[slot][0], dtype=np.float32)
+        if self._lib.pocr_slot_confidence(self._h, int(slot), _ptr(out, _f32p)):
+            raise RuntimeError("pocr_slot_confidence: " + self._err())
+        return out
 
     def slot_stage_ms(self, slot: int) -> dict:
         buf = np.zeros(len(STAGE_NAMES), dtype=np.float32)

@@ -176,7 +176,7 @@ struct Slot {
     // device-side CSC sparsification of the logits (sparsify.hpp)
     bool want_sparse = false;
     float sp_thr = 1e-4f;
-    DevBuf sp_rowstat, sp_colcount, sp_line_nnz, sp_line_off, sp_indptr, sp_data, sp_indices, sp_rows;
+    DevBuf sp_rowstat, sp_colcount, sp_line_nnz, sp_line_off, sp_indptr, sp_data, sp_indices, sp_rows, sp_conf;
     bool sp_has_rows = false;
     size_t sp_spec = 0;              // entries copied back speculatively at launch time
     void *sp_pinned = nullptr;       // [line_off (n+1) int64 | indptr n*(C+1) int32] then data | indices at collect time
@@ -576,6 +576,9 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
         const int32_t *r1 = s.sp_has_rows ? s.sp_rows.as<int32_t>() + n : nullptr;
         hipLaunchKernelGGL(sparse_count_kernel, dim3(n), dim3(256), 0, st, s.logits.as<float>(), r0, r1, s.sp_rowstat.as<float>(),
                            s.sp_colcount.as<int32_t>(), s.sp_line_nnz.as<int32_t>(), T, C, s.sp_thr, s.g_line_T, s.g_row_off);
+        if (s.sp_conf.reserve((size_t)n * sizeof(float))) return 1;
+        hipLaunchKernelGGL(line_confidence_kernel, dim3(n), dim3(256), 0, st, s.logits.as<float>(), r0, r1, s.sp_rowstat.as<float>(),
+                           s.sp_conf.as<float>(), T, C, s.sp_thr, -80.0f, s.g_line_T, s.g_row_off);
         hipLaunchKernelGGL(sparse_scan_kernel, dim3(1), dim3(64), 0, st, s.sp_line_nnz.as<int32_t>(), s.sp_line_off.as<int64_t>(), n);
         hipLaunchKernelGGL(sparse_fill_kernel, dim3(n), dim3(256), 0, st, s.logits.as<float>(), r0, r1, s.sp_rowstat.as<float>(),
                            s.sp_colcount.as<int32_t>(), s.sp_line_off.as<int64_t>(), s.sp_indptr.as<int32_t>(), s.sp_data.as<float>(),
@@ -588,7 +591,8 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
         // 1/3 density); collect tops up the rest in the rare case that was not enough.
         size_t spec = e->sp_prev_total ? e->sp_prev_total + e->sp_prev_total / 4 : cap / 3;
         spec = std::min(spec, cap);
-        const size_t trip_base = (off_bytes + ip_bytes + 15) / 16 * 16;
+        const size_t conf_off = off_bytes + ip_bytes;                    // [line_off | indptr | confidence | data | indices]
+        const size_t trip_base = (conf_off + (size_t)n * sizeof(float) + 15) / 16 * 16;
         const size_t need_sp = trip_base + spec * 8;
         if (need_sp > s.sp_pinned_cap) {
             if (s.sp_pinned) (void)hipHostFree(s.sp_pinned);
@@ -599,6 +603,7 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
         char *sp = static_cast<char *>(s.sp_pinned);
         HIP_TRY(hipMemcpyAsync(sp, s.sp_line_off.p, off_bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(sp + off_bytes, s.sp_indptr.p, ip_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(sp + conf_off, s.sp_conf.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(sp + trip_base, s.sp_data.p, spec * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(sp + trip_base + spec * sizeof(float), s.sp_indices.p, spec * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         s.sp_spec = spec;
@@ -905,7 +910,7 @@ void pocr_destroy(pocr_engine *e) {
             if (ev) (void)hipEventDestroy(ev);
         for (DevBuf *b : {&s.crops, &s.lines, &s.feat, &s.xproj, &s.hbuf, &s.cbuf, &s.logits, &s.best, &s.labels, &s.lens,
                           &s.sa_x, &s.sa_x1, &s.sa_qkv, &s.sa_att, &s.sa_tmp, &s.sa_ff, &s.sp_rowstat, &s.sp_colcount,
-                          &s.sp_line_nnz, &s.sp_line_off, &s.sp_indptr, &s.sp_data, &s.sp_indices, &s.sp_rows, &s.geom, &s.seqgeom})
+                          &s.sp_line_nnz, &s.sp_line_off, &s.sp_indptr, &s.sp_data, &s.sp_indices, &s.sp_rows, &s.sp_conf, &s.geom, &s.seqgeom})
             b->release();
         if (s.pinned) (void)hipHostFree(s.pinned);
         if (s.sp_pinned) (void)hipHostFree(s.sp_pinned);
@@ -1172,7 +1177,7 @@ int pocr_slot_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t 
     memcpy(line_off, sp, off_bytes);
     memcpy(indptr, sp + off_bytes, ip_bytes);
     if (total > 0) {
-        const size_t trip_base = (off_bytes + ip_bytes + 15) / 16 * 16, have = std::min<size_t>(s.sp_spec, (size_t)total);
+        const size_t trip_base = (off_bytes + ip_bytes + (size_t)n * sizeof(float) + 15) / 16 * 16, have = std::min<size_t>(s.sp_spec, (size_t)total);
         const char *pin = static_cast<const char *>(s.sp_pinned) + trip_base;
         memcpy(data, pin, have * sizeof(float));
         memcpy(indices, pin + s.sp_spec * sizeof(float), have * sizeof(int32_t));
@@ -1185,6 +1190,18 @@ int pocr_slot_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t 
     return collect_outputs(e, s, nullptr, frame_argmax_nt, labels_nt, label_len_n);
 }
 
+
+int pocr_slot_confidence(pocr_engine *e, int32_t slot, float *confidence_n) {
+    if (check_slot(e, slot)) return 1;
+    Slot &s = e->slot[slot];
+    if (!s.want_sparse || !s.sp_pinned || !s.staged) return fail("slot %d: no collected sparse launch", slot);
+    if (s.in_flight) return fail("slot %d: collect the launch first", slot);
+    if (!confidence_n) return fail("confidence_n is NULL");
+    const int n = s.n, C = e->cfg.num_classes;
+    const size_t conf_off = (size_t)(n + 1) * sizeof(int64_t) + (size_t)n * (C + 1) * sizeof(int32_t);
+    memcpy(confidence_n, static_cast<const char *>(s.sp_pinned) + conf_off, (size_t)n * sizeof(float));
+    return 0;
+}
 
 // ------------------------------------------------------------------ sequence-to-sequence (decoder.hpp)
 

@@ -12,6 +12,10 @@
 //   sparse_scan_kernel    exclusive scan of the per-line totals -> line_off[n+1]
 //   sparse_fill_kernel    per line: column scan -> indptr, then each thread streams its columns
 //                         top to bottom so rows come out sorted, as CSC requires
+//   line_confidence_kernel  transcription confidence of a line from the SAME kept set, i.e. what the reference's
+//                         caller computes from the sparse matrix: PageParser.compute_line_confidence + get_prob
+//                         (pero_ocr/document_ocr/page_parser.py:485-496, 437-450) on TextLine.get_dense_logits
+//                         (pero_ocr/core/layout.py:65-68: dropped entries count as -80)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -134,6 +138,69 @@ __global__ __launch_bounds__(256) void sparse_fill_kernel(const float *logits, c
                 ++pos;
             }
         }
+    }
+}
+
+// conf [n].  Per frame: D = kept ? logit : fill; winner = first arg-max of D, its probability = 1 / sum exp(D - Dmax).
+// Per line: frames are grouped into runs of equal winner, a run is worth its highest probability, the line its worst run.
+__global__ __launch_bounds__(256) void line_confidence_kernel(const float *logits, const int32_t *row_begin,
+                                                              const int32_t *row_end, const float *rowstat, float *conf,
+                                                              int T_uniform, int C, float thr, float fill,
+                                                              const int32_t *line_T, const int32_t *row_off) {
+    __shared__ int bid[SP_MAXT];
+    __shared__ float bp[SP_MAXT];
+    const int line = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = line_T ? line_T[line] : T_uniform;
+    const size_t row0 = row_off ? (size_t)row_off[line] : (size_t)line * T_uniform;
+    const int r0 = row_begin ? row_begin[line] : 0, r1 = row_end ? row_end[line] : T;
+    const float *x = logits + row0 * C;
+    for (int t = r0 + wave; t < r1; t += 4) {
+        const float *row = x + (size_t)t * C;
+        const float m = rowstat[(row0 + t) * 2], s = rowstat[(row0 + t) * 2 + 1];
+        float kv = -INFINITY, ks = 0.f;
+        int ki = 0x7fffffff, di = 0x7fffffff, nd = 0;
+        for (int c = lane; c < C; c += 64) {
+            const float v = row[c];
+            if (sp_keep(v, m, s, thr)) {
+                ks += expf(v - m);
+                if (v > kv || (v == kv && c < ki)) { kv = v; ki = c; }
+            } else {
+                ++nd;
+                di = min(di, c);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            ks += __shfl_xor(ks, off, 64);
+            nd += __shfl_xor(nd, off, 64);
+            di = min(di, __shfl_xor(di, off, 64));
+            const float ov = __shfl_xor(kv, off, 64);
+            const int oi = __shfl_xor(ki, off, 64);
+            if (ov > kv || (ov == kv && oi < ki)) { kv = ov; ki = oi; }
+        }
+        if (lane == 0) {
+            float dmax = kv;
+            int did = ki;
+            if (nd > 0 && (ki == 0x7fffffff || fill > kv || (fill == kv && di < ki))) { dmax = fill; did = di; }
+            const float sum = (ki == 0x7fffffff ? 0.f : ks * expf(m - dmax)) + (float)nd * expf(fill - dmax);
+            bid[t] = did;
+            bp[t] = 1.0f / sum;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float worst = 1.f, run_best = 1.f;
+        int run_id = -1;
+        for (int t = r0; t < r1; ++t) {
+            if (bid[t] != run_id) {
+                worst = fminf(worst, run_best);
+                run_id = bid[t];
+                run_best = bp[t];
+            } else {
+                run_best = fmaxf(run_best, bp[t]);
+            }
+        }
+        conf[line] = fminf(worst, run_best);
     }
 }
 

@@ -41,6 +41,11 @@ class PageOCR:
             line.logits = line_logits
             line.characters = self.ocr_engine.characters
             line.logit_coords = line_coords
+        # extra: confidences the GPU computed from the same sparse logits; PageParser.update_confidences
+        # (page_parser.py:505-508) recomputes the same numbers on the host if it is left in place
+        for line, conf in zip(lines, getattr(self.ocr_engine, "line_confidences", None) or []):
+            if conf is not None:
+                line.transcription_confidence = conf
         return page_layout
 
     @property

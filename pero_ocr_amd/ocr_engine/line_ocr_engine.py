@@ -160,10 +160,17 @@ class BaseEngineLineOCR:
 
         device_sparse = sparse_logits and not no_logits and getattr(self, "supports_device_sparsify", False)
 
-        def scatter(line_ids, texts, chunk_logits):
+        # Side channel (not part of the reference's return contract): with GPU-built sparse logits the engine also
+        # returns every line's transcription confidence, i.e. what PageParser.update_confidences would compute
+        # from these logits (page_parser.py:485-496, 505-508).  None where it was not computed.
+        self.line_confidences = [None] * n
+
+        def scatter(line_ids, texts, chunk_logits, conf=None):
             """chunk_logits: per-line list (ragged launches, GPU-built csc or dense [T_i, C]) or [n, T, C] array."""
             for k, i in enumerate(line_ids):
                 transcriptions[i] = texts[k]
+                if conf is not None:
+                    self.line_confidences[i] = float(conf[k])
             if no_logits:
                 return
             if device_sparse:           # chunk_logits is already a list of csc_matrix (built on the GPU)

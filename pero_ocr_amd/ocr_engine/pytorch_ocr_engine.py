@@ -140,18 +140,19 @@ class PytorchEngineLineOCR(BaseEngineLineOCR):
                 per_line = [logits[e - f:e] for e, f in zip(ends, frames)]
             return labels_to_strings(labels, lens, self.characters), per_line
         data, indices, indptr, line_off, _amax, labels, lens = self.model.slot_collect_sparse(slot)
+        conf = self.model.slot_confidence(slot)          # page_parser.py:485-496 on the same kept set, computed on the GPU
         n, C = indptr.shape[0], indptr.shape[1] - 1
         mats = []
         for i in range(n):
             a, b = int(line_off[i]), int(line_off[i + 1])
             nrows = (int(rows[1][i]) - int(rows[0][i])) if rows[0] is not None else int(frames[i])
             mats.append(sparse.csc_matrix((data[a:b], indices[a:b], indptr[i]), shape=(nrows, C)))
-        return labels_to_strings(labels, lens, self.characters), mats
+        return labels_to_strings(labels, lens, self.characters), mats, conf
 
     def _recognise_chunk(self, lines, chunk: Chunk, want_logits: bool):
         """One reference chunk, blocking (the seam BaseEngineLineOCR falls back to)."""
         from .line_ocr_engine import Launch
-        texts, per_line = self._collect_launch(self._submit_launch(lines, Launch([chunk]), want_logits, 0))
+        texts, per_line = self._collect_launch(self._submit_launch(lines, Launch([chunk]), want_logits, 0))[:2]
         return texts, (np.stack(per_line) if per_line is not None else None)
 
     supports_device_sparsify = True

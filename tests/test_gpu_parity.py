@@ -598,6 +598,7 @@ def test_page_ocr_caller_contract(golden, tmp_path):
     assert [l.logit_coords for l in page.lines] == g.logit_coords
     assert all(l.characters == g.characters for l in page.lines)
     assert all(abs(int(l.logits.nnz) - k) <= max(2, k // 200) for l, k in zip(page.lines, g.nnz_sparse))
+    assert all(0.0 < l.transcription_confidence <= 1.0 for l in page.lines)      # extra: computed on the GPU (row f-4)
     broken = Layout(g.crops()[:2])
     broken.lines[1].crop = None
     with pytest.raises(Exception, match="Missing crop in line l1"):
@@ -640,3 +641,29 @@ def test_gpu_sparsify_known_answer_and_round_trip():
         edge = np.abs(softmax(x[i], axis=1) - 1e-4) < 2e-6   # float rounding may flip entries sitting on the threshold
         assert np.array_equal(got[~edge], want[~edge])
         assert m.has_sorted_indices and m.dtype == np.float32
+
+
+@pytest.mark.gpu
+def test_gpu_line_confidence(golden, tmp_path):
+    """Row f-4, second half: per-line confidences from the device vs (a) the reference's own compute_line_confidence run
+    on the reference engine's sparse logits (tests/golden/c1_confidence.json) and (b) the oracle applied to the sparse
+    logits this engine returned."""
+    from conftest import GOLDEN_DIR
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    g = golden("c1")
+    ref = json.load(open(os.path.join(GOLDEN_DIR, "c1_confidence.json"), encoding="utf8"))
+    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=g.batch_size)
+    crops = g.crops()
+    _t, mats, _c = eng.process_lines(crops)
+    got = np.array(eng.line_confidences, dtype=np.float64)
+    assert got.shape == (g.n,) and np.all((got > 0) & (got <= 1))
+    assert np.max(np.abs(got - np.array(ref["confidence"]))) < 2e-4            # logits differ by <= 1e-4 between the engines
+    own = np.array([engine_oracle.line_confidence(m) for m in mats], dtype=np.float64)
+    assert np.max(np.abs(got - own)) < 2e-6
+    # tight crop: the confidence is computed over the returned rows
+    _t, mats, _c = eng.process_lines(crops[:5], tight_crop_logits=True)
+    own = np.array([engine_oracle.line_confidence(m) for m in mats], dtype=np.float64)
+    assert np.max(np.abs(np.array(eng.line_confidences) - own)) < 2e-6
+    # dense / no_logits modes do not compute it
+    eng.process_lines(crops[:3], sparse_logits=False)
+    assert eng.line_confidences == [None] * 3

@@ -133,3 +133,21 @@ def test_blob_roundtrip(tmp_path):
     netspec.save_blob(p, spec, w)
     spec2, w2 = netspec.load_blob(p)
     assert spec2 == spec and all(np.array_equal(w[k], w2[k]) for k in w)
+
+
+def test_line_confidence_matches_reference_functions(golden):
+    """oracle.line_confidence vs the values the reference's own compute_line_confidence produced
+    (oracle/gen_golden_conf.py) on the c1 sparse logits and on a hand-made case."""
+    import json
+    import os
+    from scipy import sparse
+    from conftest import GOLDEN_DIR
+    g = golden("c1")
+    ref = json.load(open(os.path.join(GOLDEN_DIR, "c1_confidence.json"), encoding="utf8"))
+    C = len(g.characters)
+    for i in range(g.n):
+        T = int(g.arrays["shapes"][i][0])
+        m = sparse.csc_matrix((g.arrays[f"csc_data_{i}"], g.arrays[f"csc_indices_{i}"], g.arrays[f"csc_indptr_{i}"]), shape=(T, C))
+        assert engine_oracle.line_confidence(m) == ref["confidence"][i]
+    hand = sparse.csc_matrix(np.array(ref["hand_logits"], dtype=np.float32))
+    assert engine_oracle.line_confidence(hand) == ref["hand_confidence"]
