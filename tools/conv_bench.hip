@@ -65,6 +65,8 @@ VARP(h5_p5,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P5, 0)
 VARP(h5_p5_nt128,   5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, P5, 0)
 VARP(h5_p4_nt128,   5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, P4, 0)
 VARP(h5_p6,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P6, 0)
+VARP(h5_p3_mw2,     5, 2, 2, 4, 16, 1, 1, ACT_LEAKY, true, P3, 0)
+VARP(h5_p4_mw2,     5, 2, 2, 4, 16, 1, 1, ACT_LEAKY, true, P4, 0)
 VARP(h5_p6_nt128,   5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, P6, 0)
 VARP(h5_a1,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P3, 1)
 VARP(h5_a2,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P3, 2)
@@ -117,6 +119,7 @@ int main(int argc, char **argv) {
                             {"interleaved NT64", h5_p3_nt64, 64}, {"interleaved NT128, 3 waves/SIMD", h5_w3_nt128, 128},
                             {"interleaved NT64, 4 waves/SIMD", h5_w4_nt64, 64}, {"interleaved NT256 forced 3 waves/SIMD", h5_w3_nt256, 256}, {"deep prefetch", h5_p4, 256}, {"glds weights", h5_p5, 256}, {"glds weights NT128", h5_p5_nt128, 128}, {"deep prefetch NT128", h5_p4_nt128, 128},
                             {"weights in registers (BREG)", h5_p6, 256}, {"BREG NT128", h5_p6_nt128, 128},
+                            {"interleaved MW2 NS2 NT128", h5_p3_mw2, 128}, {"deep MW2 NS2 NT128", h5_p4_mw2, 128},
                             {"ABL no global loads", h5_a1, 256}, {"ABL no LDS writes (loads die too)", h5_a2, 256},
                             {"ABL no loads/writes", h5_a3, 256}, {"ABL no ds_read", h5_a4, 256}, {"ABL no barrier", h5_a8, 256},
                             {"ABL MFMA stream only", h5_a15, 256}, {"ABL loads waited at step end, no writes", h5_a18, 256}};
