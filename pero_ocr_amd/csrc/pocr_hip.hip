@@ -120,9 +120,9 @@ POCR_CONV(agg4_k,    4, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F
 POCR_CONV(agg5_k,    5, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)
 POCR_CONV(agg6_k,    6, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_PLAIN)
 POCR_CONV(agg8_k,    8, 1, 0, 0, 1, 3, 4, 4, 16, 1, 1, ACT_LEAKY, false, STAGE_F32_NHWC, PIPE_PLAIN)
-POCR_CONV(gemm128_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // rows x 128 cols per WG
-POCR_CONV(gemm64_k,  1, 1, 0, 0, 1, 8, 1, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // rows x 64 cols per WG
-POCR_CONV(gemm128_relu_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_INTERLEAVED)   // FFN first linear
+POCR_CONV(gemm128_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC, PIPE_DEEP)   // rows x 128 cols per WG
+POCR_CONV(gemm64_k,  1, 1, 0, 0, 1, 8, 1, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC, PIPE_DEEP)   // rows x 64 cols per WG
+POCR_CONV(gemm128_relu_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_DEEP)   // FFN first linear
 const int kConvNT[9] = {64, 64, 128, 128, 128, 128, 128, 256, 256};
 // pixel-tile shape (TH, 16*MW) of conv1..conv9 and of the aggregation conv - the same numbers as in the table above
 const int kConvTH[10] = {4, 4, 4, 4, 10, 10, 10, 5, 5, 1};
