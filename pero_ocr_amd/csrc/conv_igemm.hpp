@@ -34,7 +34,7 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
 enum { STAGE_F32_NHWC = 0 };      // the u8 line stager of the first layer lives in conv1_u8.hpp
 // main-loop variants (template parameter PIPE).  ABL3 is an ablation mask used only by tools/conv_bench.hip
 // (1 no global loads, 2 no LDS writes, 4 no ds_reads, 8 no barrier, 16 loads waited for at the step end).
-enum { PIPE_PLAIN = 0, PIPE_INTERLEAVED = 3, PIPE_DEEP = 4, PIPE_GLDS = 5, PIPE_BREG = 6 };
+enum { PIPE_PLAIN = 0, PIPE_INTERLEAVED = 3, PIPE_DEEP = 4, PIPE_GLDS = 5, PIPE_BREG = 6, PIPE_DEEP3 = 7 };
 // PIPE_GLDS = PIPE_INTERLEAVED with the weight tile copied HBM/L2 -> LDS by the load unit itself
 // (global_load_lds_dwordx4: no staging VGPRs, no ds_write; the tile is already lane-linear).
 // PIPE_BREG: the weights never touch LDS.  In fragment order a wave's B operands of one step are NS 16-byte
@@ -365,9 +365,14 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a
         }
     }
     } else {
-    static_assert(PIPE == PIPE_INTERLEAVED || PIPE == PIPE_DEEP || PIPE == PIPE_GLDS, "unknown pipeline id");
+    static_assert(PIPE == PIPE_INTERLEAVED || PIPE == PIPE_DEEP || PIPE == PIPE_GLDS || PIPE == PIPE_DEEP3, "unknown pipeline id");
     constexpr bool GLDS = PIPE == PIPE_GLDS;
     constexpr bool DEEP = PIPE == PIPE_DEEP;     // weight tile s+2 is requested right after tile s+1 has been written to LDS
+    // DEEP3: two staging register sets; tile s+3 is requested right after tile s+1 has been written, so a weight
+    // load has two full steps to arrive.  The sets alternate with the step parity; the taps are unrolled, so the set
+    // of a tap is static and an odd tap count is squared up by swapping the sets once per chunk.
+    constexpr bool DEEP3 = PIPE == PIPE_DEEP3;
+    static_assert(!DEEP3 || (NTAPS % 2 == 1 && NTAPS >= 3), "DEEP3 is written for odd tap counts (3x3 convs)");
     // ------------------------------------------------------------------ interleaved two-stage pipeline
     // Same LDS double buffering as the plain loop, but (a) the tap loop is fully unrolled inside a runtime
     // chunk loop, so tap offsets are immediates and the per-step scalar bookkeeping disappears,
@@ -412,6 +417,15 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a
         const int f = tid + r * NTHR;
         if (B_F4 % NTHR == 0 || f < B_F4) ldsB[buf * B_F4 + f] = rb[r];
     };
+    f32x4 rb2[DEEP3 ? B_LD : 1];                   // second staging set (DEEP3)
+    auto ldB2 = [&](int r, const f32x4 *tile) {
+        const int f = tid + r * NTHR;
+        if (B_F4 % NTHR == 0 || f < B_F4) rb2[r] = tile[f];
+    };
+    auto stB2 = [&](int r, int buf) {
+        const int f = tid + r * NTHR;
+        if (B_F4 % NTHR == 0 || f < B_F4) ldsB[buf * B_F4 + f] = rb2[r];
+    };
     // direct-to-LDS copy of piece r of a weight tile: every lane supplies its own global address, the LDS
     // destination is (wave-uniform base) + lane * 16 B, which is exactly the tile's linear layout
     auto dmaB = [&](int r, const f32x4 *tile, int buf) {
@@ -429,11 +443,17 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a
     for (int r = 0; r < A_LD; ++r) stA(r, 0);
 #pragma unroll
     for (int r = 0; r < B_LD; ++r) stB(r, 0);
-    if constexpr (DEEP) {
+    if constexpr (DEEP || DEEP3) {
         if (nsteps > 1) {
             const f32x4 *t1 = NTAPS > 1 ? wf4 + tap_stride : wf4 + chunk_stride;
 #pragma unroll
             for (int r = 0; r < B_LD; ++r) ldB(r, t1);
+        }
+    }
+    if constexpr (DEEP3) {
+        if (nsteps > 2) {
+#pragma unroll
+            for (int r = 0; r < B_LD; ++r) ldB2(r, wf4 + 2 * tap_stride);
         }
     }
     __syncthreads();
@@ -459,6 +479,9 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a
             const int tap2 = (tap + 2) % NTAPS, adv2 = (tap + 2) / NTAPS;
             const bool more2 = chunk + adv2 < nchunks;
             const f32x4 *tile2 = wf4 + (size_t)tap2 * tap_stride + (size_t)(chunk + adv2) * chunk_stride;
+            const int tap3 = (tap + 3) % NTAPS, adv3 = (tap + 3) / NTAPS;
+            const bool more3 = chunk + adv3 < nchunks;
+            const f32x4 *tile3 = wf4 + (size_t)tap3 * tap_stride + (size_t)(chunk + adv3) * chunk_stride;
             const bool ldA_now = (NTAPS == 1 ? next_chunk : (tap == 0 && next_chunk));   // request the next halo tile early
             const bool stA_now = last && next_chunk;
 
@@ -487,15 +510,20 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a
                     if constexpr (!(ABL3 & 1)) {
                         if (slot < B_LD) {
                             if constexpr (GLDS) { if (more) dmaB(slot, tile, bnext); }
-                            else if constexpr (!DEEP) { if (more) ldB(slot, tile); }
+                            else if constexpr (!DEEP && !DEEP3) { if (more) ldB(slot, tile); }
                         }
                         else if (slot < B_LD + A_LD) { if (ldA_now) ldA(slot - B_LD, chunk + 1); }
                     }
                     const int sslot = slot - (NSLOT - B_LD - A_LD);
                     if constexpr (!(ABL3 & 2)) {
                         if (sslot >= 0 && sslot < B_LD) {
+                            if constexpr (DEEP3) {
+                                if ((tap & 1) == 0) { if (more) stB(sslot, bnext); if (more3) ldB(sslot, tile3); }
+                                else { if (more) stB2(sslot, bnext); if (more3) ldB2(sslot, tile3); }
+                            } else {
                             if constexpr (!GLDS) { if (more) stB(sslot, bnext); }
                             if constexpr (DEEP) { if (more2) ldB(sslot, tile2); }
+                            }
                         }
                         else if (sslot >= B_LD) { if (stA_now) stA(sslot - B_LD, abuf ^ 1); }
                     }
@@ -509,6 +537,10 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a
                 for (int r = 0; r < A_LD; ++r) asm volatile("" ::"v"(ra[r]));
             }
             if constexpr (!(ABL3 & 8)) __syncthreads();
+        }
+        if constexpr (DEEP3) {          // odd tap count: the set that comes next is rb2 -> make it rb
+#pragma unroll
+            for (int r = 0; r < B_LD; ++r) { const f32x4 t = rb[r]; rb[r] = rb2[r]; rb2[r] = t; }
         }
     }
     }

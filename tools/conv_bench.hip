@@ -52,6 +52,7 @@ VARW(p22_w4_mw2_nt64, 4, 2, 1, 4, 2, 2, ACT_RELU, false, 4)
 #define P4 PIPE_DEEP
 #define P5 PIPE_GLDS
 #define P6 PIPE_BREG
+#define P7 PIPE_DEEP3
 // conv8/9-shaped (H = 5)
 VARP(h5_plain,      5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P0, 0)
 VARP(h5_plain_kc32, 5, 1, 4, 4, 32, 1, 1, ACT_LEAKY, true, P0, 0)
@@ -65,6 +66,8 @@ VARP(h5_p5,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P5, 0)
 VARP(h5_p5_nt128,   5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, P5, 0)
 VARP(h5_p4_nt128,   5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, P4, 0)
 VARP(h5_p6,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P6, 0)
+VARP(h5_p7,         5, 1, 4, 4, 16, 1, 1, ACT_LEAKY, true, P7, 0)
+VARP(h5_p7_nt128,   5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, P7, 0)
 VARP(h5_p3_mw2,     5, 2, 2, 4, 16, 1, 1, ACT_LEAKY, true, P3, 0)
 VARP(h5_p4_mw2,     5, 2, 2, 4, 16, 1, 1, ACT_LEAKY, true, P4, 0)
 VARP(h5_p6_nt128,   5, 1, 2, 4, 16, 1, 1, ACT_LEAKY, true, P6, 0)
@@ -83,6 +86,7 @@ VARP(h10_p3_th5,    5, 1, 4, 4, 16, 1, 1, ACT_RELU, false, P3, 0)
 VARP(h10_p4,        10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P4, 0)
 VARP(h10_p5,        10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P5, 0)
 VARP(h10_p6,        10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P6, 0)
+VARP(h10_p7,        10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P7, 0)
 VARP(h10_p6_th5,    5, 1, 4, 4, 16, 1, 1, ACT_RELU, false, P6, 0)
 // conv3-shaped (H = 20, no pool) and conv2/4 (pool 2x2)
 VARP(h20_plain,     4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, P0, 0)
@@ -90,6 +94,7 @@ VARP(h20_p3,        4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, P3, 0)
 VARP(h20_p3_th10,   10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, P3, 0)
 VARP(h20_p4,        4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, P4, 0)
 VARP(h20_p6,        4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, P6, 0)
+VARP(h20_p7,        4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, P7, 0)
 VARP(p22_plain,     4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P0, 0)
 VARP(p22_plain_nt64, 4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, P0, 0)
 VARP(p22_p3,        4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P3, 0)
@@ -99,6 +104,8 @@ VARP(p22_p4,        4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P4, 0)
 VARP(p22_p5,        4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P5, 0)
 VARP(p22_p5_nt64,   4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, P5, 0)
 VARP(p22_p6,        4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P6, 0)
+VARP(p22_p7,        4, 2, 2, 4, 16, 2, 2, ACT_RELU, false, P7, 0)
+VARP(p22_p7_nt64,   4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, P7, 0)
 VARP(p22_p6_nt64,   4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, P6, 0)
 VARP(p22_p4_nt64,   4, 4, 1, 4, 16, 2, 2, ACT_RELU, false, P4, 0)
 
@@ -119,21 +126,21 @@ int main(int argc, char **argv) {
                             {"interleaved NT64", h5_p3_nt64, 64}, {"interleaved NT128, 3 waves/SIMD", h5_w3_nt128, 128},
                             {"interleaved NT64, 4 waves/SIMD", h5_w4_nt64, 64}, {"interleaved NT256 forced 3 waves/SIMD", h5_w3_nt256, 256}, {"deep prefetch", h5_p4, 256}, {"glds weights", h5_p5, 256}, {"glds weights NT128", h5_p5_nt128, 128}, {"deep prefetch NT128", h5_p4_nt128, 128},
                             {"weights in registers (BREG)", h5_p6, 256}, {"BREG NT128", h5_p6_nt128, 128},
-                            {"interleaved MW2 NS2 NT128", h5_p3_mw2, 128}, {"deep MW2 NS2 NT128", h5_p4_mw2, 128},
+                            {"deep3 prefetch", h5_p7, 256}, {"deep3 prefetch NT128", h5_p7_nt128, 128}, {"interleaved MW2 NS2 NT128", h5_p3_mw2, 128}, {"deep MW2 NS2 NT128", h5_p4_mw2, 128},
                             {"ABL no global loads", h5_a1, 256}, {"ABL no LDS writes (loads die too)", h5_a2, 256},
                             {"ABL no loads/writes", h5_a3, 256}, {"ABL no ds_read", h5_a4, 256}, {"ABL no barrier", h5_a8, 256},
                             {"ABL MFMA stream only", h5_a15, 256}, {"ABL loads waited at step end, no writes", h5_a18, 256}};
     else if (layer >= 5) vars = {{"plain TH10 MW1 NS2 NW4 (base)", h10_plain, 128}, {"plain TH5 NS4 NT256", h10_plain_th5, 256},
                             {"interleaved (shipped)", h10_p3, 128}, {"interleaved TH5 NS4 NT256", h10_p3_th5, 256},
-                            {"deep prefetch", h10_p4, 128}, {"glds weights", h10_p5, 128}, {"weights in registers (BREG)", h10_p6, 128}, {"BREG TH5 NS4 NT256", h10_p6_th5, 256}, {"interleaved TH5 NS2 NT128, 3 waves/SIMD", h10_w3, 128}};
+                            {"deep prefetch", h10_p4, 128}, {"glds weights", h10_p5, 128}, {"weights in registers (BREG)", h10_p6, 128}, {"deep3 prefetch", h10_p7, 128}, {"BREG TH5 NS4 NT256", h10_p6_th5, 256}, {"interleaved TH5 NS2 NT128, 3 waves/SIMD", h10_w3, 128}};
     else if (layer == 3) vars = {{"plain TH4 MW2 NS2 NW4 (base)", h20_plain, 128}, {"interleaved (shipped)", h20_p3, 128},
-                            {"interleaved TH10 MW1", h20_p3_th10, 128}, {"deep prefetch", h20_p4, 128}, {"weights in registers (BREG)", h20_p6, 128},
+                            {"interleaved TH10 MW1", h20_p3_th10, 128}, {"deep prefetch", h20_p4, 128}, {"weights in registers (BREG)", h20_p6, 128}, {"deep3 prefetch", h20_p7, 128},
                             {"interleaved, 3 waves/SIMD", h20_w3_ns2, 128}, {"interleaved NS1 NT64, 3 waves/SIMD", h20_w3, 64}};
     else if (layer == 2 || layer == 4) vars = {{"plain TH4 MW2 NS2 NW4 NT128 (base)", p22_plain, 128}, {"plain TH4 MW4 NS1 NT64", p22_plain_nt64, 64},
                             {"interleaved NT128 (conv4 shipped)", p22_p3, 128}, {"interleaved NT64 (conv2 shipped)", p22_p3_nt64, 64},
                             {"interleaved TH10 MW1", p22_p3_th10, 128}, {"deep prefetch NT128", p22_p4, 128},
                             {"deep prefetch NT64", p22_p4_nt64, 64}, {"glds NT128", p22_p5, 128}, {"glds NT64", p22_p5_nt64, 64},
-                            {"BREG NT128", p22_p6, 128}, {"BREG NT64", p22_p6_nt64, 64},
+                            {"BREG NT128", p22_p6, 128}, {"BREG NT64", p22_p6_nt64, 64}, {"deep3 NT128", p22_p7, 128}, {"deep3 NT64", p22_p7_nt64, 64},
                             {"interleaved NT64, 3 waves/SIMD", p22_w3_nt64, 64}, {"interleaved NT128, 3 waves/SIMD", p22_w3_nt128, 128},
                             {"interleaved MW2 NT64, 3 waves/SIMD", p22_w3_mw2_nt64, 64}, {"interleaved MW2 NT64, 4 waves/SIMD", p22_w4_mw2_nt64, 64}};
     else { printf("layer %d not covered\n", layer); return 1; }
