@@ -590,6 +590,7 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
         // copied back speculatively now, in stream order: 1.25x the previous launch's count (first launch:
         // 1/3 density); collect tops up the rest in the rare case that was not enough.
         size_t spec = e->sp_prev_total ? e->sp_prev_total + e->sp_prev_total / 4 : cap / 3;
+        if (const char *env = getenv("POCR_SPARSE_SPEC")) spec = (size_t)std::max(1L, atol(env));     // tests: force the top-up path
         spec = std::min(spec, cap);
         const size_t conf_off = off_bytes + ip_bytes;                    // [line_off | indptr | confidence | data | indices]
         const size_t trip_base = (conf_off + (size_t)n * sizeof(float) + 15) / 16 * 16;

@@ -667,3 +667,20 @@ def test_gpu_line_confidence(golden, tmp_path):
     # dense / no_logits modes do not compute it
     eng.process_lines(crops[:3], sparse_logits=False)
     assert eng.line_confidences == [None] * 3
+
+
+@pytest.mark.gpu
+def test_sparse_speculative_copy_top_up_path(golden, tmp_path, monkeypatch):
+    """The CSC triplets are copied back speculatively at launch time; when the guess is too small the rest is fetched
+    at collect time.  Force that path (POCR_SPARSE_SPEC) and compare with the normal one."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    g = golden("ragged")
+    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=g.batch_size)
+    crops = g.crops()
+    t0, m0, c0 = eng.process_lines(crops)
+    conf0 = list(eng.line_confidences)
+    monkeypatch.setenv("POCR_SPARSE_SPEC", "1000")
+    t1, m1, c1 = eng.process_lines(crops)
+    assert t0 == t1 and c0 == c1 and conf0 == eng.line_confidences
+    for a, b in zip(m0, m1):
+        assert a.shape == b.shape and (a != b).nnz == 0
