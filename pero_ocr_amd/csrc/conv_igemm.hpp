@@ -50,6 +50,36 @@ struct LineDesc {            // one text line of a staged chunk (read by conv1_u
 
 struct PixelTile { int32_t line; int32_t ht_wt; };     // ht_wt = (h-tile << 16) | w-tile
 
+// Padding columns.  Left and right of a line's crop the padded row is zero, and far enough from the crop and from
+// the row ends (beyond the receptive field) every conv layer's output there is the SAME column vector for every
+// line: a function of the weights and the row index only.  Those vectors are computed once per engine (a zero
+// line through the conv stack); pixel tiles lying entirely in such a region are left out of the tile tables and
+// pad_fill_kernel writes the constant instead - the very values the conv kernels would produce (each output
+// pixel is an independent fmaf chain over identical inputs).  Transformer-engine batches are padded to >= 1088
+// columns whatever the crop width, so this removes up to half of their conv work.
+struct FillSeg { int32_t layer, line, c0, c1; };        // output columns [c0, c1) of `line` in conv layer `layer`
+
+struct FillArgs {
+    float *act[9];               // conv outputs (ragged NHWC)
+    const float *cvec[9];        // constant column of every layer: [H_out][cout]
+    const int64_t *out_off[9];   // element offset of every line in act[l]
+    const int32_t *lvl_w[3];     // line widths at the three pooling levels
+    int32_t lvl_out[9], h_out[9], cout[9];
+    const FillSeg *segs;
+};
+
+__global__ __launch_bounds__(256) void pad_fill_kernel(FillArgs a) {
+    const FillSeg sg = a.segs[blockIdx.x];
+    const int l = sg.layer, h = blockIdx.y;
+    if (h >= a.h_out[l]) return;
+    const int W = a.lvl_w[a.lvl_out[l]][sg.line], C4 = a.cout[l] / 4;
+    float *dst = a.act[l] + a.out_off[l][sg.line] + ((size_t)h * W + sg.c0) * a.cout[l];
+    const float *src = a.cvec[l] + (size_t)h * a.cout[l];
+    const int total = (sg.c1 - sg.c0) * C4;
+    for (int i = threadIdx.x; i < total; i += 256)
+        reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(src)[i % C4];
+}
+
 struct ConvArgs {
     const float *x;          // input NHWC [n][H][W][cin]
     const float *wfrag;      // fragment-order weights

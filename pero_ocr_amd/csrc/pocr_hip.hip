@@ -163,6 +163,8 @@ struct Slot {
     const int32_t *g_row_t = nullptr;      // [rows] frame index of every row inside its line
     const PixelTile *g_tiles[10]{};
     int g_ntiles[10]{};
+    const FillSeg *g_fill = nullptr; // constant padding columns written by pad_fill_kernel instead of being convolved
+    int g_nfill = 0;
     int64_t act_elems[9]{};          // total elements of every conv output
     int rows = 0, t_max = 0;         // sum of T_i, max T_i
     // activations
@@ -238,6 +240,8 @@ struct pocr_engine {
     std::vector<DecLayer> dec;
     DevBuf dec_embed, dec_out_w, dec_out_b;
     int dec_out_cout16 = 0;
+    DevBuf cconst[9];                // per conv layer: the output column [H_out][cout] far inside zero padding
+    bool pad_skip = false;           // skip + fill constant padding tiles (set once the constants exist)
     int conv_cout16[9]{};
     int agg_cout16 = 0, head_cout16 = 0, proj_cout16 = 0;
     Slot slot[POCR_NUM_SLOTS];
@@ -300,9 +304,23 @@ int run_network(pocr_engine *e, Slot &s) {
         if (&prev != &s && prev.conv_done_valid) HIP_TRY(hipStreamWaitEvent(st, prev.conv_done, 0));
     }
     int h = H;
+    for (int i = 0; i < 9; ++i)
+        if (s.act[i].reserve((size_t)s.act_elems[i] * sizeof(float))) return 1;
+    if (s.g_nfill > 0) {        // constant padding columns of all nine layers in one launch (conv_igemm.hpp: pad_fill_kernel)
+        FillArgs fa{};
+        int hh = H;
+        for (int i = 0; i < 9; ++i) {
+            hh /= kConvPlan[i].ph;
+            fa.act[i] = s.act[i].as<float>(); fa.cvec[i] = e->cconst[i].as<float>(); fa.out_off[i] = s.g_act_off[i];
+            fa.lvl_out[i] = kConvLvlOut[i]; fa.h_out[i] = hh; fa.cout[i] = kConvPlan[i].cout;
+        }
+        for (int k = 0; k < 3; ++k) fa.lvl_w[k] = s.g_lvl_w[k];
+        fa.segs = s.g_fill;
+        hipLaunchKernelGGL(pad_fill_kernel, dim3(s.g_nfill, H), dim3(256), 0, st, fa);
+        HIP_TRY(hipGetLastError());
+    }
     for (int i = 0; i < 9; ++i) {
         const ConvLayer &L = kConvPlan[i];
-        if (s.act[i].reserve((size_t)s.act_elems[i] * sizeof(float))) return 1;
         ConvArgs a{};
         a.H = h; a.Ho = h;
         a.tiles = s.g_tiles[i]; a.n_ptiles = s.g_ntiles[i];
@@ -706,6 +724,38 @@ size_t pocr_num_weight_floats(const pocr_config *c) {
     return t;
 }
 
+static int stage_ragged_impl(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
+                             const int32_t *widths, const int32_t *w_pads, int32_t n, int32_t pad_left,
+                             const int32_t *pad_lefts);
+
+// The constant padding column of every conv layer (conv_igemm.hpp, FillSeg): one all-zero line of 256 columns goes
+// through the network once; column W/2 of every layer's output is far enough from both row ends (26 input pixels
+// of receptive field) to be the value every interior padding column takes.
+static int compute_pad_constants(pocr_engine *e) {
+    const uint8_t dummy = 0;
+    const int64_t off = 0;
+    const int32_t width = 0, w_pad = 256;
+    e->pad_skip = false;
+    if (stage_ragged_impl(e, 0, &dummy, &off, &width, &w_pad, 1, 0, nullptr)) return 1;
+    Slot &s = e->slot[0];
+    s.want_logits = s.want_argmax = s.want_sparse = false;
+    s.s2s_batches = 0; s.s2s_cap = 0;
+    if (run_network(e, s)) return 1;
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    HIP_TRY(hipStreamSynchronize(s.seq_stream));
+    int wl[3] = {w_pad, w_pad / 2, w_pad / 4};
+    for (int l = 0; l < 9; ++l) {
+        const int W = wl[kConvLvlOut[l]], C = kConvPlan[l].cout, Hl = s.act_h[l];
+        if (e->cconst[l].reserve((size_t)Hl * C * sizeof(float))) return 1;
+        HIP_TRY(hipMemcpy2D(e->cconst[l].p, (size_t)C * sizeof(float), s.act[l].as<float>() + (size_t)(W / 2) * C,
+                            (size_t)W * C * sizeof(float), (size_t)C * sizeof(float), (size_t)Hl, hipMemcpyDeviceToDevice));
+    }
+    s.staged = false;
+    s.conv_done_valid = false;
+    e->pad_skip = true;
+    return 0;
+}
+
 int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, int device_id, pocr_engine **out) {
     if (!out) return fail("out is NULL");
     *out = nullptr;
@@ -879,6 +929,10 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         for (int i = 0; i < 256; ++i) lut[i] = (float)i / 255.0f;
         if (upload(e->lut, lut, st)) return bail(1);
     }
+    {   // padding-column constants (POCR_NO_PAD_SKIP=1: convolve every column, for A/B checks)
+        const char *env = getenv("POCR_NO_PAD_SKIP");
+        if (!(env && atoi(env) != 0) && compute_pad_constants(e)) return bail(1);
+    }
     *out = e;
     return 0;
 }
@@ -888,6 +942,7 @@ void pocr_destroy(pocr_engine *e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     for (auto &b : e->conv_w) b.release();
+    for (auto &b : e->cconst) b.release();
     for (auto &b : e->conv_b) b.release();
     for (auto &v : {&e->proj_w, &e->proj_b, &e->whh})
         for (auto &b : *v) b.release();
@@ -933,7 +988,8 @@ void pocr_destroy(pocr_engine *e) {
 int pocr_num_slots(void) { return POCR_NUM_SLOTS; }
 
 // Builds the per-line geometry tables of a staged set of lines (host) and uploads them in one blob.
-static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n) {
+static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n, const int32_t *widths, int32_t pad_left,
+                          const int32_t *pad_lefts) {
     const pocr_config &c = e->cfg;
     const int H = c.height, E = c.conv_out;
     struct Blob {
@@ -961,17 +1017,64 @@ static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n)
     int hh = H;
     std::vector<int64_t> offs(n + 1);
     std::vector<PixelTile> tiles;
+    std::vector<FillSeg> fills;
+    std::vector<char> skipped;
+    // constant padding columns of every line on both sides of its crop, in the coordinates of the current layer's
+    // input: zlo/zhi[side][line].  Level 0: the zero columns themselves; every 3x3 conv shrinks an interval by one
+    // column per side (conservative at the row ends), every width pool halves it inwards.
+    std::vector<int32_t> zlo[2], zhi[2];
+    for (int sd = 0; sd < 2; ++sd) { zlo[sd].assign(n, 0); zhi[sd].assign(n, 0); }
+    const bool skip = e->pad_skip;
+    if (skip)
+        for (int i = 0; i < n; ++i) {
+            const int pl = pad_lefts ? pad_lefts[i] : pad_left;
+            const int c_lo = std::min(pl, w_pads[i]), c_hi = std::min(pl + widths[i], w_pads[i]);
+            zlo[0][i] = 0; zhi[0][i] = c_lo;
+            zlo[1][i] = std::max(c_hi, c_lo); zhi[1][i] = w_pads[i];
+        }
     for (int k = 0; k < 10; ++k) {
         const int th = kConvTH[k], tw = kConvTW[k];
         const int h_in = k < 9 ? hh : hh;                       // aggregation conv: one output row
         const int rows_out = k < 9 ? h_in : 1;
+        const int pw = k < 9 ? kConvPlan[k].pw : 1;
         tiles.clear();
         for (int i = 0; i < n; ++i) {
             const int w_in = lvl[kConvLvlIn[k]][i];
             const int nh = (rows_out + th - 1) / th, nw = (w_in + tw - 1) / tw;
             if (nh > 0x7fff || nw > 0xffff) return fail("line %d is too large for the tile table", i);
+            // constant output columns of this layer (before pooling): the input intervals shrunk by the 3x3 kernel
+            int plo[2] = {0, 0}, phi[2] = {0, 0};
+            if (skip && k < 9)
+                for (int sd = 0; sd < 2; ++sd) {
+                    plo[sd] = std::max(zlo[sd][i] + 1, 0);
+                    phi[sd] = std::min(zhi[sd][i] - 1, w_in);
+                }
+            int fb[2] = {-1, -1}, fe[2] = {-1, -1};             // first / last skipped w-tile per side
+            skipped.assign(nw, 0);
+            for (int b_ = 0; b_ < nw; ++b_) {
+                const int x0 = b_ * tw, x1 = std::min((b_ + 1) * tw, w_in);
+                for (int sd = 0; sd < 2; ++sd)
+                    if (skip && k < 9 && x0 >= plo[sd] && x1 <= phi[sd]) {
+                        if (fb[sd] < 0) fb[sd] = b_;
+                        fe[sd] = b_;
+                        skipped[b_] = 1;
+                    }
+            }
             for (int a_ = 0; a_ < nh; ++a_)
-                for (int b_ = 0; b_ < nw; ++b_) tiles.push_back(PixelTile{i, (a_ << 16) | b_});
+                for (int b_ = 0; b_ < nw; ++b_)
+                    if (!skipped[b_]) tiles.push_back(PixelTile{i, (a_ << 16) | b_});
+            if (k < 9) {
+                const int w_out = lvl[kConvLvlOut[k]][i];
+                for (int sd = 0; sd < 2; ++sd) {
+                    if (fb[sd] >= 0) {
+                        const int c0 = fb[sd] * tw / pw, c1 = std::min(std::min((fe[sd] + 1) * tw, w_in) / pw, w_out);
+                        if (c1 > c0) fills.push_back(FillSeg{k, i, c0, c1});
+                    }
+                    // intervals of the next layer's input (this layer's pooled output)
+                    zlo[sd][i] = std::min((plo[sd] + pw - 1) / pw, w_out);
+                    zhi[sd][i] = std::max(std::min(phi[sd] / pw, w_out), 0);
+                }
+            }
         }
         s.g_ntiles[k] = (int)tiles.size();
         off_tiles[k] = blob.add(tiles.data(), tiles.size() * sizeof(PixelTile));
@@ -1016,11 +1119,14 @@ static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n)
         memcpy(s.sg_host.data() + cap, row_off.data(), (size_t)(n + 1) * sizeof(int32_t));
         memcpy(s.sg_host.data() + 2 * cap + 16, slice_T.data(), slice_T.size() * sizeof(int32_t));
     }
+    const size_t off_fill = blob.add(fills.data(), fills.size() * sizeof(FillSeg));
     if (s.geom.reserve(s.geom_host.size())) return 1;
     const char *d = static_cast<const char *>(s.geom.p);
     for (int k = 0; k < 3; ++k) s.g_lvl_w[k] = reinterpret_cast<const int32_t *>(d + off_lvl[k]);
     for (int k = 0; k < 9; ++k) s.g_act_off[k] = reinterpret_cast<const int64_t *>(d + off_act[k]);
     for (int k = 0; k < 10; ++k) s.g_tiles[k] = reinterpret_cast<const PixelTile *>(d + off_tiles[k]);
+    s.g_fill = reinterpret_cast<const FillSeg *>(d + off_fill);
+    s.g_nfill = (int)fills.size();
     s.g_feat_off = reinterpret_cast<const int64_t *>(d + off_feat);
     (void)off_row; (void)off_slice;
     s.g_line_T = s.seqgeom.as<int32_t>();
@@ -1051,7 +1157,7 @@ static int stage_ragged_impl(pocr_engine *e, int32_t slot, const uint8_t *crops,
         const size_t end = (size_t)crop_offsets[i] + (size_t)H * widths[i] * 3;
         if (end > total) total = end;
     }
-    if (build_geometry(e, s, w_pads, n)) return 1;
+    if (build_geometry(e, s, w_pads, n, widths, pad_left, pad_lefts)) return 1;
     // pinned staging: [LineDesc table | crop pool]; the H2D copies then run asynchronously on the slot's
     // stream (they overlap the other slot's kernels) and the caller's buffers are free on return
     const size_t desc_bytes = (size_t)round_up(n, 4) * sizeof(LineDesc);

@@ -684,3 +684,41 @@ def test_sparse_speculative_copy_top_up_path(golden, tmp_path, monkeypatch):
     assert t0 == t1 and c0 == c1 and conf0 == eng.line_confidences
     for a, b in zip(m0, m1):
         assert a.shape == b.shape and (a != b).nnz == 0
+
+
+@pytest.mark.gpu
+def test_padding_column_skip_is_bit_identical(monkeypatch):
+    """Constant padding columns are filled instead of convolved (conv_igemm.hpp: FillSeg).  Same engine with the
+    optimisation switched off (POCR_NO_PAD_SKIP=1) must give bit-identical activations of every conv layer and logits."""
+    chars = synth.make_charset(50)
+    spec = netspec.NetSpec(num_classes=len(chars) + 1)
+    weights = netspec.pack_weights(spec, netspec.generate_weights(spec, 77))
+    widths = [300, 0, 1, 17, 640, 96, 33, 511, 64, 1000, 200, 5]
+    crops = synth.make_crops(9, widths)
+    pool = np.concatenate([c.reshape(-1) for c in crops])
+    offs = np.concatenate([[0], np.cumsum([c.size for c in crops])[:-1]]).astype(np.int64)
+    cases = [  # (w_pads, pad_left): CTC-style chunk padding, and rows much wider than the crops (transformer-style)
+        ([1088] * len(widths), 32),
+        ([-(-max(w, 1) // 32) * 32 + 64 for w in widths], 32),
+        ([1100, 1088, 1090, 2047, 1088, 1153, 1088, 1088, 1301, 1088, 1088, 1088], 200),
+    ]
+
+    def run(skip):
+        if skip:
+            monkeypatch.delenv("POCR_NO_PAD_SKIP", raising=False)
+        else:
+            monkeypatch.setenv("POCR_NO_PAD_SKIP", "1")
+        eng = _native.NativeEngine(spec, weights, 0)
+        out = []
+        for w_pads, pad_left in cases:
+            eng.slot_stage_ragged(0, pool, offs, np.array(widths, np.int32), w_pads, pad_left)
+            eng.slot_launch(0, want_logits=True, want_argmax=True)
+            logits, amax, labels, lens = eng.slot_collect(0)
+            out.append([eng.debug_read(k) for k in range(10)] + [logits, amax, labels, lens])
+        eng.close()
+        return out
+
+    a, b = run(True), run(False)
+    for ca, cb in zip(a, b):
+        for k, (x, y) in enumerate(zip(ca, cb)):
+            assert x.shape == y.shape and np.array_equal(x, y), f"output {k} differs with padding-column skipping"
