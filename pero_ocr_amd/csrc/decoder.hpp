@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     if constexpr (LNE > 0) {
         // one wave per row, same arithmetic as layernorm_kernel (encoder.hpp)
         constexpr int NV = LNE / 64;
-        for (int rr = wave; rr < 16; rr += 4) {
+#pragma unroll
+        for (int rr = wave; rr < 16; rr += 4) {                   // 4 rows per wave, unrolled: all 8 NV loads in flight at once
             const int row = min(row0 + rr, a.M - 1);
             const float *pa = a.ln_a + (size_t)row * LNE, *pb = a.ln_b + (size_t)row * LNE;
             float v[NV], sum = 0.f;
@@ -93,8 +94,12 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
             }
         }
         __syncthreads();
-        xr[0] = xs + li * XP + 4 * kq;                   // A fragments now come from LDS
     }
+    // A fragment of k-group g, row tile r: from LDS after the LayerNorm prologue, else from global memory
+    auto lda = [&](int r, int g) -> f32x4 {
+        if constexpr (LNE > 0) return *reinterpret_cast<const f32x4 *>(&xs[li * XP + 4 * kq + 16 * g]);
+        else return *reinterpret_cast<const f32x4 *>(xr[r] + 16 * g);
+    };
     const f32x4 *wf = reinterpret_cast<const f32x4 *>(a.wfrag) + lane;
     // two k-groups per iteration: all loads of both groups are issued before the first MFMA
     int kg = wave;
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
         for (int u = 0; u < 2; ++u) {
             const int g = kg + 4 * u;
 #pragma unroll
-            for (int r = 0; r < RM; ++r) av[u][r] = *reinterpret_cast<const f32x4 *>(xr[r] + 16 * g);
+            for (int r = 0; r < RM; ++r) av[u][r] = lda(r, g);
 #pragma unroll
             for (int c = 0; c < CN; ++c) bv[u][c] = wf[((size_t)g * a.cout16 + cf0 + c) * 64];
         }
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     for (; kg < KG; kg += 4) {
         f32x4 av[RM], bv[CN];
 #pragma unroll
-        for (int r = 0; r < RM; ++r) av[r] = *reinterpret_cast<const f32x4 *>(xr[r] + 16 * kg);
+        for (int r = 0; r < RM; ++r) av[r] = lda(r, kg);
 #pragma unroll
         for (int c = 0; c < CN; ++c) bv[c] = wf[((size_t)kg * a.cout16 + cf0 + c) * 64];
 #pragma unroll
