@@ -241,10 +241,11 @@ struct pocr_engine {
     DevBuf dec_embed, dec_out_w, dec_out_b;
     int dec_out_cout16 = 0;
     DevBuf cconst[9];                // per conv layer: the output column [H_out][cout] far inside zero padding
-    bool pad_skip = false;           // skip + fill constant padding tiles (set once the constants exist)
+    bool pad_skip = false;           // skip + fill constant padding tiles (POCR_NO_PAD_SKIP=1 turns it off)
+    bool cconst_ready = false;       // the constants are computed when a launch first needs them
     int conv_cout16[9]{};
     int agg_cout16 = 0, head_cout16 = 0, proj_cout16 = 0;
-    Slot slot[POCR_NUM_SLOTS];
+    Slot slot[POCR_NUM_SLOTS + 1];   // the last one is internal (padding-column constants), not reachable through the API
     int last_slot = 0;               // slot of the most recent launch (stage timings / debug taps)
     size_t sp_prev_total = 0;        // kept entries of the most recent sparse launch (sizes the next speculative copy)
     bool use_graphs = true;          // replay the LSTM recurrence from captured hipGraphs (POCR_NO_GRAPHS=1 disables)
@@ -735,9 +736,11 @@ static int compute_pad_constants(pocr_engine *e) {
     const uint8_t dummy = 0;
     const int64_t off = 0;
     const int32_t width = 0, w_pad = 256;
-    e->pad_skip = false;
-    if (stage_ragged_impl(e, 0, &dummy, &off, &width, &w_pad, 1, 0, nullptr)) return 1;
-    Slot &s = e->slot[0];
+    e->pad_skip = false;                         // this one launch convolves every column
+    const int rc_stage = stage_ragged_impl(e, POCR_NUM_SLOTS, &dummy, &off, &width, &w_pad, 1, 0, nullptr);
+    e->pad_skip = true;
+    if (rc_stage) return 1;
+    Slot &s = e->slot[POCR_NUM_SLOTS];
     s.want_logits = s.want_argmax = s.want_sparse = false;
     s.s2s_batches = 0; s.s2s_cap = 0;
     if (run_network(e, s)) return 1;
@@ -752,7 +755,7 @@ static int compute_pad_constants(pocr_engine *e) {
     }
     s.staged = false;
     s.conv_done_valid = false;
-    e->pad_skip = true;
+    e->cconst_ready = true;
     return 0;
 }
 
@@ -929,9 +932,10 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         for (int i = 0; i < 256; ++i) lut[i] = (float)i / 255.0f;
         if (upload(e->lut, lut, st)) return bail(1);
     }
-    {   // padding-column constants (POCR_NO_PAD_SKIP=1: convolve every column, for A/B checks)
+    {   // padding-column skipping (POCR_NO_PAD_SKIP=1: convolve every column, for A/B checks); the constants
+        // themselves are computed by the first launch that has such columns (stage_ragged_impl)
         const char *env = getenv("POCR_NO_PAD_SKIP");
-        if (!(env && atoi(env) != 0) && compute_pad_constants(e)) return bail(1);
+        e->pad_skip = !(env && atoi(env) != 0);
     }
     *out = e;
     return 0;
@@ -1140,7 +1144,7 @@ static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n,
 static int stage_ragged_impl(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
                              const int32_t *widths, const int32_t *w_pads, int32_t n, int32_t pad_left,
                              const int32_t *pad_lefts) {
-    if (check_slot(e, slot)) return 1;
+    if (slot != POCR_NUM_SLOTS && check_slot(e, slot)) return 1;         // POCR_NUM_SLOTS = the internal slot
     Slot &s = e->slot[slot];
     if (s.in_flight) return fail("slot %d has a launch in flight: collect it first", slot);
     s.staged = false;
@@ -1158,6 +1162,7 @@ static int stage_ragged_impl(pocr_engine *e, int32_t slot, const uint8_t *crops,
         if (end > total) total = end;
     }
     if (build_geometry(e, s, w_pads, n, widths, pad_left, pad_lefts)) return 1;
+    if (s.g_nfill > 0 && !e->cconst_ready && compute_pad_constants(e)) return 1;
     // pinned staging: [LineDesc table | crop pool]; the H2D copies then run asynchronously on the slot's
     // stream (they overlap the other slot's kernels) and the caller's buffers are free on return
     const size_t desc_bytes = (size_t)round_up(n, 4) * sizeof(LineDesc);
@@ -1188,6 +1193,7 @@ static int stage_ragged_impl(pocr_engine *e, int32_t slot, const uint8_t *crops,
 
 int pocr_slot_stage_ragged(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
                            const int32_t *widths, const int32_t *w_pads, int32_t n, int32_t pad_left) {
+    if (check_slot(e, slot)) return 1;
     return stage_ragged_impl(e, slot, crops, crop_offsets, widths, w_pads, n, pad_left, nullptr);
 }
 
