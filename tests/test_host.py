@@ -119,6 +119,15 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(root, f), encoding="utf8").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(root, f)
                 assert "/root/reference" not in src, os.path.join(root, f)
+    # outside the package: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use the oracle
+    for f in os.listdir(os.path.join(REPO, "tools")):
+        if f.endswith(".py"):
+            src = open(os.path.join(REPO, "tools", f), encoding="utf8").read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+            assert "/root/reference" not in src, f
+    bench = open(os.path.join(REPO, "bench.py"), encoding="utf8").read()
+    assert len(re.findall(r"^\s*(?:from|import)\s+oracle\b", bench, re.M)) == 1      # inside cpu_baseline()
+    assert "/root/reference" not in bench
 
 
 def test_export_weights_roundtrip_from_torch_state_dict(tmp_path):
