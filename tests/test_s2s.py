@@ -248,3 +248,28 @@ def test_gpu_s2s_shard_adapter_and_degenerate_inputs(golden, tmp_path):
     # the CTC entry points refuse a sequence-to-sequence engine
     with pytest.raises(RuntimeError):
         eng.net.run_batch(np.zeros((1, g.height, 64, 3), np.uint8))
+
+
+def test_batch_plan_properties_random():
+    """plan_batches vs the oracle's restatement on random width sets, plus structural invariants."""
+    rnd = random.Random(11)
+    for _ in range(200):
+        n = rnd.randint(1, 40)
+        widths = [rnd.choice([1, 5, 31, 32, 33, 300, 640, 1023, 1024, 1025, 1500, 2049, 3000, 5000]) if rnd.random() < 0.5
+                  else rnd.randint(1, 2600) for _ in range(n)]
+        bs = rnd.choice([1, 2, 4, 8, 35])
+        mlw = rnd.choice([512, 1024, 1e10])
+        ours = tengine.plan_batches(widths, 480 * bs, mlw)
+        ref = s2s_oracle.plan_batches(widths, 480 * bs, mlw)
+        assert [(b.line_ids, b.max_width) for b in ours] == [(list(ids), mw) for ids, mw in ref]
+        seen = sorted(i for b in ours for i in b.line_ids)
+        assert seen == list(range(n))                                   # every line exactly once
+        for b in ours:
+            assert b.w_pad >= tengine.MIN_INPUT_WIDTH and b.w_batch <= 480 * bs
+            assert sum(b.spans) == len(b.parts)
+            for (i, a, e_), in zip(b.parts):
+                assert 0 <= a < e_ <= widths[i] and e_ - a <= max(mlw, 1)
+            for i, span in zip(b.line_ids, b.spans):
+                assert [p[1:] for p in b.parts if p[0] == i][:span] == s2s_oracle.split_line(widths[i], mlw)
+        groups = tengine.plan_launches(ours)
+        assert [b for g_ in groups for b in g_] == ours                  # launches keep the batch order
