@@ -190,6 +190,13 @@ int pocr_s2s_collect(pocr_engine *e, int32_t slot, int32_t *tokens, float *logit
 int pocr_s2s_sparse(pocr_engine *e, int32_t slot, const int32_t *row_end, float threshold, int64_t *total_nnz);
 int pocr_s2s_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t *indices, int32_t *indptr, int64_t *line_off);
 
+/* Host-side helper (no GPU): find_best_overlap of the transformer branch (line_ocr_engine.py:196-211, edit distance
+ * pero_ocr/sequence_alignment.py:4-13) on two symbol-id sequences: the overlap length i in 1..min(na, nb) whose
+ * suffix-of-a / prefix-of-b pair has the lowest character error rate (first such i; 0 when none is below 1).
+ * Long lines are recognised in overlapping parts and every seam costs one such search: O(n^3), seconds in the
+ * reference's Python, milliseconds here. */
+int32_t pocr_best_overlap(const int32_t *a, int32_t na, const int32_t *b, int32_t nb);
+
 /* ---- measurement / test taps (not part of the reference surface) ----
  * Per-stage GPU time of the last pocr_run_* call in milliseconds, measured with HIP
  * events on the engine's stream.  Stage ids: POCR_STAGE_*.  Returns the number of

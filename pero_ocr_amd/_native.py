@@ -50,6 +50,7 @@ SYMBOLS = {
     "pocr_run_staged": (C.c_int, [C.c_void_p, _f32p, _i32p, _i32p, _i32p]),
     "pocr_ctc_greedy": (C.c_int, [C.c_int, _f32p, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _i32p]),
     "pocr_sparsify": (C.c_int, [C.c_int, _f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, _f32p, _i32p, C.c_int64, _i32p, _i64p]),
+    "pocr_best_overlap": (C.c_int32, [_i32p, C.c_int32, _i32p, C.c_int32]),
     "pocr_num_slots": (C.c_int, []),
     "pocr_slot_stage_lines": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, C.c_int32, C.c_int32, C.c_int32]),
     "pocr_slot_stage_ragged": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, _i32p, C.c_int32, C.c_int32]),
@@ -366,6 +367,17 @@ def sparsify(logits_ntc: np.ndarray, threshold: float = 1e-4, device_id: int = 0
         raise RuntimeError("pocr_sparsify: " + (lib.pocr_last_error() or b"").decode("utf8", "replace"))
     return [sparse.csc_matrix((data[line_off[i]:line_off[i + 1]].copy(), indices[line_off[i]:line_off[i + 1]].copy(), indptr[i]),
                               shape=(T, Cc)) for i in range(n)]
+
+
+def best_overlap(text1, text2) -> int:
+    """find_best_overlap (line_ocr_engine.py:196-211) in native code; works on str or sequences of hashable symbols."""
+    lib = load()
+    codes = {}
+    a = np.array([codes.setdefault(ch, len(codes)) for ch in text1], dtype=np.int32)
+    b = np.array([codes.setdefault(ch, len(codes)) for ch in text2], dtype=np.int32)
+    if a.size == 0 or b.size == 0:
+        return 0
+    return int(lib.pocr_best_overlap(_ptr(a, _i32p), int(a.size), _ptr(b, _i32p), int(b.size)))
 
 
 def device_count() -> int:

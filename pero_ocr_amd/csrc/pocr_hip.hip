@@ -1704,6 +1704,36 @@ int pocr_sparsify(int device_id, const float *logits_ntc, int32_t n, int32_t T, 
     return done(0);
 }
 
+// ---- host-side helper of the transformer branch: find_best_overlap (line_ocr_engine.py:196-211) with the unit-cost
+// edit distance of pero_ocr/sequence_alignment.py:4-13.  For i = 1 .. min(na, nb): cer_i = lev(a[na-i:], b[:i]) / i;
+// returns the first i with the smallest cer below 1, or 0.  The ratios are compared exactly (cross-multiplied
+// integers), which orders them like the reference's float divisions.  O(n^3) scalar work: ~10 ms for two
+// 270-symbol parts (the reference's numpy/Python version needs seconds), no GPU involved.
+int32_t pocr_best_overlap(const int32_t *a, int32_t na, const int32_t *b, int32_t nb) {
+    if (!a || !b || na <= 0 || nb <= 0) return 0;
+    const int n = std::min(na, nb);
+    std::vector<int32_t> prev(n + 1), cur(n + 1);
+    int64_t best_num = 1, best_den = 1;      // best cer so far = best_num / best_den (starts at 1)
+    int32_t best = 0;
+    for (int i = 1; i <= n; ++i) {
+        const int32_t *x = a + (na - i);     // suffix of a, length i
+        for (int q = 0; q <= i; ++q) prev[q] = q;
+        for (int p = 1; p <= i; ++p) {
+            cur[0] = p;
+            const int32_t xp = x[p - 1];
+            for (int q = 1; q <= i; ++q) {
+                const int32_t sub = prev[q - 1] + (xp != b[q - 1]);
+                const int32_t del = prev[q] + 1, ins = cur[q - 1] + 1;
+                cur[q] = std::min(sub, std::min(del, ins));
+            }
+            std::swap(prev, cur);
+        }
+        const int64_t d = prev[i];
+        if (d * best_den < best_num * i) { best_num = d; best_den = i; best = i; }     // d / i < best_num / best_den
+    }
+    return best;
+}
+
 int pocr_set_profiling(pocr_engine *e, int32_t enabled) {
     if (!e) return fail("engine is NULL");
     e->profiling = enabled != 0;

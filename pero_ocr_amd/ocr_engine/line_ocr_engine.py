@@ -248,7 +248,13 @@ def levenshtein_distance(source, target) -> int:
 
 def find_best_overlap(text1, text2) -> int:
     """Length i (1..min(len)) of the suffix of text1 / prefix of text2 with the lowest character error
-    rate; the first such i wins; 0 when no rate is below 1 (line_ocr_engine.py:196-211)."""
+    rate; the first such i wins; 0 when no rate is below 1 (line_ocr_engine.py:196-211).  The search is
+    O(n^3); it runs in the native library (pocr_best_overlap), find_best_overlap_py is the same in numpy."""
+    from .. import _native
+    return _native.best_overlap(text1, text2)
+
+
+def find_best_overlap_py(text1, text2) -> int:
     best_cer, best = 1, 0
     for i in range(1, min(len(text1), len(text2)) + 1):
         cer = levenshtein_distance(list(text1[-i:]), list(text2[:i])) / i

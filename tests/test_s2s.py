@@ -31,7 +31,11 @@ def test_edit_distance_and_overlap_match_oracle():
         a = "".join(rnd.choice("abcd") for _ in range(rnd.randint(0, 14)))
         b = "".join(rnd.choice("abcd") for _ in range(rnd.randint(0, 14)))
         assert host.levenshtein_distance(list(a), list(b)) == s2s_oracle.edit_distance(a, b)
-        assert host.find_best_overlap(a, b) == s2s_oracle.best_overlap(a, b)
+        assert host.find_best_overlap(a, b) == s2s_oracle.best_overlap(a, b)          # native (pocr_best_overlap)
+        assert host.find_best_overlap_py(a, b) == s2s_oracle.best_overlap(a, b)       # numpy
+    long1 = "".join(rnd.choice("abcdefgh ") for _ in range(270))
+    long2 = long1[-60:] + "".join(rnd.choice("abcdefgh ") for _ in range(200))
+    assert host.find_best_overlap(long1, long2) == s2s_oracle.best_overlap(long1, long2) == 60
     assert host.levenshtein_distance("kitten", "sitting") == 3
     assert host.find_best_overlap("hello wor", "o world") == 5      # "o wor" == "o wor"
 
