@@ -1,6 +1,6 @@
 """End-to-end throughput of the sequence-to-sequence engine on one MI355X:
 TransformerEngineLineOCR.process_lines on synthetic crops / seeded weights.
-usage: python tools/s2s_bench.py [n_lines] [width] [batch_size] [dec_layers] [boundary_bias] [lines_per_launch]"""
+usage: python tools/s2s_bench.py [n_lines] [width | 0 = ragged 128..2000] [batch_size] [dec_layers] [boundary_bias] [lines_per_launch]"""
 import json
 import os
 import sys
@@ -34,7 +34,8 @@ def main():
             json.dump({"line_px_height": 40, "line_vertical_scale": 1.0, "checkpoint": "absent", "characters": chars,
                        "net_name": net, "max_line_width": 1024, "net": {"weight_seed": 20261002, "boundary_bias": bias}}, f)
         eng = TransformerEngineLineOCR(path, torch.device("cuda:0"), batch_size=batch_size)
-    crops = synth.make_crops(602, [width] * n, 40)
+    widths = synth.make_widths(602, n, 128, 2000) if width == 0 else [width] * n      # width 0: ragged 128..2000 px
+    crops = synth.make_crops(602, widths, 40)
     eng.process_lines(crops[:64], no_logits=True)            # warm-up
     out = {}
     for mode, kw in (("no_logits", dict(no_logits=True)), ("dense", dict(sparse_logits=False)), ("sparse", {})):
