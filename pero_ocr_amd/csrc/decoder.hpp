@@ -68,6 +68,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     if constexpr (LNE > 0) {
         // one wave per row, same arithmetic as layernorm_kernel (encoder.hpp)
         constexpr int NV = LNE / 64;
+        float gam[NV], bet[NV];                                    // fetched alongside the rows, not after the reductions
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { gam[k] = a.gamma[lane + 64 * k]; bet[k] = a.beta[lane + 64 * k]; }
 #pragma unroll
         for (int rr = wave; rr < 16; rr += 4) {                   // 4 rows per wave, unrolled: all 8 NV loads in flight at once
             const int row = min(row0 + rr, a.M - 1);
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int e = lane + 64 * k;
-                const float o = (v[k] - mean) * rstd * a.gamma[e] + a.beta[e];
+                const float o = (v[k] - mean) * rstd * gam[k] + bet[k];
                 xs[rr * XP + e] = o;
                 if (store) a.ln_out[(size_t)(row0 + rr) * LNE + e] = o;
             }
@@ -101,12 +104,14 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
         else return *reinterpret_cast<const f32x4 *>(xr[r] + 16 * g);
     };
     const f32x4 *wf = reinterpret_cast<const f32x4 *>(a.wfrag) + lane;
-    // two k-groups per iteration: all loads of both groups are issued before the first MFMA
+    // U k-groups per iteration: the step is a chain of L2 round trips, so all operand loads of a batch are issued
+    // before its first MFMA (K = 512: one batch per wave; the registers bound U)
+    constexpr int U = (RM + CN <= 3) ? 8 : 4;
     int kg = wave;
-    for (; kg + 4 < KG; kg += 8) {
-        f32x4 av[2][RM], bv[2][CN];
+    for (; kg + 4 * (U - 1) < KG; kg += 4 * U) {
+        f32x4 av[U][RM], bv[U][CN];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int g = kg + 4 * u;
 #pragma unroll
             for (int r = 0; r < RM; ++r) av[u][r] = lda(r, g);
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
             for (int c = 0; c < CN; ++c) bv[u][c] = wf[((size_t)g * a.cout16 + cf0 + c) * 64];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -183,32 +188,42 @@ struct DecAttnArgs {
 template <int D>
 __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnArgs a) {
     static_assert(D == 32 || D == 64 || D == 128, "head dim");
+    // A key / value row of one head is D floats = LPR lanes x 16 bytes; a wave instruction therefore fetches RPW whole
+    // rows, fully coalesced (one lane per 16 bytes instead of one lane per row).
+    constexpr int LPR = D / 4, RPW = 64 / LPR;
     const int head = blockIdx.x, line = blockIdx.y;
     const int go = a.stop ? *a.stop : 1, done = a.line_done[line];      // fetched alongside q
-    __shared__ float qs[D];
     __shared__ float sc[DEC_MAX_KEYS];
     __shared__ float red[8];
-    __shared__ float opart[4][D];
+    __shared__ f32x4 opart[4][LPR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane % LPR, g = lane / LPR;
     const int S = a.line_len ? a.line_len[line] : a.len;
-    const size_t base = (a.row_off ? (size_t)a.row_off[line] * a.pos_stride : (size_t)line * a.line_stride) + (size_t)head * D;
-    const float qv0 = tid < D ? a.q[(size_t)line * a.ldq + head * D + tid] : 0.f;
+    const size_t base = (a.row_off ? (size_t)a.row_off[line] * a.pos_stride : (size_t)line * a.line_stride) + (size_t)head * D + 4 * li;
+    f32x4 qv = *reinterpret_cast<const f32x4 *>(a.q + (size_t)line * a.ldq + head * D + 4 * li);
     if (go == 0 || done) return;
-    if (tid < D) qs[tid] = qv0 * a.scale;                                             // q * d^-1/2 first (transformer.py:268)
+    qv *= a.scale;                                                      // q * d^-1/2 first (transformer.py:268)
+    // ---- scores: wave w takes the keys p = (w + 4 i) * RPW + g
+    constexpr int US = 4;
+    for (int p0 = wave * RPW; p0 < S; p0 += 4 * RPW * US) {
+        f32x4 kv[US];
+#pragma unroll
+        for (int u = 0; u < US; ++u) {
+            const int p = p0 + 4 * RPW * u + g;
+            kv[u] = *reinterpret_cast<const f32x4 *>(a.k + base + (size_t)min(p, S - 1) * a.pos_stride);
+        }
+#pragma unroll
+        for (int u = 0; u < US; ++u) {
+            const int p = p0 + 4 * RPW * u + g;
+            float dot = kv[u][0] * qv[0] + kv[u][1] * qv[1] + kv[u][2] * qv[2] + kv[u][3] * qv[3];
+#pragma unroll
+            for (int off = 1; off < LPR; off <<= 1) dot += __shfl_xor(dot, off, 64);
+            if (li == 0 && p < S) sc[p] = dot;
+        }
+    }
     __syncthreads();
     float m = -INFINITY;
-    for (int p = tid; p < S; p += 256) {
-        const f32x4 *kp = reinterpret_cast<const f32x4 *>(a.k + base + (size_t)p * a.pos_stride);
-        float dot = 0.f;
-#pragma unroll
-        for (int d4 = 0; d4 < D / 4; ++d4) {
-            const f32x4 kv = kp[d4];
-            const f32x4 qv = *reinterpret_cast<const f32x4 *>(&qs[4 * d4]);
-            dot += kv[0] * qv[0] + kv[1] * qv[1] + kv[2] * qv[2] + kv[3] * qv[3];
-        }
-        sc[p] = dot;
-        m = fmaxf(m, dot);
-    }
+    for (int p = tid; p < S; p += 256) m = fmaxf(m, sc[p]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if (lane == 0) red[wave] = m;
@@ -225,43 +240,31 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnArgs a) {
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
     sum = red[4] + red[5] + red[6] + red[7];
-    // weighted sum of the values: wave w takes the positions p = w, w + 4, ...; a lane owns one (or two) of the D outputs
-    constexpr int PS = D < 64 ? 64 / D : 1;          // positions handled side by side inside a wave
-    constexpr int DL = D > 64 ? D / 64 : 1;          // outputs per lane
-    const int d = lane % D, sub = lane / D;
-    float acc[DL];
+    // ---- weighted sum of the values, same key -> lane mapping; a lane accumulates its 4 outputs
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int UV = 8;
+    for (int p0 = wave * RPW; p0 < S; p0 += 4 * RPW * UV) {
+        f32x4 vv[UV];
+        float pr[UV];
 #pragma unroll
-    for (int k = 0; k < DL; ++k) acc[k] = 0.f;
-    const float *vb = a.v + base + d;
-    constexpr int U = 8;
-    for (int p0 = (wave * PS + sub); p0 < S; p0 += 4 * PS * U) {
-        float vv[U][DL], pr[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int p = p0 + 4 * PS * u;
-            const bool ok = p < S;
-            pr[u] = ok ? sc[p] : 0.f;
-            const float *vp = vb + (size_t)(ok ? p : 0) * a.pos_stride;
-#pragma unroll
-            for (int k = 0; k < DL; ++k) vv[u][k] = vp[64 * k];
+        for (int u = 0; u < UV; ++u) {
+            const int p = p0 + 4 * RPW * u + g;
+            pr[u] = p < S ? sc[p] : 0.f;
+            vv[u] = *reinterpret_cast<const f32x4 *>(a.v + base + (size_t)min(p, S - 1) * a.pos_stride);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int k = 0; k < DL; ++k) acc[k] += pr[u] * vv[u][k];
+        for (int u = 0; u < UV; ++u) acc += vv[u] * pr[u];
     }
-    if (PS > 1) {
 #pragma unroll
-        for (int k = 0; k < DL; ++k) acc[k] += __shfl_xor(acc[k], 32, 64);
+    for (int off = LPR; off < 64; off <<= 1) {
+        acc[0] += __shfl_xor(acc[0], off, 64); acc[1] += __shfl_xor(acc[1], off, 64);
+        acc[2] += __shfl_xor(acc[2], off, 64); acc[3] += __shfl_xor(acc[3], off, 64);
     }
-    if (sub == 0) {
-#pragma unroll
-        for (int k = 0; k < DL; ++k) opart[wave][d + 64 * k] = acc[k];
-    }
+    if (g == 0) opart[wave][li] = acc;
     __syncthreads();
-    if (tid < D) {
-        const float o = (opart[0][tid] + opart[1][tid] + opart[2][tid] + opart[3][tid]) / sum;
-        a.out[(size_t)line * a.E + head * D + tid] = o;
+    if (tid < LPR) {
+        const f32x4 o = (opart[0][tid] + opart[1][tid] + opart[2][tid] + opart[3][tid]) / sum;
+        *reinterpret_cast<f32x4 *>(a.out + (size_t)line * a.E + head * D + 4 * tid) = o;
     }
 }
 
