@@ -44,15 +44,15 @@ struct SkinnyArgs {
     float eps;
 };
 
-template <int RM, int CN, bool RELU, int LNE = 0>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
+template <int RM, int CN, bool RELU, int LNE = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(SkinnyArgs a) {
     static_assert(LNE == 0 || RM == 1, "the LayerNorm prologue works on one 16-row tile");
     constexpr int XP = LNE + 4;                          // LDS row pitch of the normalised rows
     __shared__ float xs[LNE > 0 ? 16 * XP : 4];
     // the stop flag is fetched together with the first operands and tested after the K loop: one memory
     // round trip less on the critical path of every decoding step
     const int go = a.stop ? *a.stop : 1;
-    __shared__ float part[4 * RM * CN * 256];            // [wave][fragment][lane][reg]
+    __shared__ float part[NW * RM * CN * 256];           // [wave][fragment][lane][reg]; NW waves split K (8 for long K)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int row0 = blockIdx.y * 16 * RM, cf0 = blockIdx.x * CN;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) { gam[k] = a.gamma[lane + 64 * k]; bet[k] = a.beta[lane + 64 * k]; }
 #pragma unroll
-        for (int rr = wave; rr < 16; rr += 4) {                   // 4 rows per wave, unrolled: all 8 NV loads in flight at once
+        for (int rr = wave; rr < 16; rr += NW) {                   // 4 rows per wave, unrolled: all 8 NV loads in flight at once
             const int row = min(row0 + rr, a.M - 1);
             const float *pa = a.ln_a + (size_t)row * LNE, *pb = a.ln_b + (size_t)row * LNE;
             float v[NV], sum = 0.f;
@@ -107,12 +107,19 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     // U k-groups per iteration: the step is a chain of L2 round trips, so all operand loads of a batch are issued
     // before its first MFMA (K = 512: one batch per wave; the registers bound U)
     constexpr int U = (RM + CN <= 3) ? 8 : 4;
+    // the epilogue's bias is requested now, not after the reduction
+    float bias_v[(RM * CN * 64 + NW * 64 - 1) / (NW * 64)];
+#pragma unroll
+    for (int it = 0; it < (RM * CN * 64 + NW * 64 - 1) / (NW * 64); ++it) {
+        const int item = tid + it * NW * 64;
+        bias_v[it] = item < RM * CN * 64 ? a.bias[(cf0 + (item >> 6) % CN) * 16 + (item & 15)] : 0.f;
+    }
     int kg = wave;
-    for (; kg + 4 * (U - 1) < KG; kg += 4 * U) {
+    for (; kg + NW * (U - 1) < KG; kg += NW * U) {
         f32x4 av[U][RM], bv[U][CN];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int g = kg + 4 * u;
+            const int g = kg + NW * u;
 #pragma unroll
             for (int r = 0; r < RM; ++r) av[u][r] = lda(r, g);
 #pragma unroll
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
                     for (int c = 0; c < CN; ++c)
                         acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r][j], bv[u][c][j], acc[r][c], 0, 0, 0);
     }
-    for (; kg < KG; kg += 4) {
+    for (; kg < KG; kg += NW) {
         f32x4 av[RM], bv[CN];
 #pragma unroll
         for (int r = 0; r < RM; ++r) av[r] = lda(r, kg);
@@ -150,14 +157,17 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
             *reinterpret_cast<f32x4 *>(&part[((wave * RM * CN + r * CN + c) * 64 + lane) * 4]) = acc[r][c];
     __syncthreads();
     // D layout of a 16x16 fragment: lane -> column lane & 15, rows 4 (lane >> 4) + reg
-    for (int item = tid; item < RM * CN * 64; item += 256) {
+#pragma unroll
+    for (int it = 0; it < (RM * CN * 64 + NW * 64 - 1) / (NW * 64); ++it) {
+        const int item = tid + it * NW * 64;
+        if (item >= RM * CN * 64) break;
         const int f = item >> 6, ln = item & 63;
         f32x4 v = *reinterpret_cast<const f32x4 *>(&part[((0 * RM * CN + f) * 64 + ln) * 4]);
 #pragma unroll
-        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4 *>(&part[((w * RM * CN + f) * 64 + ln) * 4]);
+        for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4 *>(&part[((w * RM * CN + f) * 64 + ln) * 4]);
         const int r = f / CN, c = f % CN;
         const int col = (cf0 + c) * 16 + (ln & 15);
-        const float b = a.bias[col];
+        const float b = bias_v[it];
         if (col < a.cout_valid) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

@@ -659,6 +659,11 @@ int launch_skinny(SkinnyArgs a, hipStream_t st) {
     const int c16 = a.cout16;
     auto wgs = [&](int rm, int cn) { return ((a.M + 16 * rm - 1) / (16 * rm)) * (c16 / cn); };
     // the largest tile that still gives every CU a workgroup; small problems take the smallest tile
+    if (a.K >= 1024 && c16 % 2 == 0 && wgs(1, 2) >= 128) {     // long K, few columns (the second feed-forward GEMM): eight waves split K
+        hipLaunchKernelGGL((skinny_gemm_kernel<1, 2, RELU, 0, 8>), dim3(c16 / 2, (a.M + 15) / 16), dim3(512), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (c16 % 4 == 0 && wgs(2, 4) >= 256) hipLaunchKernelGGL((skinny_gemm_kernel<2, 4, RELU>), dim3(c16 / 4, (a.M + 31) / 32), dim3(256), 0, st, a);
     else if (c16 % 2 == 0 && wgs(2, 2) >= 256) hipLaunchKernelGGL((skinny_gemm_kernel<2, 2, RELU>), dim3(c16 / 2, (a.M + 31) / 32), dim3(256), 0, st, a);
     else if (c16 % 2 == 0 && wgs(1, 2) >= 256) hipLaunchKernelGGL((skinny_gemm_kernel<1, 2, RELU>), dim3(c16 / 2, (a.M + 15) / 16), dim3(256), 0, st, a);
