@@ -89,18 +89,36 @@ def plan_batches(widths: Sequence[int], max_input_horizontal_pixels: int, max_li
 
 
 def plan_launches(batches: Sequence[_Batch]) -> List[List[_Batch]]:
-    out, cur, lines, cols = [], [], 0, 0
-    for b in batches:
-        n, c = len(b.parts), len(b.parts) * b.w_pad
-        if cur and (lines + n > LAUNCH_MAX_LINES or cols + c > LAUNCH_MAX_COLUMNS):
+    """Consecutive batches grouped into device launches.  A launch decodes all its lines side by side and a decoding
+    step costs about the same for 2 lines as for 256, so the greedy packing (fill up to the caps) is evened out
+    afterwards: the same number of launches, but of similar size instead of full ones and a small remainder."""
+    def pack(max_lines, max_cols):
+        out, cur, lines, cols = [], [], 0, 0
+        for b in batches:
+            n, c = len(b.parts), len(b.parts) * b.w_pad
+            if cur and (lines + n > max_lines or cols + c > max_cols):
+                out.append(cur)
+                cur, lines, cols = [], 0, 0
+            cur.append(b)
+            lines += n
+            cols += c
+        if cur:
             out.append(cur)
-            cur, lines, cols = [], 0, 0
-        cur.append(b)
-        lines += n
-        cols += c
-    if cur:
-        out.append(cur)
-    return out
+        return out
+
+    greedy = pack(LAUNCH_MAX_LINES, LAUNCH_MAX_COLUMNS)
+    k = len(greedy)
+    if k <= 1:
+        return greedy
+    total_lines = sum(len(b.parts) for b in batches)
+    total_cols = sum(len(b.parts) * b.w_pad for b in batches)
+    biggest = max(len(b.parts) for b in batches)
+    for slack in (1.0, 1.1, 1.25, 1.5):
+        even = pack(min(LAUNCH_MAX_LINES, int(total_lines / k * slack) + biggest),
+                    min(LAUNCH_MAX_COLUMNS, int(total_cols / k * slack) + biggest * max(b.w_pad for b in batches)))
+        if len(even) == k:
+            return even
+    return greedy
 
 
 class TransformerEngineLineOCR(BaseEngineLineOCR):
