@@ -190,6 +190,15 @@ int pocr_s2s_collect(pocr_engine *e, int32_t slot, int32_t *tokens, float *logit
 int pocr_s2s_sparse(pocr_engine *e, int32_t slot, const int32_t *row_end, float threshold, int64_t *total_nnz);
 int pocr_s2s_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t *indices, int32_t *indptr, int64_t *line_off);
 
+/* ---- line cropper remap: replaces cv2.remap(img, map_x, map_y, INTER_LINEAR, BORDER_CONSTANT)
+ * in EngineLineCropper.fast_remap (pero_ocr/core/crop_engine.py:146-163) for all lines of a page in one call.
+ * page_hwc uint8 [H][W][C] (C <= 4); line i: coords + coord_off[i] = float32 [line_height][widths[i]][2] (x, y) source
+ * position of every crop pixel (what get_crop_inputs returns, :54-99); its crop uint8 [line_height][widths[i]][C] is
+ * written at crops + crop_off[i].  OpenCV's 8-bit fixed-point bilinear arithmetic (see csrc/crop.hpp).  No engine needed. */
+int pocr_crop_lines(int device_id, const uint8_t *page_hwc, int32_t H, int32_t W, int32_t C, const float *coords,
+                    const int64_t *coord_off, const int32_t *widths, int32_t n, int32_t line_height, uint8_t *crops,
+                    const int64_t *crop_off);
+
 /* Host-side helper (no GPU): find_best_overlap of the transformer branch (line_ocr_engine.py:196-211, edit distance
  * pero_ocr/sequence_alignment.py:4-13) on two symbol-id sequences: the overlap length i in 1..min(na, nb) whose
  * suffix-of-a / prefix-of-b pair has the lowest character error rate (first such i; 0 when none is below 1).

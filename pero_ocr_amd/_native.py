@@ -51,6 +51,7 @@ SYMBOLS = {
     "pocr_ctc_greedy": (C.c_int, [C.c_int, _f32p, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _i32p]),
     "pocr_sparsify": (C.c_int, [C.c_int, _f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, _f32p, _i32p, C.c_int64, _i32p, _i64p]),
     "pocr_best_overlap": (C.c_int32, [_i32p, C.c_int32, _i32p, C.c_int32]),
+    "pocr_crop_lines": (C.c_int, [C.c_int, _u8p, C.c_int32, C.c_int32, C.c_int32, _f32p, _i64p, _i32p, C.c_int32, C.c_int32, _u8p, _i64p]),
     "pocr_num_slots": (C.c_int, []),
     "pocr_slot_stage_lines": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, C.c_int32, C.c_int32, C.c_int32]),
     "pocr_slot_stage_ragged": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, _i32p, C.c_int32, C.c_int32]),
@@ -378,6 +379,32 @@ def best_overlap(text1, text2) -> int:
     if a.size == 0 or b.size == 0:
         return 0
     return int(lib.pocr_best_overlap(_ptr(a, _i32p), int(a.size), _ptr(b, _i32p), int(b.size)))
+
+
+def crop_lines(page: np.ndarray, grids, device_id: int = 0):
+    """page uint8 [H, W, C]; grids: list of float32 [line_h, w_i, 2] (x, y) -> list of uint8 [line_h, w_i, C] crops
+    (cv2.remap INTER_LINEAR / BORDER_CONSTANT arithmetic) in one GPU call."""
+    lib = load()
+    img = np.ascontiguousarray(page, dtype=np.uint8)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    H, W, Cc = img.shape
+    if not grids:
+        return []
+    line_h = int(grids[0].shape[0])
+    flat = [np.ascontiguousarray(g, dtype=np.float32).reshape(-1) for g in grids]
+    widths = np.array([g.shape[1] for g in grids], dtype=np.int32)
+    coord_off = np.concatenate([[0], np.cumsum([f.size for f in flat])[:-1]]).astype(np.int64)
+    sizes = widths.astype(np.int64) * line_h * Cc
+    crop_off = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    coords = np.concatenate(flat) if flat else np.zeros(0, np.float32)
+    if coords.size == 0:
+        coords = np.zeros(2, np.float32)
+    out = np.zeros(max(1, int(sizes.sum())), dtype=np.uint8)
+    if lib.pocr_crop_lines(int(device_id), _ptr(img, _u8p), H, W, Cc, _ptr(coords, _f32p), _ptr(coord_off, _i64p), _ptr(widths, _i32p),
+                           int(widths.size), line_h, _ptr(out, _u8p), _ptr(crop_off, _i64p)):
+        raise RuntimeError("pocr_crop_lines: " + (lib.pocr_last_error() or b"").decode("utf8", "replace"))
+    return [out[int(o):int(o + s)].reshape(line_h, int(w), Cc).copy() for o, s, w in zip(crop_off, sizes, widths)]
 
 
 def device_count() -> int:

@@ -19,6 +19,7 @@
 #include "ctc.hpp"
 #include "encoder.hpp"
 #include "decoder.hpp"
+#include "crop.hpp"
 #include "lstm.hpp"
 #include "sparsify.hpp"
 
@@ -1737,6 +1738,42 @@ int32_t pocr_best_overlap(const int32_t *a, int32_t na, const int32_t *b, int32_
         if (d * best_den < best_num * i) { best_num = d; best_den = i; best = i; }     // d / i < best_num / best_den
     }
     return best;
+}
+
+int pocr_crop_lines(int device_id, const uint8_t *page_hwc, int32_t H, int32_t W, int32_t C, const float *coords,
+                    const int64_t *coord_off, const int32_t *widths, int32_t n, int32_t line_height, uint8_t *crops,
+                    const int64_t *crop_off) {
+    if (!page_hwc || !coords || !coord_off || !widths || !crops || !crop_off) return fail("NULL pointer");
+    if (H <= 0 || W <= 0 || C < 1 || C > 4 || line_height <= 0 || n <= 0) return fail("bad geometry (H %d, W %d, C %d, line height %d, n %d)", H, W, C, line_height, n);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available: this library has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail("device_id %d out of range (%d devices)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    std::vector<CropLine> tab(n);
+    int64_t n_coord = 0, n_out = 0;
+    int w_max = 0;
+    for (int i = 0; i < n; ++i) {
+        if (widths[i] < 0 || coord_off[i] < 0 || crop_off[i] < 0) return fail("line %d: negative width / offset", i);
+        tab[i] = CropLine{coord_off[i], crop_off[i], widths[i], 0};
+        n_coord = std::max<int64_t>(n_coord, coord_off[i] + (int64_t)line_height * widths[i] * 2);
+        n_out = std::max<int64_t>(n_out, crop_off[i] + (int64_t)line_height * widths[i] * C);
+        w_max = std::max(w_max, widths[i]);
+    }
+    if (w_max == 0) return 0;
+    DevBuf dpage, dcoord, dtab, dout;
+    const size_t page_bytes = (size_t)H * W * C;
+    int rc = dpage.reserve(page_bytes) || dcoord.reserve((size_t)n_coord * sizeof(float)) || dtab.reserve((size_t)n * sizeof(CropLine)) ||
+             dout.reserve((size_t)n_out);
+    auto done = [&](int r) { dpage.release(); dcoord.release(); dtab.release(); dout.release(); return r; };
+    if (rc) return done(1);
+    if (hipMemcpy(dpage.p, page_hwc, page_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dcoord.p, coords, (size_t)n_coord * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dtab.p, tab.data(), (size_t)n * sizeof(CropLine), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
+    hipLaunchKernelGGL(remap_u8_kernel, dim3((line_height * w_max + 255) / 256, n), dim3(256), 0, 0, dpage.as<uint8_t>(), H, W, C,
+                       dcoord.as<float>(), dtab.as<CropLine>(), line_height, dout.as<uint8_t>());
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return done(fail("remap kernel failed"));
+    if (hipMemcpy(crops, dout.p, (size_t)n_out, hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    return done(0);
 }
 
 int pocr_set_profiling(pocr_engine *e, int32_t enabled) {

@@ -13,6 +13,23 @@ from __future__ import annotations
 from .. ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
 
 
+class LineCropper:
+    """Counterpart of the reference's LineCropper (pero_ocr/document_ocr/page_parser.py:376-393): fills `line.crop`
+    for every text line of a page - here with ONE GPU call for all lines (pero_ocr_amd/core/crop_engine.py)."""
+
+    def __init__(self, config, config_path="", device_id: int = 0):
+        from ..core.crop_engine import EngineLineCropper
+        self.crop_engine = EngineLineCropper(line_height=int(config["LINE_HEIGHT"]), poly=int(config["INTERP"]),
+                                             scale=float(config["LINE_SCALE"]), device_id=device_id)
+
+    def process_page(self, img, page_layout):
+        lines = list(page_layout.lines_iterator())
+        crops = self.crop_engine.crop_lines(img, [(line.baseline, line.heights) for line in lines])
+        for line, crop in zip(lines, crops):
+            line.crop = crop
+        return page_layout
+
+
 class PageOCR:
     def __init__(self, config, device, config_path=""):
         """config: mapping with OCR_JSON (and optional USE_CPU / METHOD) like the [OCR] INI section."""

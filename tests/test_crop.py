@@ -1,0 +1,115 @@
+"""Line cropper.  The sampling grid is pinned against fixtures produced by the
+reference's own get_crop_inputs (oracle/gen_golden_crop.py); the remap arithmetic is checked against the oracle's
+restatement of OpenCV's fixed-point bilinear remap (cv2 itself is not available: parity with it is unpinned)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, gpu_available
+from oracle import crop_oracle
+from pero_ocr_amd.core.crop_engine import EngineLineCropper
+
+
+def cases():
+    meta = json.load(open(os.path.join(GOLDEN_DIR, "crop_coords.json"), encoding="utf8"))
+    z = np.load(os.path.join(GOLDEN_DIR, "crop_coords.npz"))
+    return [(c, z[c["name"]]) for c in meta["cases"]]
+
+
+def test_sampling_grid_matches_reference_functions():
+    for c, ref in cases():
+        got = crop_oracle.crop_inputs(np.array(c["baseline"]), c["heights"], c["line_height"], c["scale"], c["poly"])
+        assert got.dtype == np.float32 and np.array_equal(got, ref), c["name"]
+        host = EngineLineCropper(line_height=c["line_height"], poly=c["poly"], scale=c["scale"]).get_crop_inputs(
+            np.array(c["baseline"]), c["heights"], c["line_height"])
+        assert host.dtype == np.float32 and np.array_equal(host, ref), c["name"]            # the product's host code, bit for bit
+
+
+def test_remap_oracle_known_answers():
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, size=(9, 11, 3)).astype(np.uint8)
+    ys, xs = np.mgrid[0:9, 0:11].astype(np.float32)
+    assert np.array_equal(crop_oracle.remap_bilinear_u8(img, xs, ys), img)                   # identity map
+    assert np.array_equal(crop_oracle.remap_bilinear_u8(img, xs + 2, ys + 1)[:8, :9], img[1:, 2:])   # integer shift
+    assert np.all(crop_oracle.remap_bilinear_u8(img, xs + 2, ys + 1)[:, 9:] == 0)            # BORDER_CONSTANT 0
+    half = crop_oracle.remap_bilinear_u8(img, xs[:, :10] + 0.5, ys[:, :10])                  # half a pixel: (a + b + 1) >> 1
+    want = (img[:, :10].astype(int) + img[:, 1:].astype(int) + 1) >> 1
+    assert np.array_equal(half, want)
+    q = crop_oracle.remap_bilinear_u8(img, np.full((1, 1), 3.25, np.float32), np.full((1, 1), 4.75, np.float32))[0, 0]
+    a, b, c_, d = (img[4, 3].astype(int), img[4, 4].astype(int), img[5, 3].astype(int), img[5, 4].astype(int))
+    assert np.array_equal(q, (24 * 8 * 32 * a + 8 * 8 * 32 * b + 24 * 24 * 32 * c_ + 8 * 24 * 32 * d + 16384) >> 15)
+    # coordinates are rounded to 1/32 pixel, ties to even: 0.515625 * 32 = 16.5 -> 16; 0.546875 * 32 = 17.5 -> 18
+    r16 = crop_oracle.remap_bilinear_u8(img, np.full((1, 1), 0.515625, np.float32), np.zeros((1, 1), np.float32))[0, 0]
+    assert np.array_equal(r16, (16 * 32 * 32 * img[0, 0].astype(int) + 16 * 32 * 32 * img[0, 1].astype(int) + 16384) >> 15)
+
+
+@pytest.mark.gpu
+def test_gpu_remap_matches_oracle_bit_exactly():
+    assert gpu_available()
+    from pero_ocr_amd import _native
+    rng = np.random.RandomState(1)
+    page = rng.randint(0, 256, size=(300, 500, 3)).astype(np.uint8)
+    grids = []
+    for w in (1, 7, 64, 333):
+        g = np.empty((40, w, 2), np.float32)
+        g[..., 0] = rng.uniform(-20, 520, size=(40, w))          # partly outside the page
+        g[..., 1] = rng.uniform(-20, 320, size=(40, w))
+        grids.append(g)
+    grids.append(np.stack(np.meshgrid(np.arange(500, dtype=np.float32), np.arange(40, dtype=np.float32)), axis=2))  # identity rows
+    grids.append(np.full((40, 5, 2), 1e9, np.float32))           # far outside
+    grids.append(np.round(rng.uniform(0, 250, size=(40, 50, 2)) * 64).astype(np.float32) / 64)    # exact 1/64 ties
+    got = _native.crop_lines(page, grids)
+    for g, c in zip(grids, got):
+        assert np.array_equal(c, crop_oracle.remap_bilinear_u8(page, g[..., 0], g[..., 1]))
+    assert np.array_equal(got[4], page[:40])
+    gray = _native.crop_lines(page[:, :, 0], grids[:3])
+    for g, c in zip(grids[:3], gray):
+        assert np.array_equal(c[:, :, 0], crop_oracle.remap_bilinear_u8(page[:, :, 0], g[..., 0], g[..., 1]))
+
+
+@pytest.mark.gpu
+def test_gpu_cropper_end_to_end():
+    from pero_ocr_amd import synth
+    page = np.zeros((700, 700, 3), np.uint8)
+    page[150:190, 50:562] = synth.make_crops(5, [512])[0]
+    page += np.random.RandomState(2).randint(0, 30, size=page.shape).astype(np.uint8)
+    for c, _ref in cases():
+        eng = EngineLineCropper(line_height=c["line_height"], poly=c["poly"], scale=c["scale"])
+        got = eng.crop(page, np.array(c["baseline"]), c["heights"])
+        want = crop_oracle.crop(page, np.array(c["baseline"]), c["heights"], c["line_height"], c["scale"], c["poly"])
+        assert got.shape == want.shape and got.dtype == np.uint8
+        assert np.array_equal(got, want)
+    eng = EngineLineCropper(line_height=40)
+    many = eng.crop_lines(page, [(np.array(c["baseline"]), c["heights"]) for c, _ in cases() if c["line_height"] == 40 and not c["poly"] and c["scale"] == 1]
+                          + [(np.array([[5, 5]]), [10, 5])])          # a one-point baseline cannot be cropped
+    assert many[-1].shape == (40, 32, 3) and not many[-1].any()
+    crop0, fwd = eng.crop(page, np.array([[50, 180], [562, 180]]), [30, 10], return_forward_mapping=True)
+    assert crop0.shape[:2] == fwd.shape[:2] == (40, 512)
+    with pytest.raises(NotImplementedError):
+        eng.crop(page, np.array([[50, 180], [562, 180]]), [30, 10], return_mapping=True)
+
+
+@pytest.mark.gpu
+def test_gpu_line_cropper_page_level():
+    """LineCropper.process_page (page_parser.py:376-393): every line of the page gets its crop, one GPU call."""
+    from pero_ocr_amd.document_ocr.page_ocr import LineCropper
+
+    class Line:
+        def __init__(self, baseline, heights):
+            self.baseline, self.heights, self.crop, self.id = np.array(baseline), heights, None, "l"
+
+    class Layout:
+        def __init__(self, lines):
+            self.lines = lines
+
+        def lines_iterator(self):
+            return iter(self.lines)
+
+    page = np.random.RandomState(4).randint(0, 256, size=(600, 640, 3)).astype(np.uint8)
+    lines = [Line(c["baseline"], c["heights"]) for c, _ in cases() if c["line_height"] == 40 and not c["poly"] and c["scale"] == 1]
+    cropper = LineCropper({"LINE_HEIGHT": "40", "INTERP": "0", "LINE_SCALE": "1"})
+    cropper.process_page(page, Layout(lines))
+    for ln in lines:
+        assert np.array_equal(ln.crop, crop_oracle.crop(page, ln.baseline, ln.heights, 40))
