@@ -199,6 +199,16 @@ int pocr_crop_lines(int device_id, const uint8_t *page_hwc, int32_t H, int32_t W
                     const int64_t *coord_off, const int32_t *widths, int32_t n, int32_t line_height, uint8_t *crops,
                     const int64_t *crop_off);
 
+/* The same with the sampling grid generated on the device from each line's 1-D curves - the [line_height x width]
+ * float64 tail of get_crop_inputs (crop_engine.py:90-98) leaves the host, which keeps only the per-column work
+ * (spline of the baseline, normals).  Line i: curves = float64 [4][widths[i]] (base_x, base_y, normal_x, normal_y),
+ * packed back to back in line order; rows + i*line_height = float64 [line_height] offsets along the normal
+ * (np.linspace(-up, down, line_height)); rot + 4*i = the 2x2 rotation R (row-major).  grid_out (or NULL):
+ * float32 [line_height][widths[i]][2] grids back to back, for tests. */
+int pocr_crop_curves(int device_id, const uint8_t *page_hwc, int32_t H, int32_t W, int32_t C, const double *curves,
+                     const double *rows, const double *rot, const int32_t *widths, int32_t n, int32_t line_height,
+                     uint8_t *crops, const int64_t *crop_off, float *grid_out);
+
 /* Host-side helper (no GPU): find_best_overlap of the transformer branch (line_ocr_engine.py:196-211, edit distance
  * pero_ocr/sequence_alignment.py:4-13) on two symbol-id sequences: the overlap length i in 1..min(na, nb) whose
  * suffix-of-a / prefix-of-b pair has the lowest character error rate (first such i; 0 when none is below 1).

@@ -52,6 +52,8 @@ SYMBOLS = {
     "pocr_sparsify": (C.c_int, [C.c_int, _f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, _f32p, _i32p, C.c_int64, _i32p, _i64p]),
     "pocr_best_overlap": (C.c_int32, [_i32p, C.c_int32, _i32p, C.c_int32]),
     "pocr_crop_lines": (C.c_int, [C.c_int, _u8p, C.c_int32, C.c_int32, C.c_int32, _f32p, _i64p, _i32p, C.c_int32, C.c_int32, _u8p, _i64p]),
+    "pocr_crop_curves": (C.c_int, [C.c_int, _u8p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double), _i32p, C.c_int32, C.c_int32, _u8p, _i64p, _f32p]),
     "pocr_num_slots": (C.c_int, []),
     "pocr_slot_stage_lines": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, C.c_int32, C.c_int32, C.c_int32]),
     "pocr_slot_stage_ragged": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, _i32p, C.c_int32, C.c_int32]),
@@ -405,6 +407,37 @@ def crop_lines(page: np.ndarray, grids, device_id: int = 0):
                            int(widths.size), line_h, _ptr(out, _u8p), _ptr(crop_off, _i64p)):
         raise RuntimeError("pocr_crop_lines: " + (lib.pocr_last_error() or b"").decode("utf8", "replace"))
     return [out[int(o):int(o + s)].reshape(line_h, int(w), Cc).copy() for o, s, w in zip(crop_off, sizes, widths)]
+
+
+def crop_curves(page: np.ndarray, curves, rows, rots, device_id: int = 0, want_grids: bool = False):
+    """page uint8 [H, W, C]; per line: curves float64 [4, w_i] (base_x, base_y, normal_x, normal_y), rows float64 [line_h],
+    rots float64 [2, 2] -> crops uint8 [line_h, w_i, C] (+ the float32 grids if want_grids): grid generation + remap on the GPU."""
+    lib = load()
+    img = np.ascontiguousarray(page, dtype=np.uint8)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    H, W, Cc = img.shape
+    if not curves:
+        return ([], []) if want_grids else []
+    line_h = int(len(rows[0]))
+    widths = np.array([c.shape[1] for c in curves], dtype=np.int32)
+    cv = np.concatenate([np.ascontiguousarray(c, dtype=np.float64).reshape(-1) for c in curves] + [np.zeros(1)])
+    rw = np.ascontiguousarray(np.stack(rows), dtype=np.float64)
+    rt = np.ascontiguousarray(np.stack(rots), dtype=np.float64).reshape(-1)
+    sizes = widths.astype(np.int64) * line_h * Cc
+    crop_off = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    out = np.zeros(max(1, int(sizes.sum())), dtype=np.uint8)
+    gsz = widths.astype(np.int64) * line_h * 2
+    grid = np.zeros(max(1, int(gsz.sum())), dtype=np.float32) if want_grids else None
+    dp = C.POINTER(C.c_double)
+    if lib.pocr_crop_curves(int(device_id), _ptr(img, _u8p), H, W, Cc, cv.ctypes.data_as(dp), rw.ctypes.data_as(dp), rt.ctypes.data_as(dp),
+                            _ptr(widths, _i32p), int(widths.size), line_h, _ptr(out, _u8p), _ptr(crop_off, _i64p), _ptr(grid, _f32p)):
+        raise RuntimeError("pocr_crop_curves: " + (lib.pocr_last_error() or b"").decode("utf8", "replace"))
+    crops = [out[int(o):int(o + s)].reshape(line_h, int(w), Cc).copy() for o, s, w in zip(crop_off, sizes, widths)]
+    if not want_grids:
+        return crops
+    goff = np.concatenate([[0], np.cumsum(gsz)[:-1]])
+    return crops, [grid[int(o):int(o + s)].reshape(line_h, int(w), 2).copy() for o, s, w in zip(goff, gsz, widths)]
 
 
 def device_count() -> int:

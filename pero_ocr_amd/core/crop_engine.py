@@ -3,8 +3,9 @@
 
 The sampling grid (a few hundred 1-D operations per line: rotate the baseline, fit it, walk it at the target
 resolution, add the normals) stays on the host in numpy/scipy, exactly as the reference computes it; the
-per-pixel work - the bilinear remap of height x width x 3 samples per line - runs in a HIP kernel
-(`pocr_crop_lines`, csrc/crop.hpp), for all lines of a page in one call (`crop_lines`).
+per-pixel work - extending every column along its normal, rotating back, and the bilinear remap of
+height x width x 3 samples per line - runs in a HIP kernel (`pocr_crop_curves`, csrc/crop.hpp), for all lines of
+a page in one call (`crop_lines`).
 
 `return_mapping` (the reverse mapping used for blending crops back into the page, :113-145) is not built.
 """
@@ -28,13 +29,13 @@ class EngineLineCropper:
         self.blend_border = blend_border
         self.device_id = device_id
 
-    # ---- host part: source position of every crop pixel --------------------------------------------------
-    def get_crop_inputs(self, baseline, line_heights, target_height) -> np.ndarray:
-        """float32 [target_height, w, 2]: (x, y) in the page of every crop pixel (crop_engine.py:54-99).
-        The baseline is rotated onto the x axis, interpolated (cubic spline, or a polynomial of degree `poly`),
-        sampled at `target_height / (up + down)` columns per unit of arc length - with the reference's own
-        arc-length inversion (:101-111), which reduces to a straight interpolation between the first and last x -
-        and every column is extended along the curve's normal from -up to +down."""
+    # ---- host part: the line's 1-D curves --------------------------------------------------------------------
+    def line_curves(self, baseline, line_heights, target_height):
+        """The per-column half of get_crop_inputs (crop_engine.py:54-89): the baseline is rotated onto the x axis,
+        interpolated (cubic spline, or a polynomial of degree `poly`) and sampled at `target_height / (up + down)`
+        columns per unit of arc length - with the reference's own arc-length inversion (:101-111), which reduces to a
+        straight interpolation between the first and last x.  Returns (curves float64 [4, w] = base_x, base_y,
+        normal_x, normal_y; rows float64 [target_height] = offsets along the normal; R = the 2x2 rotation)."""
         above, below = line_heights[0] * self.scale, line_heights[1] * self.scale
         p = np.asarray(baseline).copy().astype(int)
         alpha = math.atan2(p[-1, 1] - p[0, 1], p[-1, 0] - p[0, 0])
@@ -58,8 +59,16 @@ class EngineLineCropper:
         ddx = np.full_like(bx, 0.1)
         ddy = by - f(bx + 0.1)
         length = (ddx ** 2 + ddy ** 2) ** 0.5        # (not np.hypot: the grid must round like the reference's)
-        normal_x, normal_y = -ddy / length, ddx / length
-        v = np.linspace(-above, below, target_height).reshape(-1, 1)
+        curves = np.stack((bx, by, -ddy / length, ddx / length))
+        return curves, np.linspace(-above, below, target_height), R
+
+    def get_crop_inputs(self, baseline, line_heights, target_height) -> np.ndarray:
+        """float32 [target_height, w, 2]: (x, y) in the page of every crop pixel (crop_engine.py:54-99): every column
+        of line_curves extended along its normal from -up to +down and rotated back.  (crop_lines does this last,
+        2-D step on the GPU; this host version serves return_forward_mapping and the parity tests.)"""
+        curves, rows, R = self.line_curves(baseline, line_heights, target_height)
+        bx, by, normal_x, normal_y = curves
+        v = rows.reshape(-1, 1)
         grid = np.stack((normal_x.reshape(1, -1) * v + bx.reshape(1, -1), normal_y.reshape(1, -1) * v + by.reshape(1, -1)), axis=2)
         return np.dot(grid, R).astype(np.float32)
 
@@ -76,21 +85,22 @@ class EngineLineCropper:
     def crop_lines(self, img: np.ndarray, lines: Sequence[Tuple[object, Sequence[float]]]) -> List[np.ndarray]:
         """All lines of a page in one GPU call.  lines: (baseline, heights) pairs.  A line whose grid cannot be
         computed gets the reference's fallback crop: zeros [line_height, 32, C] (crop_engine.py:20-22)."""
-        grids: List[Optional[np.ndarray]] = []
+        parts: List[Optional[tuple]] = []
         for baseline, heights in lines:
             try:
-                grids.append(self.get_crop_inputs(baseline, heights, self.line_height))
+                parts.append(self.line_curves(baseline, heights, self.line_height))
             except Exception:
                 print("ERROR: line crop failed.", heights, baseline)
-                grids.append(None)
+                parts.append(None)
         channels = img.shape[2] if img.ndim == 3 else 1
-        good = [g for g in grids if g is not None and g.shape[1] > 0]
-        crops = iter(_native.crop_lines(img, good, self.device_id)) if good else iter(())
+        good = [p for p in parts if p is not None and p[0].shape[1] > 0]
+        crops = iter(_native.crop_curves(img, [p[0] for p in good], [p[1] for p in good], [p[2] for p in good],
+                                         self.device_id)) if good else iter(())
         out = []
-        for g in grids:
-            if g is None:
+        for p in parts:
+            if p is None:
                 out.append(np.zeros([self.line_height, 32, channels], dtype=np.uint8))
-            elif g.shape[1] == 0:
+            elif p[0].shape[1] == 0:
                 out.append(np.zeros([self.line_height, 0, channels], dtype=np.uint8))
             else:
                 c = next(crops)

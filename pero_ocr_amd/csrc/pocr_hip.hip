@@ -1776,6 +1776,48 @@ int pocr_crop_lines(int device_id, const uint8_t *page_hwc, int32_t H, int32_t W
     return done(0);
 }
 
+int pocr_crop_curves(int device_id, const uint8_t *page_hwc, int32_t H, int32_t W, int32_t C, const double *curves,
+                     const double *rows, const double *rot, const int32_t *widths, int32_t n, int32_t line_height,
+                     uint8_t *crops, const int64_t *crop_off, float *grid_out) {
+    if (!page_hwc || !curves || !rows || !rot || !widths || !crops || !crop_off) return fail("NULL pointer");
+    if (H <= 0 || W <= 0 || C < 1 || C > 4 || line_height <= 0 || n <= 0) return fail("bad geometry (H %d, W %d, C %d, line height %d, n %d)", H, W, C, line_height, n);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available: this library has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail("device_id %d out of range (%d devices)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    std::vector<CurveLine> tab(n);
+    int64_t n_curve = 0, n_out = 0, n_grid = 0;
+    int w_max = 0;
+    for (int i = 0; i < n; ++i) {
+        if (widths[i] < 0 || crop_off[i] < 0) return fail("line %d: negative width / offset", i);
+        tab[i] = CurveLine{n_curve, (int64_t)i * line_height, (int64_t)i * 4, crop_off[i], n_grid, widths[i], 0};
+        n_curve += (int64_t)4 * widths[i];                       // curves are packed back to back in line order
+        n_grid += (int64_t)2 * line_height * widths[i];
+        n_out = std::max<int64_t>(n_out, crop_off[i] + (int64_t)line_height * widths[i] * C);
+        w_max = std::max(w_max, widths[i]);
+    }
+    if (w_max == 0) return 0;
+    DevBuf dpage, dcurve, drows, drot, dtab, dout, dgrid;
+    const size_t page_bytes = (size_t)H * W * C;
+    int rc = dpage.reserve(page_bytes) || dcurve.reserve((size_t)n_curve * sizeof(double)) || drows.reserve((size_t)n * line_height * sizeof(double)) ||
+             drot.reserve((size_t)n * 4 * sizeof(double)) || dtab.reserve((size_t)n * sizeof(CurveLine)) || dout.reserve((size_t)n_out) ||
+             (grid_out ? dgrid.reserve((size_t)n_grid * sizeof(float)) : 0);
+    auto done = [&](int r) { for (DevBuf *b : {&dpage, &dcurve, &drows, &drot, &dtab, &dout, &dgrid}) b->release(); return r; };
+    if (rc) return done(1);
+    if (hipMemcpy(dpage.p, page_hwc, page_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dcurve.p, curves, (size_t)n_curve * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(drows.p, rows, (size_t)n * line_height * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(drot.p, rot, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dtab.p, tab.data(), (size_t)n * sizeof(CurveLine), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
+    hipLaunchKernelGGL(remap_curves_u8_kernel, dim3((line_height * w_max + 255) / 256, n), dim3(256), 0, 0, dpage.as<uint8_t>(), H, W, C,
+                       dcurve.as<double>(), drows.as<double>(), drot.as<double>(), dtab.as<CurveLine>(), line_height, dout.as<uint8_t>(),
+                       grid_out ? dgrid.as<float>() : (float *)nullptr);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return done(fail("remap kernel failed"));
+    if (hipMemcpy(crops, dout.p, (size_t)n_out, hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    if (grid_out && hipMemcpy(grid_out, dgrid.p, (size_t)n_grid * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    return done(0);
+}
+
 int pocr_set_profiling(pocr_engine *e, int32_t enabled) {
     if (!e) return fail("engine is NULL");
     e->profiling = enabled != 0;

@@ -113,3 +113,27 @@ def test_gpu_line_cropper_page_level():
     cropper.process_page(page, Layout(lines))
     for ln in lines:
         assert np.array_equal(ln.crop, crop_oracle.crop(page, ln.baseline, ln.heights, 40))
+
+
+@pytest.mark.gpu
+def test_gpu_grid_generation_matches_host_bit_exactly():
+    """pocr_crop_curves builds the [line_h x w] float32 grid on the device from the line's 1-D curves: it must equal
+    the host's numpy result (mul + add, then np.dot's fused second product) bit for bit."""
+    from pero_ocr_amd import _native
+    rng = np.random.RandomState(6)
+    page = rng.randint(0, 256, size=(900, 1300, 3)).astype(np.uint8)
+    todo = [(np.array(c["baseline"]), c["heights"], c["line_height"], c["poly"], c["scale"]) for c, _ in cases()]
+    for k in range(40):                                              # random wavy baselines
+        n = int(rng.randint(2, 7))
+        xs = np.sort(rng.choice(np.arange(20, 1250), size=n, replace=False))
+        ys = 100 + rng.randint(0, 700) + rng.randint(-12, 13, size=n)
+        todo.append((np.stack([xs, ys], axis=1), [int(rng.randint(10, 40)), int(rng.randint(4, 20))], 40, 0, 1))
+    for baseline, heights, line_h, poly, scale in todo:
+        eng = EngineLineCropper(line_height=line_h, poly=poly, scale=scale)
+        curves, rows, R = eng.line_curves(baseline, heights, line_h)
+        if curves.shape[1] == 0:
+            continue
+        (crop,), (grid,) = _native.crop_curves(page, [curves], [rows], [R], want_grids=True)
+        host = eng.get_crop_inputs(baseline, heights, line_h)
+        assert np.array_equal(grid, host)
+        assert np.array_equal(crop, crop_oracle.remap_bilinear_u8(page, host[..., 0], host[..., 1]))
