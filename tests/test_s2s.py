@@ -277,3 +277,36 @@ def test_batch_plan_properties_random():
                 assert [p[1:] for p in b.parts if p[0] == i][:span] == s2s_oracle.split_line(widths[i], mlw)
         groups = tengine.plan_launches(ours)
         assert [b for g_ in groups for b in g_] == ours                  # launches keep the batch order
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(conv_out=256, sa_heads=4, sa_ff=512, sa_layers=1, dec_layers=1),      # LayerNorm prologue instance for E = 256
+    dict(conv_out=512, sa_heads=16, sa_ff=1024, sa_layers=1, dec_layers=2),    # head dim 32
+    dict(conv_out=384, sa_heads=3, sa_ff=768, sa_layers=1, dec_layers=1),      # head dim 128, E without a fused-LN instance
+    dict(conv_out=512, sa_heads=8, sa_ff=2048, sa_layers=1, dec_layers=1, height=32),
+])
+def test_gpu_s2s_other_geometries_against_oracle(kw, tmp_path):
+    """Other widths / head dims / heights than the fixtures use: HIP engine vs the (reference-pinned) oracle."""
+    chars = [chr(0x61 + i) for i in range(20)]
+    height = kw.pop("height", 40)
+    spec = netspec.NetSpec(num_classes=len(chars) + 2, arch=netspec.ARCH_S2S, height=height, **kw)
+    weights = netspec.generate_weights(spec, 99, boundary_bias=30.0)
+    path = os.path.join(str(tmp_path), "m.pocrw")
+    netspec.save_blob(path, spec, weights)
+    cfg = {"line_px_height": height, "line_vertical_scale": 1.0, "checkpoint": path, "characters": chars, "max_line_width": 1024,
+           "net_name": {"dim_model": spec.conv_out, "dim_ff": spec.sa_ff, "heads": spec.sa_heads, "encoder_layers": spec.sa_layers,
+                        "decoder_layers": spec.dec_layers, "conv_subsampling": [8, 4]}}
+    jpath = os.path.join(str(tmp_path), "e.json")
+    with open(jpath, "w", encoding="utf8") as f:
+        json.dump(cfg, f)
+    import torch
+    from pero_ocr_amd import synth
+    eng = tengine.TransformerEngineLineOCR(jpath, torch.device("cuda:0"), batch_size=4)
+    crops = synth.make_crops(31, [200, 64, 333, 500, 90], height)
+    model = s2s_oracle.OracleS2S(spec, weights)
+    want_t, want_l, want_c, _ = s2s_oracle.process_lines(model, crops, eng.characters, height, 480 * 4, 1024)
+    got_t, got_l, got_c = eng.process_lines(crops, sparse_logits=False)
+    assert got_t == want_t and got_c == want_c
+    worst = max([float(np.max(np.abs(a - b))) for a, b in zip(got_l, want_l) if a.size] or [0.0])
+    assert worst < LOGIT_TOL, worst
