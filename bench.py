@@ -2,21 +2,34 @@
 """bench.py — throughput of the batched text-line recognition hot path on MI355X.
 
 Metric (BASELINE.json): text-line crops/s, CTC-decoded, at 40x512.
-Workload  (BASELINE.json configs[1]): 256 synthetic 40x512 line crops = ONE reference chunk
-(batch_size 274 -> 480*274//512 = 256 lines, W_pad 576, T 144), VGG+BiLSTM+CTC engine,
-C = 232 classes, seeded synthetic weights.  One "step" = one pass of the hot path over that
-chunk: crops resident in HBM -> staging/normalise -> conv backbone -> BiLSTM -> head -> greedy
-CTC -> label ids on the host -> strings.  With N > 1 GPUs every rank runs its own chunk
-(weak scaling, chunks are independent units) and the decoded labels are all-gathered over RCCL.
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
-        python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Workloads (--workload, default c2):
+  c2  BASELINE configs[1]: 256 synthetic 40x512 line crops = ONE reference chunk (batch_size 274 -> 480*274//512 =
+      256 lines, W_pad 576, T 144), VGG+BiLSTM+CTC engine, C = 232.  One "step" = one pass of the hot path over that
+      chunk.  Two timed regions in one run:
+        value        crops already resident in HBM -> staging/normalise -> conv backbone -> BiLSTM -> head -> greedy
+                     CTC -> label ids on the host -> strings                                  (the contract's `value`)
+        end_to_end   the same, but every step packs its 256 crops from host memory and uploads them (H2D) first:
+                     what PytorchEngineLineOCR.process_lines does per launch
+      With N > 1 GPUs every rank runs its own chunk (weak scaling; chunks are independent units) and the decoded
+      labels are all-gathered over RCCL (one fixed-stride ncclAllGather per step through the C ABI).
+  c3  BASELINE configs[2]: a 2048-line page stream, widths uniform in 128..1024, the reference's default batch_size 8
+      (300+ chunks), chunk-sharded over the ranks (LPT), one all-gather of the labels per pass - STRONG scaling.
+      One "step" = the whole stream; inputs come from host memory every step (that is the path).
+  c4  BASELINE configs[3]: 256 x 40x768, self-attention encoder instead of the BiLSTM (W_pad 832, T 208).
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4]
+With --gpus N > 1 and no WORLD_SIZE in the environment bench.py starts the N ranks itself
+(python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...); under torchrun it reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_*.  Fewer than N visible GPUs is an error, never a silent 1-GPU run.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -25,8 +38,34 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
-N_LINES, WIDTH, HEIGHT, N_SYMBOLS = 256, 512, 40, 231
-WEIGHT_SEED, CROP_SEED, BATCH_SIZE = 20260929, 305, 274
+HEIGHT = 40
+WORKLOADS = {
+    # fixture = tests/golden/<name>: weight seed / kwargs / calibrated head bias (and, for c3, the page stream itself)
+    "c2": dict(fixture="c2", n_lines=256, width=512, batch_size=274, crop_seed=305),
+    "c3": dict(fixture="c3", batch_size=8),
+    "c4": dict(fixture="c4", n_lines=256, width=768, batch_size=410, crop_seed=501),
+}
+
+
+class Dev:
+    type = "cuda"
+
+    def __init__(self, index):
+        self.index = index
+
+
+def fixture_model(name):
+    """(meta, spec, weights) of a golden fixture: the seeded weights plus the calibrated tensors it stores."""
+    from pero_ocr_amd import netspec
+    with open(os.path.join(REPO, "tests", "golden", f"{name}.json"), encoding="utf8") as f:
+        meta = json.load(f)
+    arrays = np.load(os.path.join(REPO, "tests", "golden", f"{name}.npz"))
+    spec = netspec.NetSpec.from_json(meta["spec"])
+    weights = netspec.generate_weights(spec, meta["weight_seed"], **meta.get("weight_kwargs", {}))
+    for k in arrays.files:
+        if k.startswith("override_"):
+            weights[k[len("override_"):]] = arrays[k]
+    return meta, spec, weights
 
 
 def conv_flops_per_line(w_pad, height=HEIGHT, conv_out=512):
@@ -41,172 +80,299 @@ def conv_flops_per_line(w_pad, height=HEIGHT, conv_out=512):
     return out
 
 
-def cpu_baseline(spec, weights, crops, seconds_budget=20.0):
-    """The oracle (PyTorch-CPU restatement of the reference path, parity-pinned against the
-    imported reference) timed on this box's host cores, on a bounded sample of the workload."""
+def physical_cores():
+    try:
+        pairs = set()
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                elif not ln.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+        return len(pairs) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(spec, weights, crops, width, batch_size):
+    """The oracle (PyTorch-CPU restatement of the reference path, parity-pinned against the imported reference) timed
+    on this box's host cores: a thread-count sweep on 64 lines, then ALL lines of the step at the best count."""
     import torch
     from oracle import engine_oracle, model_oracle
     net = model_oracle.OracleNet(spec, weights)
-    sample = 32
-    ids = list(range(sample))
     chars = [""] * spec.num_classes
+    max_width = -(-width // 32) * 32
 
-    def one_pass():
-        batch = engine_oracle.assemble_batch(crops, ids, spec.height, WIDTH, 480 * BATCH_SIZE)
+    def one_pass(ids):
+        batch = engine_oracle.assemble_batch(crops, ids, spec.height, max_width, 480 * batch_size)
         nct = model_oracle.forward_logits(net, batch)
         _best, labels = engine_oracle.greedy_ctc(nct)
         return [engine_oracle.labels_to_text(l, chars) for l in labels]
 
-    one_pass()                                   # warm-up (discarded)
-    times = []
-    t_end = time.perf_counter() + seconds_budget
-    while len(times) < 5 and (time.perf_counter() < t_end or not times):
+    phys = physical_cores()
+    sweep, cands = {}, sorted({c for c in (8, 16, 32, 64, phys, os.cpu_count() or 1) if c <= (os.cpu_count() or 1)})
+    sample = list(range(min(64, len(crops))))
+    for c in cands:
+        torch.set_num_threads(c)
+        one_pass(sample)                         # warm-up (discarded)
         t0 = time.perf_counter()
-        one_pass()
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return {"value": round(sample / med, 2), "unit": "lines/s", "cores": int(torch.get_num_threads()),
-            "kind": "port",
-            "sample": f"{sample} of the {N_LINES} 40x{WIDTH} crops as one chunk (W_pad 576), median of "
-                      f"{len(times)} passes after 1 warm-up, torch {torch.__version__} CPU fp32"}
+        one_pass(sample)
+        sweep[c] = len(sample) / (time.perf_counter() - t0)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    ids = list(range(len(crops)))
+    t0 = time.perf_counter()
+    one_pass(ids)
+    full = len(ids) / (time.perf_counter() - t0)
+    return {"value": round(full, 2), "unit": "lines/s", "cores": int(best), "kind": "port",
+            "sample": f"all {len(ids)} 40x{width} crops of one step as one chunk (W_pad {max_width + 64}), one pass at the best "
+                      f"thread count of a sweep on {len(sample)} lines (1 warm-up + 1 timed pass each); torch {torch.__version__} "
+                      f"CPU fp32, {phys} physical cores / {os.cpu_count()} logical",
+            "thread_sweep_lines_per_s": {str(k): round(v, 2) for k, v in sweep.items()}}
+
+
+def spawn_ranks(n, argv):
+    """--gpus N without a launcher: start the N ranks ourselves, one process per GPU."""
+    import socket
+    from pero_ocr_amd import _native
+    have = _native.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 5 if args.workload == "c3" else 20
+    if args.warmup is None:
+        args.warmup = 1 if args.workload == "c3" else 3
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a run of a different size")
 
-    import torch
-    dist = None
-    force_dist = os.environ.get("POCR_FORCE_DIST") == "1"      # exercise the RCCL path with a single rank
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from pero_ocr_amd import _native, netspec, sharding, synth
+    from pero_ocr_amd.ocr_engine.line_ocr_engine import Chunk, Launch
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR, labels_to_strings
+    if _native.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: GPU {local_rank} not visible ({_native.device_count()} device(s))")
 
-    from pero_ocr_amd import _native, netspec, synth, sharding
-    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import labels_to_strings
-
-    chars = synth.make_charset(N_SYMBOLS) + ["\u200b"]
-    spec = netspec.NetSpec(num_classes=len(chars), height=HEIGHT)
-    weights = netspec.generate_weights(spec, WEIGHT_SEED)
-    crops = synth.make_crops(CROP_SEED + 1000 * rank, [WIDTH] * N_LINES, HEIGHT)
-    eng = _native.NativeEngine(spec, netspec.pack_weights(spec, weights), local_rank)
-
-    w_pad = WIDTH + 64
-    pool = np.concatenate([c.reshape(-1) for c in crops])
-    offsets = np.arange(N_LINES, dtype=np.int64) * (HEIGHT * WIDTH * 3)
+    wl = WORKLOADS[args.workload]
+    meta, spec, weights = fixture_model(wl["fixture"])
+    chars = meta["characters"]
+    tmp = tempfile.TemporaryDirectory(prefix="pocr_bench_")
+    netspec.save_blob(os.path.join(tmp.name, "weights.pocrw"), spec, weights)
+    with open(os.path.join(tmp.name, "ocr.json"), "w", encoding="utf8") as f:
+        json.dump({"line_px_height": spec.height, "line_vertical_scale": 1.0, "checkpoint": "weights.pocrw",
+                   "characters": chars[:-1], "net_name": "bench"}, f)
+    engine = PytorchEngineLineOCR(os.path.join(tmp.name, "ocr.json"), Dev(local_rank), batch_size=wl["batch_size"])
+    eng = engine.model
     n_slots = eng.num_slots
-    for sl in range(n_slots):                   # inputs resident in HBM (one staged copy per pipeline slot)
-        eng.slot_stage_lines(sl, pool, offsets, np.full(N_LINES, WIDTH, np.int32), w_pad, 32)
-    eng.slot_launch(0, want_logits=False)       # also waits for the uploads
-    eng.slot_collect(0)
-    gather_dev = torch.device("cuda", local_rank) if dist is not None else None
-    line_ids = np.arange(N_LINES, dtype=np.int32) + rank * N_LINES
 
-    # Steps are software-pipelined over the engine's two slots: step i is enqueued (conv backbone ->
-    # BiLSTM -> head -> CTC -> async D2H) before step i-1 is collected and decoded to strings, so the
-    # latency-bound LSTM tail and the host work of one step overlap the MFMA-bound convs of the next.
-    # Every step's work, including its string decode and all-gather, completes inside the timed region.
-    stage_sum = {}
-
-    def finish(slot):
-        _lg, _am, labels, lens = eng.slot_collect(slot)
-        for k, v in eng.slot_stage_ms(slot).items():
-            stage_sum[k] = stage_sum.get(k, 0.0) + v
-        if dist is not None:
-            labels, lens, _ids = sharding.allgather_labels(labels, lens, line_ids, gather_dev)
-        return labels_to_strings(labels, lens, chars)
-
-    def run_steps(k_steps):
-        texts = None
-        for i in range(k_steps):
-            eng.slot_launch(i % n_slots, want_logits=False)
-            if i > 0:
-                texts = finish((i - 1) % n_slots)
-        return finish((k_steps - 1) % n_slots)
+    # the exchange step: RCCL through the C ABI (POCR_FORCE_DIST=1 exercises it with a single rank)
+    transport = None
+    if world > 1 or os.environ.get("POCR_FORCE_DIST") == "1":
+        transport = sharding.init_rccl_from_env(eng, rank, world)
 
     def fence():
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
+        eng.device_synchronize()
+        if transport is not None:
+            transport.barrier()
+        eng.device_synchronize()
 
-    if args.warmup:
-        run_steps(args.warmup)
-    eng.set_profiling(True)
-    stage_sum.clear()
-    fence()
-    t0 = time.perf_counter()
-    texts = run_steps(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    assert len(texts) == N_LINES * world
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    stage_sum = {}
+    extra = {}
+
+    if args.workload == "c3":
+        # ------------------------------------------------------------------ c3: sharded page stream (strong scaling)
+        widths = meta["widths"]
+        lines = synth.make_crops(meta["crop_seed"], widths, spec.height, meta.get("crop_indices"))
+        n_total = len(lines)
+        sh = sharding.ShardedLineOCR(sharding.engine_recogniser(engine), engine.characters, engine.max_input_horizontal_pixels,
+                                     transport=transport if transport is not None else sharding.LocalTransport())
+        texts = None
+        for _ in range(args.warmup):
+            texts = sh.process_lines(lines)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            texts = sh.process_lines(lines)
+        fence()
+        elapsed = time.perf_counter() - t0
+        assert texts == meta["transcriptions"], "c3: transcriptions differ from the reference fixture"
+        lines_per_step = n_total
+        scaling = "strong"
+        workload_txt = (f"c3: {n_total}-line page stream, widths 128..1024 (seeded), reference plan at default batch_size 8 "
+                        f"({len(meta['plan'])} chunks), whole chunks dealt to {world} rank(s) (LPT), inputs: host->device every "
+                        "step, one RCCL all-gather of the labels per pass; transcriptions checked against the reference fixture")
+        w_pad = None
+    else:
+        # ------------------------------------------------------------------ c2 / c4: one reference chunk per step
+        n_lines, width = wl["n_lines"], wl["width"]
+        crops = synth.make_crops(wl["crop_seed"] + 1000 * rank, [width] * n_lines, spec.height)
+        w_pad = width + 64
+        T = (w_pad // 2) // 2
+        pool = np.concatenate([c.reshape(-1) for c in crops])
+        offsets = np.arange(n_lines, dtype=np.int64) * (spec.height * width * 3)
+        for sl in range(n_slots):                   # inputs resident in HBM (one staged copy per pipeline slot)
+            eng.slot_stage_lines(sl, pool, offsets, np.full(n_lines, width, np.int32), w_pad, 32)
+        eng.slot_launch(0, want_logits=False)       # also waits for the uploads
+        eng.slot_collect(0)
+        line_ids = np.arange(n_lines, dtype=np.int32) + rank * n_lines
+        m_of = [n_lines] * world
+
+        def to_strings(labels, lens):
+            if transport is not None:               # ONE fixed-stride all-gather: rows [line id, length, labels...]
+                rows = np.full((n_lines, T + 2), -1, dtype=np.int32)
+                rows[:, 0], rows[:, 1], rows[:, 2:2 + labels.shape[1]] = line_ids, lens, labels
+                got = sharding.allgather_rows(transport, rows, n_lines, m_of)
+                labels, lens = got[:, 2:], got[:, 1]
+            return labels_to_strings(labels, lens, chars)
+
+        # Steps are software-pipelined over the engine's two slots: step i is enqueued (conv backbone -> sequence
+        # model -> head -> CTC -> async D2H) before step i-1 is collected and decoded to strings, so the latency-bound
+        # tail and the host work of one step overlap the MFMA-bound convs of the next.  Every step's work,
+        # including its string decode and all-gather, completes inside the timed region.
+        def finish(slot):
+            _lg, _am, labels, lens = eng.slot_collect(slot)
+            for k, v in eng.slot_stage_ms(slot).items():
+                stage_sum[k] = stage_sum.get(k, 0.0) + v
+            return to_strings(labels, lens)
+
+        def run_resident(k_steps):
+            for i in range(k_steps):
+                eng.slot_launch(i % n_slots, want_logits=False)
+                if i > 0:
+                    finish((i - 1) % n_slots)
+            return finish((k_steps - 1) % n_slots)
+
+        chunk = Chunk(list(range(n_lines)), -(-width // 32) * 32, w_pad)
+
+        def run_end_to_end(k_steps):
+            """Per step: pack the crops from host memory, H2D, launch, collect, strings (process_lines' launch loop)."""
+            pending, texts = None, None
+            for i in range(k_steps):
+                handle = engine._submit_launch(crops, Launch([chunk]), False, i % n_slots)
+                if pending is not None:
+                    t_, _l = engine._collect_launch(pending)[:2]
+                    texts = t_
+                pending = handle
+            return engine._collect_launch(pending)[0]
+
+        if args.warmup:
+            run_resident(args.warmup)
+        eng.set_profiling(True)
+        stage_sum.clear()
+        fence()
+        t0 = time.perf_counter()
+        texts = run_resident(args.steps)
+        fence()
+        elapsed = time.perf_counter() - t0
+        assert len(texts) == n_lines * world
+        ms = {k: v / args.steps for k, v in stage_sum.items()}
+        eng.set_profiling(False)
+        # second timed region: host crops -> strings per step (PCIe-inclusive); N = 1 only reports it
+        run_end_to_end(max(1, args.warmup))
+        fence()
+        t1 = time.perf_counter()
+        texts_e2e = run_end_to_end(args.steps)
+        fence()
+        e2e = time.perf_counter() - t1
+        assert texts_e2e == texts[rank * n_lines:(rank + 1) * n_lines] if transport is None else len(texts_e2e) == n_lines
+        if transport is not None:
+            e2e = transport.allreduce_max(e2e)
+        extra["end_to_end"] = {"value": round(n_lines * world * args.steps / e2e, 1), "unit": "lines/s",
+                               "ms_per_step": round(1e3 * e2e / args.steps, 3),
+                               "what": "every step packs its crops from host memory (numpy), H2D, launch, collect, strings - "
+                                       "PytorchEngineLineOCR's launch loop; no all-gather in this region"}
+        lines_per_step = n_lines * world
+        scaling = "weak"
+        seq = "BiLSTM(2x256)" if spec.arch == netspec.ARCH else f"self-attention encoder ({spec.sa_layers}x{spec.sa_heads} heads, ff {spec.sa_ff})"
+        workload_txt = (f"{args.workload}: {n_lines} lines @40x{width} per GPU, one reference chunk (batch_size {wl['batch_size']}, "
+                        f"W_pad {w_pad}, T {T}), VGG+{seq}+CTC, C={spec.num_classes}, seeded synthetic weights; "
+                        "value: inputs resident in HBM, strings on the host; end_to_end: inputs host->device every step")
+
+    if transport is not None:
+        elapsed = transport.allreduce_max(elapsed)
 
     if rank == 0:
-        ms = {k: v / args.steps for k, v in stage_sum.items()}
-        traffic = None          # HBM bytes per launch of the dominant kernel, from the committed PMC passes
-        try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_summary.json")))
-            for kname, ctr in pmc.items():
-                if "5, 1, 4, 4, 16, 1, 1, 2, true" in kname and "hbm_bytes_per_launch" in ctr:
-                    traffic = ctr["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
-        fl = conv_flops_per_line(w_pad)
-        dom = "conv9"                                    # 24 % of the conv FLOPs, the largest single kernel
-        dom_tf = fl[dom] * N_LINES / (ms[dom] * 1e-3) / 1e12
-        conv_ms = sum(ms[k] for k in fl)
-        conv_tf = sum(fl.values()) * N_LINES / (conv_ms * 1e-3) / 1e12
         result = {
-            "metric": "text-line crops/s (CTC-decoded) at 40x512",
-            "value": round(N_LINES * world * args.steps / elapsed, 1),
+            "metric": "text-line crops/s (CTC-decoded) at 40x512" if args.workload != "c4" else "text-line crops/s (CTC-decoded) at 40x768",
+            "value": round(lines_per_step * args.steps / elapsed, 1),
             "unit": "lines/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "c2: 256 lines @40x512 per GPU, one reference chunk (batch_size 274, W_pad 576, "
-                                   "T 144), VGG+BiLSTM(2x256)+CTC, C=232, seeded synthetic weights",
-                       "lines_per_step_per_gpu": N_LINES, "parallelism": f"chunk-sharded x{world}, RCCL all-gather of labels",
-                       "pipelining": f"{n_slots} chunks in flight per GPU (separate HIP streams)"},
-            "roofline": {"bound": "mfma", "kernel": f"conv_igemm_kernel<3x3,TH5,NT256,leaky+BN> ({dom}, 512->512 @5x144)",
-                         "achieved": round(dom_tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(dom_tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (KiB -> B; gfx950 FETCH_SIZE x2 correction) from "
-                                         "separate rocprofv3 --pmc passes of this bench, profiles/pmc_summary.json",
-                         "flops_per_launch": fl[dom] * N_LINES, "avg_launch_ms": round(ms[dom], 4),
-                         "peak_dtype": "fp32 MFMA (v_mfma_f32_16x16x4_f32), dense"},
-            "conv_backbone": {"achieved": round(conv_tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(conv_tf / F32_MFMA_PEAK_TFLOPS, 4), "gflop_per_line": round(sum(fl.values()) / 1e9, 3),
-                              "ms_per_step": round(conv_ms, 3)},
-            "stage_ms": {k: round(v, 4) for k, v in ms.items()},
+            "config": {"workload": workload_txt, "lines_per_step": lines_per_step,
+                       "parallelism": f"chunk-sharded x{world}, one RCCL all-gather of labels per step (C ABI)"
+                                      if transport is not None else "single GPU, no collective",
+                       "pipelining": f"{n_slots} launches in flight per GPU (separate HIP streams)"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(spec, weights, crops)
+        if w_pad is not None:
+            traffic = None          # HBM bytes per launch of the dominant kernel, from the committed PMC passes
+            try:
+                pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_summary.json")))
+                for kname, ctr in pmc.items():
+                    if "5, 1, 4, 4, 16, 1, 1, 2, true" in kname and "hbm_bytes_per_launch" in ctr and args.workload == "c2":
+                        traffic = ctr["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+            fl = conv_flops_per_line(w_pad)
+            dom = "conv9"                                    # 24 % of the conv FLOPs, the largest single kernel
+            dom_tf = fl[dom] * n_lines / (ms[dom] * 1e-3) / 1e12
+            conv_ms = sum(ms[k] for k in fl)
+            conv_tf = sum(fl.values()) * n_lines / (conv_ms * 1e-3) / 1e12
+            result["roofline"] = {
+                "bound": "mfma", "kernel": f"conv_igemm_kernel<3x3,TH5,NT256,leaky+BN> ({dom}, 512->512 @5x{w_pad // 4})",
+                "achieved": round(dom_tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(dom_tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (KiB -> B; gfx950 FETCH_SIZE x2 correction) from "
+                                "separate rocprofv3 --pmc passes of this bench, profiles/pmc_summary.json",
+                "flops_per_launch": fl[dom] * n_lines, "avg_launch_ms": round(ms[dom], 4),
+                "peak_dtype": "fp32 MFMA (v_mfma_f32_16x16x4_f32), dense"}
+            result["conv_backbone"] = {"achieved": round(conv_tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(conv_tf / F32_MFMA_PEAK_TFLOPS, 4),
+                                       "gflop_per_line": round(sum(fl.values()) / 1e9, 3), "ms_per_step": round(conv_ms, 3)}
+            if spec.arch == netspec.ARCH_SA:
+                E, FF, Tn = spec.conv_out, spec.sa_ff, (w_pad // 2) // 2
+                enc_fl = spec.sa_layers * (2.0 * Tn * (4 * E * E + 2 * E * FF) + 4.0 * Tn * Tn * E) + 2.0 * Tn * E * spec.num_classes
+                result["encoder"] = {"gflop_per_line": round(enc_fl / 1e9, 3), "ms_per_step": round(ms["lstm"] + ms["head"], 3),
+                                     "achieved": round(enc_fl * n_lines / ((ms["lstm"] + ms["head"]) * 1e-3) / 1e12, 2),
+                                     "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "what": "LayerNorm+PE, encoder layers (QKV / attention / out / FFN) and the head, stage events"}
+            result["stage_ms"] = {k: round(v, 4) for k, v in ms.items()}
+        result.update(extra)
+        if world == 1 and not args.no_cpu_baseline and args.workload != "c3":
+            result["cpu_baseline"] = cpu_baseline(spec, weights, crops, wl["width"], wl["batch_size"])
         print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if transport is not None:
+        transport.barrier()
+        eng.comm_destroy()
+    tmp.cleanup()
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define POCR_ABI_VERSION 6
+#define POCR_ABI_VERSION 7
 #define POCR_NUM_SLOTS 2
 
 typedef struct pocr_engine pocr_engine;
@@ -140,6 +140,32 @@ int pocr_slot_stage_ragged(pocr_engine *e, int32_t slot, const uint8_t *crops, c
 int pocr_slot_launch(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t want_argmax);
 int pocr_slot_collect(pocr_engine *e, int32_t slot, float *logits_ntc, int32_t *frame_argmax_nt,
                       int32_t *labels_nt, int32_t *label_len_n);
+
+/* Error recovery (no reference counterpart): drains both streams of `slot` and clears its staged / in-flight state, so
+ * that an engine stays usable after a failure or an interrupt between launch and collect.  Results of the abandoned
+ * launch are lost. */
+int pocr_slot_reset(pocr_engine *e, int32_t slot);
+
+/* ---- multi-GPU exchange (the reference is single-device).  Pages shard by the reference's own
+ * chunks (line_ocr_engine.py:79-90: independent forwards), one process + one engine per GPU, and the only exchange
+ * is ONE RCCL all-gather of the decoded label ids per page stream over xGMI.  librccl.so is dlopen()ed by the first
+ * of these calls; a single-GPU process never loads it.
+ *   pocr_comm_unique_id : rank 0 creates the 128-byte rendezvous id (ncclGetUniqueId) and hands it to the other ranks
+ *                         through any out-of-band channel (the Python host uses a TCP socket, sharding.py).
+ *   pocr_comm_init      : every rank, same id (ncclCommInitRank; blocks until all ranks have joined).
+ *   pocr_allgather_labels: send = int32 [count] host buffer of THIS rank (fixed stride: every rank passes the same
+ *                         count - all ranks derive it from the same chunk plan, so no size exchange is needed);
+ *                         recv = int32 [world * count], rank r's block at r * count.  Blocking.
+ *   pocr_comm_allreduce_max: in-place max over ranks of one double (also a barrier; bench.py's max-over-ranks time).
+ *   pocr_comm_destroy   : optional, pocr_destroy() does it too. */
+#define POCR_UNIQUE_ID_BYTES 128
+int pocr_comm_unique_id(uint8_t *id128);
+int pocr_comm_init(pocr_engine *e, const uint8_t *id128, int32_t rank, int32_t world);
+int pocr_comm_destroy(pocr_engine *e);
+int pocr_allgather_labels(pocr_engine *e, const int32_t *send, int64_t count, int32_t *recv);
+int pocr_comm_allreduce_max(pocr_engine *e, double *value);
+/* hipDeviceSynchronize() on the engine's device (fences of the measurement harness). */
+int pocr_device_synchronize(pocr_engine *e);
 
 /* ---- sparse logits: replaces `softmax -> logits[p < 1e-4] = 0 -> scipy.sparse.csc_matrix` per line
  * (line_ocr_engine.py:168-171, softmax.py:4-46) with device kernels, so only CSC triplets cross PCIe.

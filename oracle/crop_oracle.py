@@ -104,6 +104,8 @@ def crop(img: np.ndarray, baseline, heights, line_height: int = 32, scale: float
     """EngineLineCropper.crop (crop_engine.py:16-30): any failure gives a zero crop of 32 columns."""
     try:
         coords = crop_inputs(baseline, heights, line_height, scale, poly)
+        if coords.shape[1] == 0:        # fast_remap's np.amin(coords) raises on an empty grid (crop_engine.py:147)
+            raise ValueError("zero-size array to reduction operation minimum which has no identity")
         return remap_bilinear_u8(img, coords[:, :, 0], coords[:, :, 1])
     except Exception:
         return np.zeros([line_height, 32, img.shape[2]], dtype=np.uint8)

@@ -14,7 +14,8 @@ import numpy as np
 from .netspec import NetSpec
 
 LIB_NAME = "libpocr_hip.so"
-ABI_VERSION = 6
+ABI_VERSION = 7
+UNIQUE_ID_BYTES = 128
 STAGE_NAMES = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv8", "conv9",
                "agg", "lstm", "head", "ctc", "total")
 
@@ -70,6 +71,13 @@ SYMBOLS = {
     "pocr_s2s_sparse": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_float, C.POINTER(C.c_int64)]),
     "pocr_s2s_collect_sparse": (C.c_int, [C.c_void_p, C.c_int32, _f32p, _i32p, _i32p, _i64p]),
     "pocr_slot_confidence": (C.c_int, [C.c_void_p, C.c_int32, _f32p]),
+    "pocr_slot_reset": (C.c_int, [C.c_void_p, C.c_int32]),
+    "pocr_comm_unique_id": (C.c_int, [_u8p]),
+    "pocr_comm_init": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32]),
+    "pocr_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pocr_allgather_labels": (C.c_int, [C.c_void_p, _i32p, C.c_int64, _i32p]),
+    "pocr_comm_allreduce_max": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "pocr_device_synchronize": (C.c_int, [C.c_void_p]),
     "pocr_last_stage_ms": (C.c_int, [C.c_void_p, _f32p, C.c_int32]),
     "pocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "pocr_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -320,6 +328,50 @@ class NativeEngine:
             raise RuntimeError("pocr_slot_confidence: " + self._err())
         return out
 
+    def slot_reset(self, slot: int):
+        """Drain and forget whatever `slot` has staged / in flight (error recovery)."""
+        if self._lib.pocr_slot_reset(self._h, int(slot)):
+            raise RuntimeError("pocr_slot_reset: " + self._err())
+
+    def reset(self):
+        """slot_reset on every slot; never raises (used from `finally` blocks)."""
+        for sl in range(self.num_slots):
+            try:
+                self.slot_reset(sl)
+            except Exception:
+                pass
+
+    # ---- multi-GPU exchange over RCCL (include/pocr.h "multi-GPU exchange") ------------------------
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+        if buf.size != UNIQUE_ID_BYTES:
+            raise ValueError(f"unique id must be {UNIQUE_ID_BYTES} bytes")
+        if self._lib.pocr_comm_init(self._h, _ptr(buf, _u8p), int(rank), int(world)):
+            raise RuntimeError("pocr_comm_init: " + self._err())
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def comm_destroy(self):
+        if self._lib.pocr_comm_destroy(self._h):
+            raise RuntimeError("pocr_comm_destroy: " + self._err())
+
+    def allgather_labels(self, send: np.ndarray) -> np.ndarray:
+        """int32 [count] of this rank -> int32 [world, count]: one ncclAllGather (every rank passes the same count)."""
+        snd = np.ascontiguousarray(send, dtype=np.int32).reshape(-1)
+        out = np.empty((self.comm_world, snd.size), dtype=np.int32)
+        if self._lib.pocr_allgather_labels(self._h, _ptr(snd, _i32p), int(snd.size), _ptr(out, _i32p)):
+            raise RuntimeError("pocr_allgather_labels: " + self._err())
+        return out
+
+    def allreduce_max(self, value: float) -> float:
+        v = C.c_double(float(value))
+        if self._lib.pocr_comm_allreduce_max(self._h, C.byref(v)):
+            raise RuntimeError("pocr_comm_allreduce_max: " + self._err())
+        return float(v.value)
+
+    def device_synchronize(self):
+        if self._lib.pocr_device_synchronize(self._h):
+            raise RuntimeError("pocr_device_synchronize: " + self._err())
+
     def slot_stage_ms(self, slot: int) -> dict:
         buf = np.zeros(len(STAGE_NAMES), dtype=np.float32)
         k = self._lib.pocr_slot_stage_ms(self._h, int(slot), _ptr(buf, _f32p), buf.size)
@@ -438,6 +490,15 @@ def crop_curves(page: np.ndarray, curves, rows, rots, device_id: int = 0, want_g
         return crops
     goff = np.concatenate([[0], np.cumsum(gsz)[:-1]])
     return crops, [grid[int(o):int(o + s)].reshape(line_h, int(w), 2).copy() for o, s, w in zip(goff, gsz, widths)]
+
+
+def comm_unique_id() -> bytes:
+    """Rank 0: the 128-byte RCCL rendezvous id (ncclGetUniqueId) to hand to every rank's comm_init."""
+    buf = np.zeros(UNIQUE_ID_BYTES, dtype=np.uint8)
+    lib = load()
+    if lib.pocr_comm_unique_id(_ptr(buf, _u8p)):
+        raise RuntimeError("pocr_comm_unique_id: " + (lib.pocr_last_error() or b"").decode("utf8", "replace"))
+    return buf.tobytes()
 
 
 def device_count() -> int:

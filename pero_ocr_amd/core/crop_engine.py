@@ -88,20 +88,23 @@ class EngineLineCropper:
         parts: List[Optional[tuple]] = []
         for baseline, heights in lines:
             try:
-                parts.append(self.line_curves(baseline, heights, self.line_height))
+                part = self.line_curves(baseline, heights, self.line_height)
+                if part[0].shape[1] == 0:
+                    # a grid without columns (arc length * zoom < 1): the reference's fast_remap raises on np.amin of the
+                    # empty grid (crop_engine.py:147) and crop() falls back to the zero crop like for any other failure
+                    raise ValueError("empty sampling grid")
+                parts.append(part)
             except Exception:
                 print("ERROR: line crop failed.", heights, baseline)
                 parts.append(None)
         channels = img.shape[2] if img.ndim == 3 else 1
-        good = [p for p in parts if p is not None and p[0].shape[1] > 0]
+        good = [p for p in parts if p is not None]
         crops = iter(_native.crop_curves(img, [p[0] for p in good], [p[1] for p in good], [p[2] for p in good],
                                          self.device_id)) if good else iter(())
         out = []
         for p in parts:
             if p is None:
                 out.append(np.zeros([self.line_height, 32, channels], dtype=np.uint8))
-            elif p[0].shape[1] == 0:
-                out.append(np.zeros([self.line_height, 0, channels], dtype=np.uint8))
             else:
                 c = next(crops)
                 out.append(c if img.ndim == 3 else c[:, :, 0])

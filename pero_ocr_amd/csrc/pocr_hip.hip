@@ -22,6 +22,7 @@
 #include "crop.hpp"
 #include "lstm.hpp"
 #include "sparsify.hpp"
+#include "comm.hpp"
 
 using namespace pocr;
 
@@ -251,6 +252,7 @@ struct pocr_engine {
     size_t sp_prev_total = 0;        // kept entries of the most recent sparse launch (sizes the next speculative copy)
     bool use_graphs = true;          // replay the LSTM recurrence from captured hipGraphs (POCR_NO_GRAPHS=1 disables)
     bool profiling = false;
+    Comm comm;                       // RCCL communicator of the multi-GPU path (comm.hpp); inactive on a single GPU
 };
 
 namespace {
@@ -947,10 +949,13 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     return 0;
 }
 
+static void comm_release(pocr_engine *e);
+
 void pocr_destroy(pocr_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
+    if (e->comm.active()) comm_release(e);
     for (auto &b : e->conv_w) b.release();
     for (auto &b : e->cconst) b.release();
     for (auto &b : e->conv_b) b.release();
@@ -1319,6 +1324,144 @@ int pocr_slot_confidence(pocr_engine *e, int32_t slot, float *confidence_n) {
     const int n = s.n, C = e->cfg.num_classes;
     const size_t conf_off = (size_t)(n + 1) * sizeof(int64_t) + (size_t)n * (C + 1) * sizeof(int32_t);
     memcpy(confidence_n, static_cast<const char *>(s.sp_pinned) + conf_off, (size_t)n * sizeof(float));
+    return 0;
+}
+
+int pocr_slot_reset(pocr_engine *e, int32_t slot) {
+    if (check_slot(e, slot)) return 1;
+    Slot &s = e->slot[slot];
+    HIP_TRY(hipSetDevice(e->device));
+    // drain whatever the slot still has queued (both of its streams), then forget the launch
+    hipError_t e1 = hipStreamSynchronize(s.stream), e2 = hipStreamSynchronize(s.seq_stream);
+    s.in_flight = false;
+    s.s2s_launched = s.s2s_decoded = false;
+    s.staged = false;
+    (void)hipGetLastError();
+    if (e1 != hipSuccess || e2 != hipSuccess)
+        return fail("slot %d: device error while draining: %s", slot, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    return 0;
+}
+
+// ------------------------------------------------------------------ multi-GPU exchange (comm.hpp)
+
+#define NCCL_TRY(expr)                                                                          \
+    do {                                                                                        \
+        ncclResult_t _r = (expr);                                                               \
+        if (_r != ncclSuccess) return fail("%s failed: %s", #expr, rccl().GetErrorString(_r));  \
+    } while (0)
+
+int pocr_comm_unique_id(uint8_t *id128) {
+    if (!id128) return fail("id128 is NULL");
+    if (rccl().load()) return fail("%s", rccl().err.c_str());
+    ncclUniqueId id;
+    NCCL_TRY(rccl().GetUniqueId(&id));
+    static_assert(sizeof(id) == POCR_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+int pocr_comm_init(pocr_engine *e, const uint8_t *id128, int32_t rank, int32_t world) {
+    if (!e) return fail("engine is NULL");
+    if (!id128) return fail("id128 is NULL");
+    if (world < 1 || rank < 0 || rank >= world) return fail("rank %d / world %d invalid", rank, world);
+    if (e->comm.active()) return fail("engine already has a communicator");
+    if (rccl().load()) return fail("%s", rccl().err.c_str());
+    HIP_TRY(hipSetDevice(e->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    HIP_TRY(hipStreamCreateWithFlags(&e->comm.stream, hipStreamNonBlocking));
+    ncclResult_t r = rccl().CommInitRank(&e->comm.comm, world, id, rank);
+    if (r != ncclSuccess) {
+        (void)hipStreamDestroy(e->comm.stream);
+        e->comm = Comm{};
+        return fail("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl().GetErrorString(r));
+    }
+    e->comm.rank = rank; e->comm.world = world;
+    return 0;
+}
+
+static void comm_release(pocr_engine *e) {
+    Comm &c = e->comm;
+    if (c.comm) (void)rccl().CommDestroy(c.comm);
+    if (c.d_send) (void)hipFree(c.d_send);
+    if (c.d_recv) (void)hipFree(c.d_recv);
+    if (c.h_send) (void)hipHostFree(c.h_send);
+    if (c.h_recv) (void)hipHostFree(c.h_recv);
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+    c = Comm{};
+}
+
+int pocr_comm_destroy(pocr_engine *e) {
+    if (!e) return fail("engine is NULL");
+    if (!e->comm.active()) return 0;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->comm.stream);
+    comm_release(e);
+    return 0;
+}
+
+static int comm_reserve(pocr_engine *e, size_t send_bytes) {
+    Comm &c = e->comm;
+    const size_t recv_bytes = send_bytes * (size_t)c.world;
+    if (send_bytes > c.send_cap) {
+        if (c.d_send) (void)hipFree(c.d_send);
+        if (c.h_send) (void)hipHostFree(c.h_send);
+        c.d_send = c.h_send = nullptr; c.send_cap = 0;
+        const size_t want = send_bytes + send_bytes / 4 + 256;
+        HIP_TRY(hipMalloc(&c.d_send, want));
+        HIP_TRY(hipHostMalloc(&c.h_send, want, hipHostMallocDefault));
+        c.send_cap = want;
+    }
+    if (recv_bytes > c.recv_cap) {
+        if (c.d_recv) (void)hipFree(c.d_recv);
+        if (c.h_recv) (void)hipHostFree(c.h_recv);
+        c.d_recv = c.h_recv = nullptr; c.recv_cap = 0;
+        const size_t want = recv_bytes + recv_bytes / 4 + 256;
+        HIP_TRY(hipMalloc(&c.d_recv, want));
+        HIP_TRY(hipHostMalloc(&c.h_recv, want, hipHostMallocDefault));
+        c.recv_cap = want;
+    }
+    return 0;
+}
+
+int pocr_allgather_labels(pocr_engine *e, const int32_t *send, int64_t count, int32_t *recv) {
+    if (!e) return fail("engine is NULL");
+    if (!e->comm.active()) return fail("no communicator: call pocr_comm_init first");
+    if (count < 0 || (count > 0 && (!send || !recv))) return fail("invalid buffers / count");
+    if (count == 0) return 0;
+    HIP_TRY(hipSetDevice(e->device));
+    Comm &c = e->comm;
+    const size_t bytes = (size_t)count * sizeof(int32_t);
+    if (comm_reserve(e, bytes)) return 1;
+    memcpy(c.h_send, send, bytes);
+    HIP_TRY(hipMemcpyAsync(c.d_send, c.h_send, bytes, hipMemcpyHostToDevice, c.stream));
+    NCCL_TRY(rccl().AllGather(c.d_send, c.d_recv, (size_t)count, ncclInt32, c.comm, c.stream));
+    HIP_TRY(hipMemcpyAsync(c.h_recv, c.d_recv, bytes * c.world, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    memcpy(recv, c.h_recv, bytes * c.world);
+    return 0;
+}
+
+int pocr_comm_allreduce_max(pocr_engine *e, double *value) {
+    if (!e) return fail("engine is NULL");
+    if (!e->comm.active()) return fail("no communicator: call pocr_comm_init first");
+    if (!value) return fail("value is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    Comm &c = e->comm;
+    if (comm_reserve(e, sizeof(double))) return 1;
+    memcpy(c.h_send, value, sizeof(double));
+    HIP_TRY(hipMemcpyAsync(c.d_send, c.h_send, sizeof(double), hipMemcpyHostToDevice, c.stream));
+    NCCL_TRY(rccl().AllReduce(c.d_send, c.d_recv, 1, ncclDouble, ncclMax, c.comm, c.stream));
+    HIP_TRY(hipMemcpyAsync(c.h_recv, c.d_recv, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    memcpy(value, c.h_recv, sizeof(double));
+    return 0;
+}
+
+int pocr_device_synchronize(pocr_engine *e) {
+    if (!e) return fail("engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
 

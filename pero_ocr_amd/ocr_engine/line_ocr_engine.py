@@ -165,7 +165,7 @@ class BaseEngineLineOCR:
         # from these logits (page_parser.py:485-496, 505-508).  None where it was not computed.
         self.line_confidences = [None] * n
 
-        def scatter(line_ids, texts, chunk_logits, conf=None):
+        def scatter(line_ids, texts, chunk_logits, conf=None, on_device=False):
             """chunk_logits: per-line list (ragged launches, GPU-built csc or dense [T_i, C]) or [n, T, C] array."""
             for k, i in enumerate(line_ids):
                 transcriptions[i] = texts[k]
@@ -173,7 +173,7 @@ class BaseEngineLineOCR:
                     self.line_confidences[i] = float(conf[k])
             if no_logits:
                 return
-            if device_sparse:           # chunk_logits is already a list of csc_matrix (built on the GPU)
+            if on_device:               # chunk_logits is already a list of csc_matrix (built on the GPU)
                 for k, i in enumerate(line_ids):
                     w = lines[i].shape[1]
                     coords_out[i] = [None, None] if tight_crop_logits else [pad // sub, (pad + w) // sub]
@@ -211,20 +211,30 @@ class BaseEngineLineOCR:
         # host-side assembly.  (The reference runs chunk after chunk, line_ocr_engine.py:80-129; lines are
         # independent given their padded width, so the results are the same.)
         pending = None
-        for k, launch in enumerate(plan_launches(chunks)):
-            rows = None
-            if device_sparse:
-                rows = (None, None)
-                if tight_crop_logits:
-                    frames = [(wp // 2) // 2 for wp in launch.w_pads]
-                    ws = [lines[i].shape[1] for i in launch.line_ids]
-                    rows = ([min(pad // sub, f) for f in frames], [min((pad + w) // sub, f) for w, f in zip(ws, frames)])
-            handle = self._submit_launch(lines, launch, not no_logits, k % 2, rows)
+        max_sparse_frames = getattr(self, "device_sparsify_max_frames", 0)
+        try:
+            for k, launch in enumerate(plan_launches(chunks)):
+                rows = None
+                frames = [(wp // 2) // 2 for wp in launch.w_pads]
+                # the GPU sparsification kernels hold one line's frames per workgroup pass: launches with longer lines
+                # (batch_size > 8 and a padded width over 4096 px) take the dense read-back + host softmax / CSC instead
+                launch_sparse = device_sparse and max(frames, default=0) <= max_sparse_frames
+                if launch_sparse:
+                    rows = (None, None)
+                    if tight_crop_logits:
+                        ws = [lines[i].shape[1] for i in launch.line_ids]
+                        rows = ([min(pad // sub, f) for f in frames], [min((pad + w) // sub, f) for w, f in zip(ws, frames)])
+                handle = self._submit_launch(lines, launch, not no_logits, k % 2, rows)
+                if pending is not None:
+                    scatter(pending[0].line_ids, *self._collect_launch(pending[1]), on_device=pending[2])
+                pending = (launch, handle, launch_sparse)
             if pending is not None:
-                scatter(pending[0].line_ids, *self._collect_launch(pending[1]))
-            pending = (launch, handle)
-        if pending is not None:
-            scatter(pending[0].line_ids, *self._collect_launch(pending[1]))
+                scatter(pending[0].line_ids, *self._collect_launch(pending[1]), on_device=pending[2])
+        except BaseException:
+            reset = getattr(getattr(self, "model", None), "reset", None)
+            if reset is not None:
+                reset()               # a launch may still be in flight on either slot: leave the engine usable
+            raise
         return transcriptions, logits_out, coords_out
 
 

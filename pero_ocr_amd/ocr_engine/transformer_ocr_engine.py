@@ -248,7 +248,9 @@ class TransformerEngineLineOCR(BaseEngineLineOCR):
             images, w_pads, lefts, first = [], [], [], [0]
             for b in group:
                 for i, a, e in b.parts:
-                    images.append(lines[i][:, a:e])
+                    # the reference cuts its batch to w_batch columns BEFORE centring it in 1088 (line_ocr_engine.py:125-127,
+                    # transformer_ocr_engine.py:36-40): image columns past w_batch - padding never reach the network
+                    images.append(lines[i][:, a:min(e, a + max(b.w_batch - self.line_padding_px, 0))])
                     w_pads.append(b.w_pad)
                     lefts.append(b.pad_left)
                 first.append(len(images))
@@ -278,13 +280,17 @@ class TransformerEngineLineOCR(BaseEngineLineOCR):
         # (blocking) decoding loop of launch k runs
         pending = None
         serial = os.environ.get("POCR_S2S_SERIAL") == "1"        # measurement switch: no overlap between launches
-        for k, group in enumerate(plan_launches(batches)):
-            first = submit(k % 2, group)
-            if serial:
-                finish(k % 2, group, first)
-                continue
+        try:
+            for k, group in enumerate(plan_launches(batches)):
+                first = submit(k % 2, group)
+                if serial:
+                    finish(k % 2, group, first)
+                    continue
+                if pending is not None:
+                    finish(*pending)
+                pending = (k % 2, group, first)
             if pending is not None:
                 finish(*pending)
-            pending = (k % 2, group, first)
-        if pending is not None:
-            finish(*pending)
+        except BaseException:
+            self.net.reset()          # a launch may still be in flight on either slot: leave the engine usable
+            raise

@@ -1,5 +1,5 @@
-"""Multi-GPU sharding of the line-recognition path: one process per GPU
-(`torch.distributed`, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
+"""Multi-GPU sharding of the line-recognition path: one process per GPU, RCCL over xGMI
+through the C ABI (include/pocr.h: pocr_comm_init / pocr_allgather_labels).
 
 The reference is single-device (no torch.distributed / DataParallel anywhere,
 SURVEY.md section 2a).  The unit of parallelism is the reference's own chunk
@@ -7,8 +7,12 @@ SURVEY.md section 2a).  The unit of parallelism is the reference's own chunk
 pass and a line's logits depend on its chunk's padded width, so whole chunks are dealt
 to ranks and never split or re-bucketed.  There is no data-path collective inside the
 network; the only exchange is ONE all-gather of the decoded label ids per
-`process_lines` call (fixed-stride int32 [lines, T_max] + int32 lengths; <= ~1.2 MB
-per 2048 lines, latency-bound on xGMI).  Logits stay on the rank that produced them.
+`process_lines` call (fixed-stride int32 rows [line id, length, labels...]; <= ~1.2 MB
+per 2048 lines, latency-bound on xGMI; the stride and the rows per rank follow from the
+chunk plan every rank computes, so no sizes are exchanged).  Logits stay on the rank
+that produced them.  The product carries it over RCCL through the C ABI
+(pocr_allgather_labels, include/pocr.h); torch.distributed appears only as the carrier
+of the CPU tests (TorchDistTransport, "gloo").
 """
 from __future__ import annotations
 
@@ -38,84 +42,173 @@ def assign_by_cost(cost: Sequence[int], world_size: int) -> List[List[int]]:
     return [sorted(m) for m in mine]
 
 
-def _dist():
-    import torch.distributed as dist
-    return dist
+# ---- transports: who carries the one all-gather ------------------------------------------------------------------
+
+class RcclTransport:
+    """The product transport: RCCL through the C ABI (pocr_comm_init / pocr_allgather_labels, include/pocr.h) on the
+    engine's own GPU - no torch.distributed.  `engine` is a _native.NativeEngine whose comm_init has been called
+    (see init_rccl_from_env)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.rank, self.world = engine.comm_rank, engine.comm_world
+
+    def allgather_i32(self, send: np.ndarray) -> np.ndarray:
+        return self.engine.allgather_labels(send)
+
+    def allreduce_max(self, value: float) -> float:
+        return self.engine.allreduce_max(value)
+
+    def barrier(self):
+        self.engine.allreduce_max(0.0)
 
 
-def allgather_labels(labels: np.ndarray, lens: np.ndarray, line_ids: np.ndarray, device=None
-                     ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """All-gather ragged label sets.  Each rank passes int32 labels [m_r, T_r], lens [m_r],
-    global line ids [m_r] (m_r and T_r may differ per rank, m_r may be 0).  Returns the
-    concatenation over ranks (labels padded to the global T_max).  Two collectives:
-    a tiny all-gather of (m_r, T_r), then one of the fixed-stride payload."""
-    import torch
-    dist = _dist()
-    world = dist.get_world_size()
-    dev = device if device is not None else "cpu"
-    m, t = int(labels.shape[0]), int(labels.shape[1]) if labels.ndim == 2 else 0
-    shape = torch.tensor([m, t], dtype=torch.int32, device=dev)
-    shapes = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(world)]
-    dist.all_gather(shapes, shape)
-    shapes = [s.cpu().tolist() for s in shapes]
-    m_max = max(s[0] for s in shapes)
-    t_max = max(s[1] for s in shapes)
-    # payload row = [line_id, len, labels...]; stride t_max + 2
-    pay = np.full((m_max, t_max + 2), -1, dtype=np.int32)
-    if m:
-        pay[:m, 0] = line_ids
-        pay[:m, 1] = lens
-        pay[:m, 2:2 + t] = labels
-    mine = torch.from_numpy(pay).to(dev)
-    out = torch.empty((world, m_max, t_max + 2), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(out.view(-1), mine.view(-1))      # flat: ncclAllGather layout on RCCL
-    out = out.cpu().numpy()
-    rows = np.concatenate([out[r, :shapes[r][0]] for r in range(world)], axis=0) if m_max else \
-        np.zeros((0, 2), np.int32)
-    return rows[:, 2:], rows[:, 1].copy(), rows[:, 0].copy()
+class LocalTransport:
+    """A world of one without any communicator (single-GPU runs of the sharded driver)."""
+    rank, world = 0, 1
+
+    def allgather_i32(self, send: np.ndarray) -> np.ndarray:
+        return np.ascontiguousarray(send, dtype=np.int32).reshape(1, -1)
+
+    def allreduce_max(self, value: float) -> float:
+        return float(value)
+
+    def barrier(self):
+        pass
+
+
+class TorchDistTransport:
+    """torch.distributed's default process group as the carrier: "gloo" in the CPU tests of the N > 1 logic
+    (tests/test_sharding.py); not used by the product path."""
+
+    def __init__(self, device=None):
+        import torch.distributed as dist
+        self.dist, self.device = dist, (device if device is not None else "cpu")
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def allgather_i32(self, send: np.ndarray) -> np.ndarray:
+        import torch
+        mine = torch.from_numpy(np.ascontiguousarray(send, dtype=np.int32).reshape(-1)).to(self.device)
+        out = torch.empty(self.world * mine.numel(), dtype=torch.int32, device=self.device)
+        self.dist.all_gather_into_tensor(out, mine)
+        return out.cpu().numpy().reshape(self.world, -1)
+
+    def allreduce_max(self, value: float) -> float:
+        import torch
+        t = torch.tensor([value], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def exchange_unique_id(rank: int, world: int, addr: str, port: int, make_id: Callable[[], bytes], timeout_s: float = 300.0) -> bytes:
+    """Out-of-band rendezvous of RCCL's 128-byte unique id: rank 0 creates it and serves it on (addr, port) to the
+    other world - 1 ranks, which connect (retrying until rank 0 listens)."""
+    import socket
+    import time
+    if world == 1:
+        return make_id()
+    if rank == 0:
+        uid = make_id()
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout_s)
+        try:
+            for _ in range(world - 1):
+                conn, _peer = srv.accept()
+                with conn:
+                    conn.sendall(uid)
+        finally:
+            srv.close()
+        return uid
+    deadline = time.monotonic() + timeout_s
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as conn:
+                buf = b""
+                while len(buf) < 128:
+                    part = conn.recv(128 - len(buf))
+                    if not part:
+                        break
+                    buf += part
+            if len(buf) == 128:
+                return buf
+        except OSError:
+            pass
+        if time.monotonic() > deadline:
+            raise RuntimeError(f"rank {rank}: no RCCL unique id from rank 0 at {addr}:{port} within {timeout_s:.0f} s")
+        time.sleep(0.05)
+
+
+def init_rccl_from_env(engine, rank: Optional[int] = None, world: Optional[int] = None) -> RcclTransport:
+    """One process per GPU, started by torchrun or bench.py's own launcher: RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT come from the environment.  The id travels over MASTER_PORT + 1 (MASTER_PORT itself belongs to the
+    launcher's store; POCR_RDZV_PORT overrides)."""
+    import os
+    from . import _native
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("POCR_RDZV_PORT", int(os.environ.get("MASTER_PORT", "29533")) + 1))
+    uid = exchange_unique_id(rank, world, addr, port, _native.comm_unique_id)
+    engine.comm_init(uid, rank, world)
+    return RcclTransport(engine)
+
+
+def allgather_rows(transport, rows: np.ndarray, m_max: int, m_of: Sequence[int]) -> np.ndarray:
+    """ONE fixed-stride all-gather.  rows: int32 [m_r, stride] of this rank; every rank knows m_of (rows per rank) and
+    therefore m_max from the shared plan, so no sizes are exchanged.  Returns the ranks' rows back to back."""
+    stride = rows.shape[1]
+    pay = np.full((m_max, stride), -1, dtype=np.int32)
+    pay[:rows.shape[0]] = rows
+    out = transport.allgather_i32(pay.reshape(-1)).reshape(transport.world, m_max, stride)
+    return np.concatenate([out[r, :m_of[r]] for r in range(transport.world)], axis=0) if m_max else np.zeros((0, stride), np.int32)
 
 
 class ShardedLineOCR:
-    """process_lines over all ranks of the default process group.  Every rank calls it with the
-    SAME list of crops (the page stream); each runs the chunks `assign_chunks` gives it on its
-    own GPU and all ranks end up with every transcription.
+    """process_lines over all ranks.  Every rank calls it with the SAME list of crops (the page stream); each runs the
+    chunks `assign_chunks` gives it on its own GPU and all ranks end up with every transcription.
 
-    `recognise(lines, chunk) -> (labels int32 [n, T], lens int32 [n])` is the per-chunk device
-    call (PytorchEngineLineOCR on a GPU box; a stand-in in the gloo CPU tests)."""
+    `recognise(lines, chunk) -> (labels int32 [n, T], lens int32 [n])` is the per-chunk device call
+    (PytorchEngineLineOCR on a GPU box; a stand-in in the gloo CPU tests); `transport` carries the all-gather
+    (RcclTransport in the product, TorchDistTransport in the CPU tests)."""
 
     def __init__(self, recognise: Callable, characters: Sequence[str], max_input_horizontal_pixels: int,
-                 line_padding_px: int = 32, gather_device=None):
+                 line_padding_px: int = 32, transport=None):
         self.recognise = recognise
         self.characters = list(characters)
         self.max_input_horizontal_pixels = max_input_horizontal_pixels
         self.line_padding_px = line_padding_px
-        self.gather_device = gather_device
+        self.transport = transport if transport is not None else TorchDistTransport()
 
     def process_lines(self, lines) -> List[str]:
-        dist = _dist()
-        rank, world = dist.get_rank(), dist.get_world_size()
+        tr = self.transport
         chunks = plan_chunks([l.shape[1] for l in lines], self.max_input_horizontal_pixels, self.line_padding_px)
-        mine = assign_chunks(chunks, world)[rank]
-        labs, lens, ids = [], [], []
-        t_max = max([chunks[i].frames for i in mine], default=0)
+        parts = assign_chunks(chunks, tr.world)
+        mine = parts[tr.rank]
+        # payload geometry from the plan alone (identical on every rank): rows per rank, longest label row
+        m_of = [sum(len(chunks[i].line_ids) for i in p) for p in parts]
+        t_max = max([c.frames for c in chunks], default=0)
+        rows = np.full((m_of[tr.rank], t_max + 2), -1, dtype=np.int32)       # [line id, length, labels...]
         many = getattr(self.recognise, "many", None)
         results = many(lines, [chunks[ci] for ci in mine]) if many else None     # merged, pipelined launches
+        k0 = 0
         for k, ci in enumerate(mine):
             ch = chunks[ci]
             lab, ln = results[k] if results is not None else self.recognise(lines, ch)
-            pad = np.full((lab.shape[0], t_max), -1, dtype=np.int32)
-            pad[:, :lab.shape[1]] = lab
-            labs.append(pad)
-            lens.append(np.asarray(ln, dtype=np.int32))
-            ids.append(np.asarray(ch.line_ids, dtype=np.int32))
-        if labs:
-            L, N, I = np.concatenate(labs), np.concatenate(lens), np.concatenate(ids)
-        else:
-            L, N, I = np.zeros((0, 0), np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32)
-        gl, gn, gi = allgather_labels(L, N, I, self.gather_device)
+            m = len(ch.line_ids)
+            rows[k0:k0 + m, 0] = ch.line_ids
+            rows[k0:k0 + m, 1] = ln
+            rows[k0:k0 + m, 2:2 + lab.shape[1]] = lab
+            k0 += m
+        got = allgather_rows(tr, rows, max(m_of, default=0), m_of)
         texts: List[Optional[str]] = [None] * len(lines)
-        for row, ln, i in zip(gl, gn, gi):
-            texts[int(i)] = "".join(self.characters[c] for c in row[:ln])
+        for row in got:
+            texts[int(row[0])] = "".join(self.characters[c] for c in row[2:2 + row[1]])
         return texts
 
 
@@ -143,13 +236,17 @@ def engine_recogniser(engine) -> Callable:
                 k += m
 
         pending = None
-        for j, launch in enumerate(plan_launches(chunks)):
-            handle = engine._submit_launch(lines, launch, False, j % 2)
+        try:
+            for j, launch in enumerate(plan_launches(chunks)):
+                handle = engine._submit_launch(lines, launch, False, j % 2)
+                if pending is not None:
+                    finish(*pending)
+                pending = (launch, handle)
             if pending is not None:
                 finish(*pending)
-            pending = (launch, handle)
-        if pending is not None:
-            finish(*pending)
+        except BaseException:
+            engine.model.reset()      # a launch may still be in flight on either slot: leave the engine usable
+            raise
         return [out[id(ch)] for ch in chunks]
 
     recognise.many = many
@@ -160,37 +257,48 @@ class ShardedSeq2SeqOCR:
     """The same scheme for the transformer (sequence-to-sequence) engine: the unit is the reference batch of
     process_lines' "transformer" branch (line_ocr_engine.py:79-119) - a line's result depends on its batch's
     padded width and the decoding loop runs per batch, so whole batches are dealt to ranks (cost = parts x
-    padded width).  Transcriptions are exchanged as code points with the all-gather above.
+    padded width).  Transcriptions are exchanged as code points with the same single all-gather; the row stride is
+    the plan's bound on a transcription's length (every part stops after w_pad / 4 + 1 steps at the latest,
+    transformer_ocr_engine.py:74-80).
 
     `recognise(lines, batches) -> {line id: transcription}` runs one rank's batches
     (TransformerEngineLineOCR via `seq2seq_recogniser`; a stand-in in the gloo CPU tests)."""
 
     def __init__(self, recognise: Callable, max_input_horizontal_pixels: int, max_line_width, line_padding_px: int = 32,
-                 gather_device=None):
+                 transport=None):
         self.recognise = recognise
         self.max_input_horizontal_pixels = max_input_horizontal_pixels
         self.max_line_width = max_line_width
         self.line_padding_px = line_padding_px
-        self.gather_device = gather_device
+        self.transport = transport if transport is not None else TorchDistTransport()
 
     def process_lines(self, lines) -> List[str]:
         from .ocr_engine.transformer_ocr_engine import plan_batches
-        dist = _dist()
-        rank, world = dist.get_rank(), dist.get_world_size()
+        tr = self.transport
         batches = plan_batches([l.shape[1] for l in lines], self.max_input_horizontal_pixels, self.max_line_width,
                                self.line_padding_px)
-        mine = assign_by_cost([len(b.parts) * b.w_pad for b in batches], world)[rank]
+        parts = assign_by_cost([len(b.parts) * b.w_pad for b in batches], tr.world)
+        mine = parts[tr.rank]
+        ids_of = [sorted({i for bi in p for i in batches[bi].line_ids}) for p in parts]
+        bound = {}
+        for b in batches:                                  # an over-long line is recognised in several parts
+            for i, _first, _end in b.parts:
+                bound[i] = bound.get(i, 0) + b.w_pad // 4 + 1
+        stride = max(bound.values(), default=0) + 2
         texts = self.recognise(lines, [batches[i] for i in mine]) if mine else {}
         ids = sorted(texts)
-        t_max = max([len(texts[i]) for i in ids], default=0)
-        lab = np.full((len(ids), t_max), -1, dtype=np.int32)
+        rows = np.full((len(ids), stride), -1, dtype=np.int32)
         for k, i in enumerate(ids):
-            lab[k, :len(texts[i])] = [ord(ch) for ch in texts[i]]
-        lens = np.array([len(texts[i]) for i in ids], dtype=np.int32)
-        gl, gn, gi = allgather_labels(lab, lens, np.array(ids, dtype=np.int32), self.gather_device)
+            cps = [ord(ch) for ch in texts[i]][:stride - 2]
+            rows[k, 0], rows[k, 1] = i, len(cps)
+            rows[k, 2:2 + len(cps)] = cps
+        m_of = [len(x) for x in ids_of]
+        if m_of[tr.rank] != len(ids):
+            raise RuntimeError("the recogniser did not return every line of this rank's batches")
+        got = allgather_rows(tr, rows, max(m_of, default=0), m_of)
         out: List[Optional[str]] = [None] * len(lines)
-        for row, ln, i in zip(gl, gn, gi):
-            out[int(i)] = "".join(chr(int(c)) for c in row[:ln])
+        for row in got:
+            out[int(row[0])] = "".join(chr(int(c)) for c in row[2:2 + row[1]])
         return out
 
 

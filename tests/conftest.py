@@ -38,27 +38,74 @@ class Golden:
         return netspec.NetSpec.from_json(self.meta["spec"])
 
     def weights(self):
+        """Seeded weights + the data-calibrated tensors the fixture stores ("override_<name>", see
+        oracle/gen_golden.py calibrated_weights)."""
         from pero_ocr_amd import netspec
-        extra = {"boundary_bias": self.meta["boundary_bias"]} if "boundary_bias" in self.meta else {}
-        return netspec.generate_weights(self.spec(), self.meta["weight_seed"], **extra)
+        extra = dict(self.meta.get("weight_kwargs", {}))
+        if "boundary_bias" in self.meta:
+            extra["boundary_bias"] = self.meta["boundary_bias"]
+        w = netspec.generate_weights(self.spec(), self.meta["weight_seed"], **extra)
+        for k in self.arrays.files:
+            if k.startswith("override_"):
+                w[k[len("override_"):]] = self.arrays[k]
+        return w
 
     def crops(self):
         from pero_ocr_amd import synth
-        return synth.make_crops(self.meta["crop_seed"], self.meta["widths"], self.meta["height"])
+        return synth.make_crops(self.meta["crop_seed"], self.meta["widths"], self.meta["height"],
+                                self.meta.get("crop_indices"))
+
+    def _frame_slice(self, i):
+        if not hasattr(self, "_row_off"):
+            self._row_off = np.concatenate([[0], np.cumsum(self.arrays["shapes"][:, 0])])
+        return slice(int(self._row_off[i]), int(self._row_off[i + 1]))
+
+    def _whole(self, key):
+        """npz members are decompressed on every access: keep the concatenated ones."""
+        if not hasattr(self, "_memo"):
+            self._memo = {}
+        if key not in self._memo:
+            self._memo[key] = self.arrays[key]
+        return self._memo[key]
 
     def argmax(self, i):
+        if "argmax_all" in self.arrays.files:
+            return self._whole("argmax_all")[self._frame_slice(i)].astype(np.int64)
         return self.arrays[f"argmax_{i}"].astype(np.int64)
 
     def margin(self, i):
         """Reference top-2 logit margin per frame (how robust 'argmax identical' is on that frame)."""
+        if "margin_all" in self.arrays.files:
+            return self._whole("margin_all")[self._frame_slice(i)]
         return self.arrays[f"margin_{i}"]
+
+    def rows(self, i):
+        """Reference logits of the sampled frames sample_rows[i] of line i: [k, C]."""
+        if "rows_all" in self.arrays.files:
+            if not hasattr(self, "_srow_off"):
+                self._srow_off = np.concatenate([[0], np.cumsum([len(r) for r in self.meta["sample_rows"]])])
+            return self._whole("rows_all")[int(self._srow_off[i]):int(self._srow_off[i + 1])]
+        return self.arrays[f"rows_{i}"]
+
+    def l2(self, i):
+        if "l2_all" in self.arrays.files:
+            return float(self._whole("l2_all")[i])
+        return float(self.arrays[f"l2_{i}"][0])
+
+    def rowlse(self, i):
+        return self._whole("rowlse")[self._frame_slice(i)]
 
     def write_engine_json(self, tmpdir):
         """Engine JSON in the reference's schema + the build-specific "net" key."""
         path = os.path.join(str(tmpdir), "ocr.json")
+        checkpoint = "absent.pocrw"
+        if self.meta.get("weight_kwargs") or any(k.startswith("override_") for k in self.arrays.files):
+            from pero_ocr_amd import netspec        # not reproducible from the seed alone: ship a weight blob
+            checkpoint = "weights.pocrw"
+            netspec.save_blob(os.path.join(str(tmpdir), checkpoint), self.spec(), self.weights())
         with open(path, "w", encoding="utf8") as f:
             json.dump({"line_px_height": self.meta["height"], "line_vertical_scale": 1.0,
-                       "checkpoint": "absent.pocrw", "characters": self.meta["characters"][:-1],
+                       "checkpoint": checkpoint, "characters": self.meta["characters"][:-1],
                        "net_name": "VGG_BLSTM_CTC",
                        "net": {"arch": self.meta["spec"].get("arch", "vgg_blstm_ctc"),
                                "weight_seed": self.meta["weight_seed"]}}, f)

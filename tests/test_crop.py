@@ -69,6 +69,35 @@ def test_gpu_remap_matches_oracle_bit_exactly():
         assert np.array_equal(c[:, :, 0], crop_oracle.remap_bilinear_u8(page[:, :, 0], g[..., 0], g[..., 1]))
 
 
+def test_empty_sampling_grid_is_the_reference_fallback_crop(capsys):
+    """A baseline shorter than one crop column (arc length * zoom < 1, or two identical points) gives a grid without
+    columns: the reference's fast_remap raises on np.amin of it (crop_engine.py:147) and crop() returns the zero crop
+    [line_height, 32, C] of its bare except (:20-22) - not a [line_height, 0, C] array, which would also stop the
+    chunk planner (division by ceil32(0))."""
+    img = np.full((64, 64, 3), 200, np.uint8)
+    for baseline, heights in (([[5, 5], [6, 5]], [60, 20]), ([[9, 9], [9, 9]], [10, 5])):
+        assert crop_oracle.crop(img, np.array(baseline), heights, line_height=40).shape == (40, 32, 3)
+    # the product's host half reaches the same decision before any GPU work (no device needed for this line)
+    eng = EngineLineCropper(line_height=40)
+    curves, _rows, _R = eng.line_curves(np.array([[5, 5], [6, 5]]), [60, 20], 40)
+    assert curves.shape[1] == 0
+
+
+@pytest.mark.gpu
+def test_gpu_empty_grid_and_failed_lines_get_the_fallback_crop():
+    img = np.full((64, 64, 3), 200, np.uint8)
+    eng = EngineLineCropper(line_height=40)
+    got = eng.crop_lines(img, [(np.array([[5, 5], [6, 5]]), [60, 20]), (np.array([[4, 30], [60, 30]]), [20, 10]),
+                               (np.array([[9, 9], [9, 9]]), [10, 5])])
+    assert got[0].shape == (40, 32, 3) and not got[0].any()
+    assert got[2].shape == (40, 32, 3) and not got[2].any()
+    want = crop_oracle.crop(img, np.array([[4, 30], [60, 30]]), [20, 10], 40)
+    assert np.array_equal(got[1], want)
+    # a page that holds ONLY such a line goes through the whole pipeline like in the reference
+    from pero_ocr_amd.ocr_engine.line_ocr_engine import plan_chunks
+    assert len(plan_chunks([c.shape[1] for c in got[:1]], 3840)) == 1
+
+
 @pytest.mark.gpu
 def test_gpu_cropper_end_to_end():
     from pero_ocr_amd import synth

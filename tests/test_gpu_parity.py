@@ -115,9 +115,9 @@ def test_engine_matches_reference_golden(golden, tmp_path, name):
         li = np.asarray(logits[i])
         assert li.dtype == np.float32 and list(li.shape) == g.arrays["shapes"][i].tolist()
         assert np.array_equal(np.argmax(li, axis=1), g.argmax(i)), f"line {i}: per-frame argmax differs"
-        worst = max(worst, float(np.max(np.abs(li[g.sample_rows[i]] - g.arrays[f"rows_{i}"]))))
+        worst = max(worst, float(np.max(np.abs(li[g.sample_rows[i]] - g.rows(i)))))
         l2 = float(np.sqrt(np.sum(li.astype(np.float64) ** 2)))
-        assert abs(l2 - float(g.arrays[f"l2_{i}"][0])) < 1e-3 * max(1.0, l2)
+        assert abs(l2 - g.l2(i)) < 1e-3 * max(1.0, l2)
         if f"dense_{i}" in g.arrays:
             worst = max(worst, float(np.max(np.abs(li - g.arrays[f"dense_{i}"]))))
     assert worst < LOGIT_TOL, worst
@@ -135,10 +135,30 @@ def test_engine_matches_reference_golden(golden, tmp_path, name):
     assert t4 == texts and all(x is None for x in l4) and all(x is None for x in c4)
 
 
+def _check_full_tensor_stats(g, logits):
+    """Checks that cover EVERY element of a config's logits without storing them: per line the L2 norm, and the
+    statistics that are 1-Lipschitz in the max norm - per class max and mean over the line's frames (a wrong head column
+    anywhere shows up here), per frame logsumexp over the classes.  Returns the worst deviation."""
+    colmax, colmean = g.arrays["colmax"], g.arrays["colmean"]
+    worst = 0.0
+    for i in range(g.n):
+        li = np.asarray(logits[i])
+        l2 = float(np.sqrt(np.sum(li.astype(np.float64) ** 2)))
+        assert abs(l2 - g.l2(i)) < 1e-4 * max(1.0, l2), f"line {i}: L2 {l2} vs {g.l2(i)}"
+        worst = max(worst, float(np.max(np.abs(li.max(axis=0) - colmax[i]))),
+                    float(np.max(np.abs(li.astype(np.float64).mean(axis=0) - colmean[i]))),
+                    float(np.max(np.abs(np.logaddexp.reduce(li.astype(np.float64), axis=1) - g.rowlse(i)))))
+    return worst
+
+
 def test_c2_full_batch_matches_reference_golden(golden, tmp_path):
-    """BASELINE config 2: 256 lines @40x512 in ONE chunk (batch_size 274), W_pad 576, T 144."""
+    """BASELINE config 2: 256 lines @40x512 in ONE chunk (batch_size 274), W_pad 576, T 144.  Every line of the fixture
+    was picked so that the reference's top-2 margin is >= 1e-3 on each of its 36 864 frames and the winners cover ~190 of
+    the 232 classes: strings and per-frame argmax must be IDENTICAL, logits within 1e-3 (sampled rows, and the
+    full-tensor statistics)."""
     from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
     g = golden("c2")
+    assert g.min_top2_margin >= 1e-3 and g.classes_used >= 100
     eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=g.batch_size)
     texts, logits, coords = eng.process_lines(g.crops(), sparse_logits=False)
     assert texts == g.transcriptions
@@ -148,9 +168,10 @@ def test_c2_full_batch_matches_reference_golden(golden, tmp_path):
         li = np.asarray(logits[i])
         if not np.array_equal(np.argmax(li, axis=1), g.argmax(i)):
             bad.append(i)
-        worst = max(worst, float(np.max(np.abs(li[g.sample_rows[i]] - g.arrays[f"rows_{i}"]))))
+        worst = max(worst, float(np.max(np.abs(li[g.sample_rows[i]] - g.rows(i)))))
     assert not bad, f"argmax differs on lines {bad} (reference min top-2 margin {g.min_top2_margin:.2e})"
     assert worst < LOGIT_TOL, worst
+    assert _check_full_tensor_stats(g, logits) < LOGIT_TOL
 
 
 def test_run_ocr_padded_path_equals_ragged_path(golden, tmp_path):
@@ -279,7 +300,7 @@ def _check_against_golden(g, texts, logits, coords, exact_margin):
         flips += line_flips
         if line_flips == 0:
             assert texts[i] == g.transcriptions[i]
-        worst = max(worst, float(np.max(np.abs(li[g.sample_rows[i]] - g.arrays[f"rows_{i}"]))))
+        worst = max(worst, float(np.max(np.abs(li[g.sample_rows[i]] - g.rows(i)))))
     assert worst < LOGIT_TOL, worst
     return flips
 
@@ -294,15 +315,17 @@ def test_sa_engine_matches_reference_golden(golden, tmp_path):
 
 
 def test_c4_full_batch_matches_reference_golden(golden, tmp_path):
-    """BASELINE config 4: 256 lines @40x768, one chunk (batch_size 410), W_pad 832, T 208, encoder
-    variant.  53k frames: the reference's own minimum top-2 margin is ~4e-6 (below fp32 noise), so
-    identity is required on every frame with margin > 2e-4 and at most 3 frames may differ at all."""
+    """BASELINE config 4: 256 lines @40x768, one chunk (batch_size 410), W_pad 832, T 208, encoder variant.  The lines
+    were picked so that the reference's top-2 margin is >= 1e-3 on each of the 53 248 frames: zero differing frames,
+    identical strings, logits within 1e-3."""
     from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
     g = golden("c4")
+    assert g.min_top2_margin >= 1e-3 and g.classes_used >= 100
     eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=g.batch_size)
     texts, logits, coords = eng.process_lines(g.crops(), sparse_logits=False)
-    flips = _check_against_golden(g, texts, logits, coords, exact_margin=2e-4)
-    assert flips <= 3, flips
+    flips = _check_against_golden(g, texts, logits, coords, exact_margin=0.0)
+    assert flips == 0 and texts == g.transcriptions
+    assert _check_full_tensor_stats(g, logits) < LOGIT_TOL
 
 
 def test_pipelined_slots_match_blocking_calls(small):
@@ -342,28 +365,85 @@ def test_pipelined_slots_match_blocking_calls(small):
         eng.slot_launch(7)
 
 
-def test_sharded_page_stream_matches_single_engine(golden, tmp_path):
-    """BASELINE config 3 shape (seeded width distribution 128..1024, chunk-sharded) on ONE rank:
-    ShardedLineOCR (chunk assignment + label all-gather through torch.distributed) must return exactly
-    what the plain engine returns for the same page stream, and every chunk keeps the reference plan."""
-    import os
-    import torch.distributed as dist
+def test_c3_page_stream_over_rccl_matches_reference_golden(golden, tmp_path):
+    """BASELINE config 3: the full 2048-line page stream (widths 128..1024, reference default batch_size 8) through
+    ShardedLineOCR with the RCCL transport of the C ABI (pocr_comm_init / pocr_allgather_labels; world 1 on this box).
+    Chunk plan, transcriptions and every frame's argmax must equal the fixture the REFERENCE engine produced."""
     from pero_ocr_amd import sharding
+    from pero_ocr_amd.ocr_engine import line_ocr_engine
     from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
-    g = golden("c1")
-    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=32)
-    widths = synth.make_widths(3, 384)
-    lines = synth.make_crops(9, widths)
-    expect, _l, _c = eng.process_lines(lines, no_logits=True)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
-    dist.init_process_group("gloo", rank=0, world_size=1)
+    g = golden("c3")
+    assert g.n == 2048 and g.batch_size == 8 and g.min_top2_margin >= 1e-3
+    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=g.batch_size)
+    lines = g.crops()
+    plan = line_ocr_engine.plan_chunks(g.widths, eng.max_input_horizontal_pixels)
+    assert [[c.line_ids, c.max_width] for c in plan] == g.plan
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    tr = sharding.init_rccl_from_env(eng.model, rank=0, world=1)
     try:
-        sh = sharding.ShardedLineOCR(sharding.engine_recogniser(eng), eng.characters, eng.max_input_horizontal_pixels)
+        calls = []
+        inner = tr.allgather_i32
+        tr.allgather_i32 = lambda send: (calls.append(send.size), inner(send))[1]
+        sh = sharding.ShardedLineOCR(sharding.engine_recogniser(eng), eng.characters, eng.max_input_horizontal_pixels, transport=tr)
         got = sh.process_lines(lines)
+        assert len(calls) == 1, "exactly ONE collective per page stream"
     finally:
-        dist.destroy_process_group()
-    assert got == expect
-    assert sum(len(t) for t in got) > 0
+        eng.model.comm_destroy()
+    assert got == g.transcriptions
+    # per-frame argmax of the whole stream through the plain engine (dense logits of 330k frames stay off the fixture)
+    texts, logits, coords = eng.process_lines(lines, sparse_logits=False)
+    assert texts == g.transcriptions and coords == g.logit_coords
+    worst = 0.0
+    for i in range(g.n):
+        li = np.asarray(logits[i])
+        assert np.array_equal(np.argmax(li, axis=1), g.argmax(i)), f"line {i}: per-frame argmax differs"
+        worst = max(worst, float(np.max(np.abs(li[g.sample_rows[i]] - g.rows(i)))))
+        l2 = float(np.sqrt(np.sum(li.astype(np.float64) ** 2)))
+        assert abs(l2 - g.l2(i)) < 1e-4 * max(1.0, l2)
+    assert worst < LOGIT_TOL, worst
+
+
+def test_rccl_allgather_and_allreduce_world1():
+    """The collective entry points of the C ABI on their own (single rank): payload round trip, max-reduce."""
+    from pero_ocr_amd import sharding
+    chars = synth.make_charset(19)
+    spec = netspec.NetSpec(num_classes=len(chars) + 1, conv_out=64, lstm_hidden=64, lstm_layers=1)
+    eng = _native.NativeEngine(spec, netspec.pack_weights(spec, netspec.generate_weights(spec, 5)), 0)
+    with pytest.raises(RuntimeError, match="no communicator"):
+        eng.comm_world = 1
+        eng.allgather_labels(np.arange(4, dtype=np.int32))
+    tr = sharding.init_rccl_from_env(eng, rank=0, world=1)
+    for count in (1, 7, 4096, 300000):
+        send = (np.arange(count, dtype=np.int64) * 2654435761 % 100003).astype(np.int32)
+        out = tr.allgather_i32(send)
+        assert out.shape == (1, count) and np.array_equal(out[0], send)
+    assert tr.allreduce_max(3.25) == 3.25
+    tr.barrier()
+    with pytest.raises(RuntimeError, match="already has a communicator"):
+        eng.comm_init(_native.comm_unique_id(), 0, 1)
+    eng.comm_destroy()
+    eng.comm_destroy()          # idempotent
+
+
+def test_slot_reset_recovers_an_abandoned_launch(small):
+    """A launch that is never collected (exception between launch and collect) must not wedge the engine."""
+    spec, weights, eng, net = small
+    crops = synth.make_crops(31, [120, 64])
+    pool = np.concatenate([c.reshape(-1) for c in crops])
+    offs = np.array([0, crops[0].size], dtype=np.int64)
+    wd = np.array([120, 64], np.int32)
+    eng.slot_stage_lines(1, pool, offs, wd, 192, 32)
+    eng.slot_launch(1)
+    with pytest.raises(RuntimeError, match="in flight"):
+        eng.slot_stage_lines(1, pool, offs, wd, 192, 32)
+    eng.slot_reset(1)
+    eng.slot_stage_lines(1, pool, offs, wd, 192, 32)
+    eng.slot_launch(1, want_logits=True, want_argmax=True)
+    got = eng.slot_collect(1)
+    eng.stage_lines(pool, offs, wd, 192, 32)
+    ref = eng.run_staged()
+    for r, x in zip(ref, got):
+        assert np.array_equal(r, x)
 
 
 def test_device_sparsify_equals_host_sparsify(golden, tmp_path):

@@ -85,7 +85,7 @@ def test_oracle_reproduces_reference_golden(golden, name):
     assert coords == g.logit_coords
     for i in range(g.n):
         assert np.array_equal(extras["frame_argmax"][i], g.argmax(i)), f"line {i}"
-        rows = g.arrays[f"rows_{i}"]
+        rows = g.rows(i)
         got = np.asarray(logits[i])[g.sample_rows[i]]
         # same torch build -> normally bit-identical; 1e-4 leaves room for a different host CPU
         assert np.max(np.abs(got - rows)) < 1e-4

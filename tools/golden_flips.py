@@ -14,5 +14,5 @@ for name in ("c4", "c2"):
         li = np.asarray(logits[i]); am = np.argmax(li, 1); bad = am != g.argmax(i)
         flips += int(bad.sum())
         if bad.any(): minm = min(minm, float(g.margin(i)[bad].max()))
-        worst = max(worst, float(np.max(np.abs(li[g.sample_rows[i]] - g.arrays[f"rows_{i}"]))))
+        worst = max(worst, float(np.max(np.abs(li[g.sample_rows[i]] - g.rows(i)))))
     print(name, "flips", flips, "max margin among flipped", minm, "worst sampled |dlogit|", worst, "texts equal", texts == g.transcriptions)
