@@ -25,6 +25,7 @@ struct Conv1Args {
     const int32_t *line_w;       // padded width of every line
     const int64_t *out_off;
     int32_t H, n_ptiles;
+    int32_t src_h;               // rows the crops really have (0: = H); rows [src_h, H) are zero padding (layout network pages)
 };
 
 __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
@@ -42,11 +43,12 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
     const int Wp = a.line_w[img];
     const LineDesc ld = a.lines[img];
     const uint8_t *src = a.crops + ld.offset;
+    const int src_h = a.src_h > 0 ? a.src_h : a.H;
     for (int e = tid; e < NH; e += 256) {
         const int c = e % 3, p = e / 3, wc = p % HW, hr = p / HW;
         const int hi = h0 - 1 + hr, wi = w0 - 1 + wc, xc = wi - ld.pad_left;
         float v = 0.f;
-        if (hi >= 0 && hi < a.H && wi >= 0 && wi < Wp && xc >= 0 && xc < ld.width)
+        if (hi >= 0 && hi < src_h && wi >= 0 && wi < Wp && xc >= 0 && xc < ld.width)
             v = a.lut[src[((size_t)hi * ld.width + xc) * 3 + c]];
         halo[e] = v;
     }

@@ -31,7 +31,11 @@ namespace pocr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
-enum { STAGE_F32_NHWC = 0 };      // the u8 line stager of the first layer lives in conv1_u8.hpp
+enum { STAGE_F32_NHWC = 0, STAGE_UPCAT = 1 };      // the u8 line stager of the first layer lives in conv1_u8.hpp
+// STAGE_UPCAT (U-Net decoder convs of the layout network, parsenet.hpp): the conv input is the VIRTUAL tensor
+// cat([nearest-upsample-x2(x), x2], channels) - channels [0, cin_up) come from x at half resolution, pixel (h/2, w/2),
+// channels [cin_up, cin) from the skip tensor x2 at full resolution; neither the upsampled nor the concatenated tensor
+// is ever materialised (a 16-channel staging chunk lies entirely inside one of the two sources).
 // main-loop variants (template parameter PIPE).  ABL3 is an ablation mask used only by tools/conv_bench.hip
 // (1 no global loads, 2 no LDS writes, 4 no ds_reads, 8 no barrier, 16 loads waited for at the step end).
 enum { PIPE_PLAIN = 0, PIPE_INTERLEAVED = 3, PIPE_DEEP = 4, PIPE_GLDS = 5, PIPE_BREG = 6, PIPE_DEEP3 = 7 };
@@ -103,6 +107,9 @@ struct ConvArgs {
     const int64_t *in_off;
     const int64_t *out_off;
     int32_t n_ptiles;
+    // STAGE_UPCAT: x = [n][H/2][W/2][cin_up] (upsampled on the fly), x2 = [n][H][W][cin - cin_up] (skip connection)
+    const float *x2;
+    int32_t cin_up;
 };
 
 // number of workgroups for a conv launch (must match the block -> tile mapping in the kernel)
@@ -267,6 +274,7 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a
         }
     };
 
+    static_assert(STAGER != STAGE_UPCAT || PIPE == PIPE_INTERLEAVED || PIPE == PIPE_DEEP, "the up-sample/concat stager lives in the interleaved pipelines");
     if constexpr (PIPE == PIPE_PLAIN) {
     // ------------------------------------------------------------------ plain two-stage loop
     // (conv1's u8 stager and the rare aggregation heights use it; KC may be 32 here)
@@ -418,9 +426,12 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a
     constexpr int STRIDE = NMFMA / NSLOT;                   // MFMAs between slots
     static_assert(NMFMA % NSLOT == 0 && B_LD + A_LD <= NSLOT / 2, "slot plan does not fit");
     // per-thread constant parts of the staging addresses
+    constexpr bool UPCAT = STAGER == STAGE_UPCAT;
     unsigned a_off[A_LD];
+    unsigned a_off2[UPCAT ? A_LD : 1];          // UPCAT: offsets into the skip tensor (a_off: into the half-resolution one)
     bool a_ok[A_LD];
     int a_lds[A_LD];
+    const int cin_skip = a.cin - a.cin_up, nch_up = a.cin_up / KC;
 #pragma unroll
     for (int r = 0; r < A_LD; ++r) {
         const int e = tid + r * NTHR;
@@ -428,15 +439,26 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void conv_igemm_kernel(ConvArgs a
         const int hr = p / HW, wc = p % HW;
         const int hi = h0 - PADH + hr, wi = w0 - PADW + wc;
         a_ok[r] = e < CQ * NP && hi >= 0 && hi < a.H && wi >= 0 && wi < Win;
-        a_off[r] = a_ok[r] ? (unsigned)((hi * Win + wi) * a.cin + cq * 4) : 0u;
+        if constexpr (UPCAT) {
+            a_off[r] = a_ok[r] ? (unsigned)(((hi >> 1) * (Win >> 1) + (wi >> 1)) * a.cin_up + cq * 4) : 0u;
+            a_off2[r] = a_ok[r] ? (unsigned)((hi * Win + wi) * cin_skip + cq * 4) : 0u;
+        } else {
+            a_off[r] = a_ok[r] ? (unsigned)((hi * Win + wi) * a.cin + cq * 4) : 0u;
+        }
         a_lds[r] = e < CQ * NP ? cq * NPPAD + p : -1;
     }
-    const float *ximg = a.x + img_base;
+    const float *ximg = UPCAT ? a.x + (size_t)img * (a.H >> 1) * (Win >> 1) * a.cin_up : a.x + img_base;
+    const float *ximg2 = UPCAT ? a.x2 + (size_t)img * a.H * Win * cin_skip : nullptr;
     const f32x4 *wf4 = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * (NT / 16) * 64;
     const size_t tap_stride = (size_t)(a.cin / 16) * a.cout16 * 64;     // f32x4 per tap
     const size_t chunk_stride = (size_t)a.cout16 * 64;                   // f32x4 per 16-channel group
     auto ldA = [&](int r, int chunk_) {
-        ra[r] = a_ok[r] ? *reinterpret_cast<const f32x4 *>(ximg + chunk_ * KC + a_off[r]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (UPCAT) {
+            const float *src = chunk_ < nch_up ? ximg + chunk_ * KC + a_off[r] : ximg2 + (chunk_ - nch_up) * KC + a_off2[r];
+            ra[r] = a_ok[r] ? *reinterpret_cast<const f32x4 *>(src) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else {
+            ra[r] = a_ok[r] ? *reinterpret_cast<const f32x4 *>(ximg + chunk_ * KC + a_off[r]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     };
     auto stA = [&](int r, int buf) { if (a_lds[r] >= 0) ldsA[buf * A_F4 + a_lds[r]] = ra[r]; };
     auto ldB = [&](int r, const f32x4 *tile) {

@@ -21,6 +21,7 @@
 #include "decoder.hpp"
 #include "crop.hpp"
 #include "lstm.hpp"
+#include "lstm_persist.hpp"
 #include "sparsify.hpp"
 #include "comm.hpp"
 
@@ -192,6 +193,9 @@ struct Slot {
     // BiLSTM recurrence as replayable hipGraphs: key (layer, T, slice bucket) -> 2 memsets + T step launches.
     // Node parameters hold this slot's buffer addresses; any re-allocation of those buffers flushes the cache.
     std::map<std::tuple<int, int, int>, hipGraphExec_t> lstm_graphs;
+    DevBuf lstm_flags;               // persistent recurrence: [layer][2][n_slices] item counters, then one error word
+    int lstm_err_off = -1;           // index of that error word (uint32) inside lstm_flags; -1 = none this launch
+    uint32_t *lstm_err_host = nullptr;   // pinned copy of the error word, read at collect time
     DevBuf lstm_dims;                // device {n, npad} read by the replayed step kernels
     int32_t *lstm_dims_host = nullptr;   // pinned source of that copy
     size_t h_stride = 0;             // floats between the two h ping-pong buffers (capacity-based, stable)
@@ -228,6 +232,9 @@ struct pocr_engine {
     // weights (device)
     DevBuf conv_w[9], conv_b[9], bn_scale, bn_shift, agg_w, agg_b, head_w, head_b, lut;
     std::vector<DevBuf> proj_w, proj_b, whh;       // per LSTM layer
+    std::vector<DevBuf> whh_p;                     // per LSTM layer: W_hh as wave-private register fragments (lstm_persist.hpp)
+    bool lstm_persist = false;                     // POCR_LSTM_PERSIST=1: one persistent launch per layer (lstm_persist.hpp) instead
+                                                   // of T step launches; measured slower on MI355X, so opt-in
     // self-attention encoder (POCR_ARCH_SA): per layer in_proj, out_proj, lin1, lin2 (fragment order) + LN params
     struct SaLayer { DevBuf w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b; };
     std::vector<SaLayer> sa;
@@ -492,14 +499,64 @@ int run_network(pocr_engine *e, Slot &s) {
     };
     int bucket = 1;                          // slices rounded up to a power of two: few distinct graphs
     while (bucket * 16 < npad) bucket *= 2;
-    s.lstm_dims_host[0] = n; s.lstm_dims_host[1] = npad;
-    HIP_TRY(hipMemcpyAsync(s.lstm_dims.p, s.lstm_dims_host, 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    const int nsl = npad / 16;
+    const bool persist = e->lstm_persist && (Hh == 64 || Hh == 128 || Hh == 256 || Hh == 512) && npad <= LSTM_PERSIST_MAX_LINES &&
+                         (size_t)rows * 2 * Hh * sizeof(float) < 0x7ffffff0ull;
+    s.lstm_err_off = -1;
+    if (persist) {
+        const size_t words = (size_t)c.lstm_layers * 2 * nsl + 1;
+        if (s.lstm_flags.reserve(words * sizeof(uint32_t))) return 1;
+        HIP_TRY(hipMemsetAsync(s.lstm_flags.p, 0, words * sizeof(uint32_t), st));
+        s.lstm_err_off = (int)(words - 1);
+    } else {
+        s.lstm_dims_host[0] = n; s.lstm_dims_host[1] = npad;
+        HIP_TRY(hipMemcpyAsync(s.lstm_dims.p, s.lstm_dims_host, 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
     for (int l = 0; l < c.lstm_layers; ++l) {
         ConvArgs a{};
         a.x = layer_in; a.n = 1; a.H = 1; a.W = rows; a.Ho = 1; a.Wo = rows; a.cin = din;
         a.cout16 = e->proj_cout16; a.cout_valid = 8 * Hh; a.out_stride = 8 * Hh;
         a.wfrag = e->proj_w[l].as<float>(); a.bias = e->proj_b[l].as<float>(); a.y = s.xproj.as<float>();
         if (gemm128_k(a, st)) return 1;
+        if (persist) {
+            // the serial part in ONE launch: 2 x H/16 resident workgroups walk (step, 16-line slice) items (lstm_persist.hpp)
+            LstmPersistArgs pa{};
+            pa.xproj = s.xproj.as<float>(); pa.whh_p = e->whh_p[l].as<float>(); pa.y = s.lstm_y[l].as<float>();
+            pa.c = s.cbuf.as<float>();
+            pa.flags = s.lstm_flags.as<unsigned>() + (size_t)l * 2 * nsl;
+            pa.err = s.lstm_flags.as<unsigned>() + s.lstm_err_off;
+            pa.line_T = s.g_line_T; pa.row_off = s.g_row_off; pa.slice_T = s.g_slice_T;
+            pa.n = n; pa.npad = npad; pa.n_slices = nsl; pa.T = T;
+            pa.y_bytes = (int32_t)((size_t)rows * 2 * Hh * sizeof(float));
+            if (getenv("POCR_LSTM_DBG")) {
+                static DevBuf dbgbuf;
+                if (dbgbuf.reserve(sizeof(unsigned long long) * (16 + 128))) return 1;
+                pa.dbg = dbgbuf.as<unsigned long long>();
+                if (const char *m = getenv("POCR_LSTM_DBG_MASK")) pa.dbg_mask = atoi(m);
+            }
+            // slices are independent chains: with many of them, a few workgroups per unit group take every z-th slice
+            // (more waves per CU cover each other's hand-off latency); every workgroup keeps >= 8 slices to pipeline over
+            int zs = std::max(1, std::min(4, nsl / 8));
+            if (const char *env = getenv("POCR_LSTM_Z")) zs = std::max(1, std::min(nsl, atoi(env)));
+            // 8 waves (32 hidden units) per workgroup = 2 waves per SIMD; H = 512 keeps 128 + 2 x 128 registers per wave: 4 waves
+            switch (Hh) {
+                case 64: hipLaunchKernelGGL((lstm_persist_kernel<4, 8>), dim3(Hh / 32, 2, zs), dim3(512), 0, st, pa); break;
+                case 128: hipLaunchKernelGGL((lstm_persist_kernel<8, 8>), dim3(Hh / 32, 2, zs), dim3(512), 0, st, pa); break;
+                case 256: hipLaunchKernelGGL((lstm_persist_kernel<16, 8>), dim3(Hh / 32, 2, zs), dim3(512), 0, st, pa); break;
+                default: hipLaunchKernelGGL((lstm_persist_kernel<32, 4>), dim3(Hh / 16, 2, zs), dim3(256), 0, st, pa); break;
+            }
+            HIP_TRY(hipGetLastError());
+            if (pa.dbg) {       // POCR_LSTM_DBG=1: phase cycle counts of workgroup (0, 0, 0), wave 0 (blocks the stream)
+                unsigned long long h[16 + 128];
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipMemcpy(h, pa.dbg, sizeof(h), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[lstm dbg] layer %d z %d: items %llu blocking %llu | cycles/item: wait %.0f barrier %.0f mfma %.0f cell %.0f publish %.0f store %.0f fetch %.0f | total %.0f | first miss: step %llu slice %llu flag %llu\n",
+                        l, zs, h[0], h[1], (double)h[2] / h[0], (double)h[4] / h[0], (double)h[5] / h[0], (double)h[6] / h[0], (double)h[3] / h[0], (double)h[8] / h[0], (double)h[9] / h[0], (double)h[7] / h[0], h[4] >> 48, (h[4] >> 32) & 0xffff, h[4] & 0xffffffffull);
+            }
+            layer_in = s.lstm_y[l].as<float>();
+            din = 2 * Hh;
+            continue;
+        }
         // the serial part: 2 memsets + T dependent step launches, replayed from a captured graph
         const auto key = std::make_tuple(l, T, bucket);
         auto it = s.lstm_graphs.find(key);
@@ -581,6 +638,10 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
         s.pinned_cap = need + need / 4;
     }
     char *pin = static_cast<char *>(s.pinned);
+    if (s.lstm_err_off >= 0) {
+        if (!s.lstm_err_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.lstm_err_host), 16, hipHostMallocDefault));
+        HIP_TRY(hipMemcpyAsync(s.lstm_err_host, s.lstm_flags.as<uint32_t>() + s.lstm_err_off, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipMemcpyAsync(pin, s.labels.p, nt_bytes, hipMemcpyDeviceToHost, st));
     if (s.want_argmax) HIP_TRY(hipMemcpyAsync(pin + nt_bytes, s.best.p, (size_t)rows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(pin + 2 * nt_bytes, s.lens.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -638,6 +699,8 @@ int collect_outputs(pocr_engine *e, Slot &s, float *logits_ntc, int32_t *frame_a
     const int n = s.n, T = s.t_max, C = e->cfg.num_classes, rows = s.rows;
     HIP_TRY(hipStreamSynchronize(s.seq_stream));
     s.in_flight = false;
+    if (s.lstm_err_off >= 0 && s.lstm_err_host && *s.lstm_err_host != 0)
+        return fail("BiLSTM recurrence: a hand-off between workgroups timed out (not all workgroups of the persistent launch became resident)");
     const size_t nt_bytes = (size_t)n * T * sizeof(int32_t);
     const char *pin = static_cast<const char *>(s.pinned);
     if (logits_ntc && !s.want_logits) return fail("logits were not requested at launch");
@@ -787,6 +850,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     pocr_engine *e = new pocr_engine();
     e->cfg = *cfg;
     if (const char *env = getenv("POCR_NO_GRAPHS")) e->use_graphs = atoi(env) == 0;
+    if (const char *env = getenv("POCR_LSTM_PERSIST")) e->lstm_persist = atoi(env) != 0;
     e->device = device_id;
     auto bail = [&](int rc) { pocr_destroy(e); return rc; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
@@ -901,6 +965,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         e->proj_cout16 = round_up(8 * Hh, kProjNT) / 16;
         e->proj_w.resize(cfg->lstm_layers); e->proj_b.resize(cfg->lstm_layers);
         e->whh.resize(cfg->lstm_layers);
+        e->whh_p.resize(cfg->lstm_layers);
         for (int l = 0; l < cfg->lstm_layers; ++l) {
             const int din = l == 0 ? cfg->conv_out : 2 * Hh;
             const float *wih[2], *whh[2], *bih[2], *bhh[2];
@@ -923,6 +988,19 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
                                 for (int j = 0; j < 4; ++j)
                                     wf[o++] = whh[d][(size_t)(g * Hh + 16 * ug + (lane & 15)) * Hh + 16 * kg + 4 * (lane >> 4) + j];
             if (upload(e->proj_w[l], frag, st) || upload(e->proj_b[l], bias, st) || upload(e->whh[l], wf, st)) return bail(1);
+            // whh_p[dir][unit quad][kg][lane][j] = W_hh[(lane & 15) / 4 * H + 4 * quad + (lane & 3)][16 kg + 4 (lane >> 4) + j]:
+            // the 16 gate columns (gate-major) of 4 hidden units, the B operand a wave of lstm_persist_kernel keeps in registers
+            std::vector<float> wpf((size_t)2 * (Hh / 4) * KGT * 256);
+            o = 0;
+            for (int d = 0; d < 2; ++d)
+                for (int quad = 0; quad < Hh / 4; ++quad)
+                    for (int kg = 0; kg < KGT; ++kg)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j) {
+                                const int col = lane & 15, g = col >> 2, us = col & 3;
+                                wpf[o++] = whh[d][(size_t)(g * Hh + 4 * quad + us) * Hh + 16 * kg + 4 * (lane >> 4) + j];
+                            }
+            if (upload(e->whh_p[l], wpf, st)) return bail(1);
         }
     }
     {   // head
@@ -959,7 +1037,7 @@ void pocr_destroy(pocr_engine *e) {
     for (auto &b : e->conv_w) b.release();
     for (auto &b : e->cconst) b.release();
     for (auto &b : e->conv_b) b.release();
-    for (auto &v : {&e->proj_w, &e->proj_b, &e->whh})
+    for (auto &v : {&e->proj_w, &e->proj_b, &e->whh, &e->whh_p})
         for (auto &b : *v) b.release();
     for (auto &L : e->sa)
         for (DevBuf *b : {&L.w_in, &L.b_in, &L.w_out, &L.b_out, &L.w1, &L.b1, &L.w2, &L.b2, &L.n1w, &L.n1b, &L.n2w, &L.n2b}) b->release();
@@ -988,7 +1066,9 @@ void pocr_destroy(pocr_engine *e) {
         for (auto &kv : s.lstm_graphs) (void)hipGraphExecDestroy(kv.second);
         s.lstm_graphs.clear();
         s.lstm_dims.release();
+        s.lstm_flags.release();
         if (s.lstm_dims_host) (void)hipHostFree(s.lstm_dims_host);
+        if (s.lstm_err_host) (void)hipHostFree(s.lstm_err_host);
         if (s.host_in) (void)hipHostFree(s.host_in);
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);

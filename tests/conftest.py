@@ -27,7 +27,10 @@ class Golden:
         self.name = name
 
     def __getattr__(self, k):
-        return self.meta[k]
+        try:
+            return self.__dict__["meta"][k]
+        except KeyError:
+            raise AttributeError(k) from None
 
     @property
     def n(self):
@@ -86,6 +89,13 @@ class Golden:
                 self._srow_off = np.concatenate([[0], np.cumsum([len(r) for r in self.meta["sample_rows"]])])
             return self._whole("rows_all")[int(self._srow_off[i]):int(self._srow_off[i + 1])]
         return self.arrays[f"rows_{i}"]
+
+    def rows64(self, i):
+        """The sampled rows computed in float64 by the restated network (oracle/gen_truth_rows.py), or None."""
+        if "rows64_all" not in self.arrays.files:
+            return None
+        self.rows(i)                     # builds _srow_off
+        return self._whole("rows64_all")[int(self._srow_off[i]):int(self._srow_off[i + 1])]
 
     def l2(self, i):
         if "l2_all" in self.arrays.files:

@@ -328,6 +328,57 @@ def test_c4_full_batch_matches_reference_golden(golden, tmp_path):
     assert _check_full_tensor_stats(g, logits) < LOGIT_TOL
 
 
+def test_lstm_persistent_launch_matches_step_kernel(monkeypatch):
+    """The one-launch-per-layer recurrence (csrc/lstm_persist.hpp: resident workgroups, h handed over through L2 with
+    per-slice counters; opt-in with POCR_LSTM_PERSIST=1) against the shipped per-step kernel (csrc/lstm.hpp) and the oracle, on launch shapes
+    that exercise every path of its item pipeline: one slice (every item waits), two, three and many slices, ragged
+    line lengths inside a slice, a line count that is not a multiple of 16, a batch of one, hidden sizes 64 / 128 / 256."""
+    chars = synth.make_charset(40)
+    for hidden, layers in ((256, 2), (128, 1), (64, 2)):
+        spec = netspec.NetSpec(num_classes=len(chars) + 1, lstm_hidden=hidden, lstm_layers=layers)
+        weights = netspec.generate_weights(spec, 20260928 + hidden)
+        flat = netspec.pack_weights(spec, weights)
+        monkeypatch.setenv("POCR_LSTM_PERSIST", "0")
+        step_eng = _native.NativeEngine(spec, flat, 0)
+        monkeypatch.setenv("POCR_LSTM_PERSIST", "1")
+        pers_eng = _native.NativeEngine(spec, flat, 0)
+        net = model_oracle.OracleNet(spec, weights)
+        cases = [[96], [130, 40, 77], [64] * 16, [200, 33] + [90] * 19, [48] * 35 + [300, 17, 5], [120] * 70 + [64, 31]]
+        if hidden != 256:
+            cases = cases[:4]
+        for k, widths in enumerate(cases):
+            crops = synth.make_crops(50 + k, widths)
+            w_pads = [(-(-w // 32) * 32) + 64 for w in widths]          # every line padded on its own: ragged frame counts
+            pool = np.concatenate([c.reshape(-1) for c in crops])
+            sizes = np.array([c.size for c in crops], dtype=np.int64)
+            offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+            outs = []
+            for eng in (step_eng, pers_eng):
+                eng.slot_stage_ragged(0, pool, offs, np.array(widths, np.int32), w_pads, 32)
+                eng.slot_launch(0, want_logits=True, want_argmax=True)
+                logits, amax, labels, lens = eng.slot_collect(0)
+                ys = [eng.debug_read(10 + l) for l in range(layers)]
+                outs.append((logits, amax, labels, lens, ys))
+            (l0, a0, lab0, len0, y0), (l1, a1, lab1, len1, y1) = outs
+            for l in range(layers):
+                assert y0[l].shape == y1[l].shape
+                assert float(np.max(np.abs(y0[l] - y1[l]))) < 5e-6, f"H={hidden} case {k} layer {l}"
+            assert float(np.max(np.abs(l0 - l1))) < 1e-4
+            srt = np.sort(l0, axis=1)
+            safe = (srt[:, -1] - srt[:, -2]) > 1e-3
+            assert np.array_equal(a0[safe], a1[safe])
+            # and against the oracle, line by line (each line in its own padded width)
+            row = 0
+            for i, (crop, wp) in enumerate(zip(crops, w_pads)):
+                batch = engine_oracle.assemble_batch([crop], [0], spec.height, wp - 64, 3840)
+                ref = model_oracle.forward_logits(net, batch)[0].T                  # [T, C]
+                got = l1[row:row + ref.shape[0]]
+                assert float(np.max(np.abs(got - ref))) < LOGIT_TOL, f"H={hidden} case {k} line {i}"
+                row += ref.shape[0]
+        step_eng.close()
+        pers_eng.close()
+
+
 def test_pipelined_slots_match_blocking_calls(small):
     """stage/launch/collect on both slots (two chunks in flight) == the blocking calls, bit for bit;
     misuse of the slot protocol is reported, not silently accepted."""
@@ -393,14 +444,20 @@ def test_c3_page_stream_over_rccl_matches_reference_golden(golden, tmp_path):
     # per-frame argmax of the whole stream through the plain engine (dense logits of 330k frames stay off the fixture)
     texts, logits, coords = eng.process_lines(lines, sparse_logits=False)
     assert texts == g.transcriptions and coords == g.logit_coords
-    worst = 0.0
+    # Logits.  On lines of 200+ frames the float32 REFERENCE is itself up to 1.1e-3 away from exact arithmetic on a few
+    # logits (oracle/gen_truth_rows.py; line 1530, class 63), so the fixture also holds the sampled rows computed in
+    # float64: this build must be within 1e-3 of THAT, and within 1e-3 of the reference plus the reference's own deviation.
+    worst_truth = worst_ref = 0.0
     for i in range(g.n):
         li = np.asarray(logits[i])
         assert np.array_equal(np.argmax(li, axis=1), g.argmax(i)), f"line {i}: per-frame argmax differs"
-        worst = max(worst, float(np.max(np.abs(li[g.sample_rows[i]] - g.rows(i)))))
+        got, ref, truth = li[g.sample_rows[i]], g.rows(i), g.rows64(i)
+        worst_truth = max(worst_truth, float(np.max(np.abs(got - truth))))
+        worst_ref = max(worst_ref, float(np.max(np.abs(got - ref) - np.abs(ref - truth))))
         l2 = float(np.sqrt(np.sum(li.astype(np.float64) ** 2)))
         assert abs(l2 - g.l2(i)) < 1e-4 * max(1.0, l2)
-    assert worst < LOGIT_TOL, worst
+    assert worst_truth < LOGIT_TOL, worst_truth
+    assert worst_ref < LOGIT_TOL, worst_ref
 
 
 def test_rccl_allgather_and_allreduce_world1():
