@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define POCR_ABI_VERSION 7
+#define POCR_ABI_VERSION 8
 #define POCR_NUM_SLOTS 2
 
 typedef struct pocr_engine pocr_engine;
@@ -241,6 +241,25 @@ int pocr_crop_curves(int device_id, const uint8_t *page_hwc, int32_t H, int32_t 
  * Long lines are recognised in overlapping parts and every seam costs one such search: O(n^3), seconds in the
  * reference's Python, milliseconds here. */
 int32_t pocr_best_overlap(const int32_t *a, int32_t na, const int32_t *b, int32_t nb);
+
+/* ---- layout network: replaces Net.__init__ (torch.jit.load of the ParseNet model,
+ * pero_ocr/layout_engines/torch_parsenet.py:8-20) and TorchParseNet.get_maps (:37-58) - area down-sampling by an
+ * integer factor (cv2.resize INTER_AREA, :42), zero canvas padded to multiples of 64 (:44-47), uint8 * (1/255.) (:50),
+ * the network, crop to the un-padded size (:56).  Network = this build's "parsenet_unet64" (pero_ocr_amd/parsenet_spec.py;
+ * the reference's model is an opaque download); weights = float32 blob in parsenet_spec.tensor_table() order.
+ *   img_hwc : uint8 [H][W][3] page;  downsample >= 1 (1 = no resize)
+ *   out_hw5 : float32 [h][w][5] with (h, w) = pocr_parsenet_out_shape(H, W, downsample) = cvRound(H / ds), cvRound(W / ds);
+ *             channels: 0, 1 line heights above / below the baseline, 2 baseline, 3 line end, 4 region border.
+ * The host-side adaptive resolution loop (get_maps_with_optimal_resolution, :60-103) stays in the host language
+ * (pero_ocr_amd/layout_engines/torch_parsenet.py).  Blocking; one handle = one GPU + one stream. */
+typedef struct pocr_parsenet pocr_parsenet;
+size_t pocr_parsenet_num_weight_floats(void);
+int pocr_parsenet_create(const float *weights, size_t n_floats, int device_id, pocr_parsenet **out);
+void pocr_parsenet_destroy(pocr_parsenet *p);
+int pocr_parsenet_out_shape(int32_t h, int32_t w, int32_t downsample, int32_t *out_h, int32_t *out_w);
+int pocr_parsenet_get_maps(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, int32_t W, int32_t downsample, float *out_hw5);
+/* GPU time in ms of the last get_maps between the end of the upload and the end of the last kernel (HIP events). */
+int pocr_parsenet_last_ms(pocr_parsenet *p, float *ms);
 
 /* ---- measurement / test taps (not part of the reference surface) ----
  * Per-stage GPU time of the last pocr_run_* call in milliseconds, measured with HIP

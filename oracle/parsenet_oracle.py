@@ -1,0 +1,71 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/model_oracle.py header).
+
+PyTorch-CPU fp32 restatement of the layout network this build defines behind the reference's TorchParseNet contract
+(pero_ocr/layout_engines/torch_parsenet.py:37-58: canvas padded to multiples of 64, `* (1/255.)`, `out_map, _ = net(x)`,
+crop to the un-padded size).  Topology: pero_ocr_amd/parsenet_spec.py ("parsenet_unet64"): stock nn.Conv2d / max_pool2d /
+nearest interpolate / cat.  The reference's own network is an opaque TorchScript download that is not in the tree, so what
+pins this restatement is the reference's get_maps run on the scripted module (oracle/gen_golden_parsenet.py ->
+tests/golden/parsenet_*.npz): network parity is pinned by those fixtures, not by reference-held vectors.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from pero_ocr_amd import parsenet_spec as ps
+
+
+class ParseNetOracle(nn.Module):
+    def __init__(self, weights: Dict[str, np.ndarray]):
+        super().__init__()
+        self.enc = nn.ModuleList()
+        for name, cin, cout, _pool in ps.ENCODER:
+            conv = nn.Conv2d(cin, cout, 3, padding=1)
+            conv.weight.data = torch.from_numpy(weights[f"{name}.weight"].copy())
+            conv.bias.data = torch.from_numpy(weights[f"{name}.bias"].copy())
+            self.enc.append(conv)
+        self.dec = nn.ModuleList()
+        for name, cup, cskip, cout in ps.DECODER:
+            conv = nn.Conv2d(cup + cskip, cout, 3, padding=1)
+            conv.weight.data = torch.from_numpy(weights[f"{name}.weight"].copy())
+            conv.bias.data = torch.from_numpy(weights[f"{name}.bias"].copy())
+            self.dec.append(conv)
+        self.head = nn.Conv2d(ps.HEAD_IN, ps.OUT_CHANNELS, 1)
+        self.head.weight.data = torch.from_numpy(weights["head.weight"].copy())
+        self.head.bias.data = torch.from_numpy(weights["head.bias"].copy())
+        self.eval()
+
+    def features(self, x: torch.Tensor) -> torch.Tensor:
+        """[N,3,H,W] (H, W multiples of 64) -> decoder output y0 [N,64,H,W]"""
+        skips = []
+        for k, conv in enumerate(self.enc):
+            x = F.relu(conv(x))
+            if ps.ENCODER[k][3] == 2:
+                x = F.max_pool2d(x, 2)
+            elif k + 1 < len(self.enc):
+                skips.append(x)                     # e0 .. e5 feed the decoder; e6 is the bottleneck
+        for conv in self.dec:
+            skip = skips.pop()
+            x = F.relu(conv(torch.cat([F.interpolate(x, scale_factor=2.0, mode="nearest"), skip], dim=1)))
+        return x
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        z = self.head(self.features(x))
+        out = torch.cat([F.relu(z[:, 0:2]), torch.sigmoid(z[:, 2:5])], dim=1)
+        return out, z                               # the reference unpacks two outputs (torch_parsenet.py:51)
+
+
+def get_maps(net: ParseNetOracle, img_u8: np.ndarray) -> np.ndarray:
+    """TorchParseNet.get_maps after its cv2.resize (torch_parsenet.py:44-56): uint8 [h, w, 3] -> float32 [h, w, 5]."""
+    h, w = img_u8.shape[:2]
+    hp, wp = ps.padded_shape(h, w)
+    canvas = np.zeros((1, hp, wp, 3), dtype=np.uint8)
+    canvas[0, :h, :w] = img_u8
+    with torch.no_grad():
+        x = torch.from_numpy(canvas).float().permute(0, 3, 1, 2) * (1 / 255.)
+        out, _ = net(x)
+    return out.permute(0, 2, 3, 1).numpy()[0, :h, :w, :]

@@ -14,7 +14,7 @@ import numpy as np
 from .netspec import NetSpec
 
 LIB_NAME = "libpocr_hip.so"
-ABI_VERSION = 7
+ABI_VERSION = 8
 UNIQUE_ID_BYTES = 128
 STAGE_NAMES = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv8", "conv9",
                "agg", "lstm", "head", "ctc", "total")
@@ -78,6 +78,12 @@ SYMBOLS = {
     "pocr_allgather_labels": (C.c_int, [C.c_void_p, _i32p, C.c_int64, _i32p]),
     "pocr_comm_allreduce_max": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "pocr_device_synchronize": (C.c_int, [C.c_void_p]),
+    "pocr_parsenet_num_weight_floats": (C.c_size_t, []),
+    "pocr_parsenet_create": (C.c_int, [_f32p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "pocr_parsenet_destroy": (None, [C.c_void_p]),
+    "pocr_parsenet_out_shape": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p]),
+    "pocr_parsenet_get_maps": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, C.c_int32, _f32p]),
+    "pocr_parsenet_last_ms": (C.c_int, [C.c_void_p, _f32p]),
     "pocr_last_stage_ms": (C.c_int, [C.c_void_p, _f32p, C.c_int32]),
     "pocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "pocr_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -393,6 +399,50 @@ class NativeEngine:
         if self._lib.pocr_debug_read(self._h, what, _ptr(out, _f32p), out.size, C.byref(n)):
             raise RuntimeError("pocr_debug_read: " + self._err())
         return out
+
+
+class NativeParseNet:
+    """Owns one pocr_parsenet handle: the layout network on one GPU (include/pocr.h "layout network")."""
+
+    def __init__(self, flat_weights: np.ndarray, device_id: int = 0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        w = np.ascontiguousarray(flat_weights, dtype=np.float32)
+        if self._lib.pocr_parsenet_create(_ptr(w, _f32p), w.size, int(device_id), C.byref(self._h)):
+            raise RuntimeError("pocr_parsenet_create: " + (self._lib.pocr_last_error() or b"").decode("utf8", "replace"))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pocr_parsenet_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def out_shape(self, h: int, w: int, downsample: int = 1):
+        oh, ow = C.c_int32(0), C.c_int32(0)
+        if self._lib.pocr_parsenet_out_shape(int(h), int(w), int(downsample), C.byref(oh), C.byref(ow)):
+            raise RuntimeError("pocr_parsenet_out_shape: " + (self._lib.pocr_last_error() or b"").decode("utf8", "replace"))
+        return oh.value, ow.value
+
+    def get_maps(self, img: np.ndarray, downsample: int = 1) -> np.ndarray:
+        """uint8 [H, W, 3] -> float32 [h, w, 5] (area down-sampling by the integer `downsample`, padding, network, crop)."""
+        im = np.ascontiguousarray(img, dtype=np.uint8)
+        if im.ndim != 3 or im.shape[2] != 3:
+            raise ValueError(f"expected a uint8 [H, W, 3] page, got {im.shape}")
+        h, w = self.out_shape(im.shape[0], im.shape[1], downsample)
+        out = np.empty((h, w, 5), dtype=np.float32)
+        if self._lib.pocr_parsenet_get_maps(self._h, _ptr(im, _u8p), im.shape[0], im.shape[1], int(downsample), _ptr(out, _f32p)):
+            raise RuntimeError("pocr_parsenet_get_maps: " + (self._lib.pocr_last_error() or b"").decode("utf8", "replace"))
+        return out
+
+    def last_ms(self) -> float:
+        ms = C.c_float(0)
+        self._lib.pocr_parsenet_last_ms(self._h, C.byref(ms))
+        return float(ms.value)
 
 
 def ctc_greedy(logits_ntc: np.ndarray, device_id: int = 0):

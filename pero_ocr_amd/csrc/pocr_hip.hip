@@ -24,6 +24,7 @@
 #include "lstm_persist.hpp"
 #include "sparsify.hpp"
 #include "comm.hpp"
+#include "parsenet.hpp"
 
 using namespace pocr;
 
@@ -2091,3 +2092,5 @@ int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t
 }
 
 }  // extern "C"
+
+#include "parsenet_host.hpp"

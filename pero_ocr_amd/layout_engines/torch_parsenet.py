@@ -1,0 +1,133 @@
+"""Layout network on the MI355X with the reference's TorchParseNet surface.
+
+Drop-in for pero_ocr/layout_engines/torch_parsenet.py:23-103: class name, constructor
+`(model_path, device, downsample=4, max_mp=5, detection_threshold=0.2, adaptive_downsample=True)`, the public
+attributes the layout engine reads (`last_downsample`, `detection_threshold`, ...), `get_maps(img, downsample)`,
+`get_maps_with_optimal_resolution(img)` and `get_med_height(out_map)`.  Where the reference does `torch.jit.load(model_path)`
+and `self.net(x)` (:15, :51) this class hands the uint8 page to hand-written HIP kernels through the C ABI
+(include/pocr.h, pocr_parsenet_*).  There is no CPU fallback.
+
+`model_path` names a POCRP001 weight blob of this build's "parsenet_unet64" network (pero_ocr_amd/parsenet_spec.py); if the
+file does not exist a path of the form "seed:<int>" gives seeded synthetic weights (no real pero checkpoint can be fetched).
+
+cv2.resize(INTER_AREA) of the reference (:42) runs on the device for integer factors (the default downsample 4 and every
+integer the adaptive loop lands on); fractional factors - the adaptive second pass - are resampled on the host with the
+same area-averaging rule.  Both are restatements of OpenCV's algorithm (cv2 is not installed here): parity unpinned.
+"""
+from __future__ import annotations
+
+import os
+import struct
+
+import numpy as np
+
+from .. import _native, parsenet_spec
+from ..ocr_engine.pytorch_ocr_engine import _device_index
+
+MAGIC = b"POCRP001"
+
+
+def save_blob(path: str, weights) -> None:
+    flat = parsenet_spec.pack_weights(weights)
+    with open(path, "wb") as f:
+        f.write(MAGIC)
+        f.write(struct.pack("<Q", flat.size))
+        f.write(flat.tobytes())
+
+
+def load_blob(path: str) -> np.ndarray:
+    with open(path, "rb") as f:
+        if f.read(8) != MAGIC:
+            raise ValueError(f"{path}: not a POCRP001 layout-network blob")
+        (n,) = struct.unpack("<Q", f.read(8))
+        flat = np.frombuffer(f.read(), dtype=np.float32)
+    if flat.size != n or n != parsenet_spec.num_weight_floats():
+        raise ValueError(f"{path}: {flat.size} floats, the network needs {parsenet_spec.num_weight_floats()}")
+    return flat
+
+
+def resize_area(img: np.ndarray, downsample: float) -> np.ndarray:
+    """Host INTER_AREA for a fractional factor (the device handles integers): output pixel = area-weighted mean of the
+    source rectangle it covers, rounded to nearest; output size cvRound(size / downsample) like cv2.resize(fx=1/ds)."""
+    h, w = img.shape[:2]
+    oh, ow = int(np.rint(h / downsample)), int(np.rint(w / downsample))
+
+    def weights(n_in, n_out):
+        scale = n_in / n_out
+        m = np.zeros((n_out, n_in), dtype=np.float64)
+        for o in range(n_out):
+            a, b = o * scale, min((o + 1) * scale, n_in)
+            i0, i1 = int(np.floor(a)), int(np.ceil(b))
+            for i in range(i0, min(i1, n_in)):
+                m[o, i] = min(b, i + 1) - max(a, i)
+            m[o] /= m[o].sum()
+        return m
+    wy, wx = weights(h, oh), weights(w, ow)
+    out = np.einsum("oh,hwc->owc", wy, img.astype(np.float64))
+    out = np.einsum("pw,owc->opc", wx, out)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+class Net(object):
+    def __init__(self, model_path, device, max_mp=5):
+        self.max_megapixels = max_mp if max_mp is not None else 5
+        self.device = device
+        if model_path is None:
+            self.net = None
+            return
+        if os.path.exists(model_path):
+            flat = load_blob(model_path)
+        elif str(model_path).startswith("seed:"):
+            flat = parsenet_spec.pack_weights(parsenet_spec.generate_weights(int(str(model_path)[5:])))
+        else:
+            raise FileNotFoundError(f"layout-network blob {model_path} not found (use 'seed:<int>' for synthetic weights)")
+        self.net = _native.NativeParseNet(flat, _device_index(device))
+
+
+class TorchParseNet(Net):
+    def __init__(self, model_path, device, downsample=4, max_mp=5, detection_threshold=0.2, adaptive_downsample=True):
+        super().__init__(model_path, device=device, max_mp=max_mp)
+        self.detection_threshold = detection_threshold
+        self.adaptive_downsample = adaptive_downsample
+        self.init_downsample = downsample
+        self.last_downsample = downsample
+        self.downsample_line_pixel_adapt_threshold = 100
+        self.min_line_processing_height = 9
+        self.max_line_processing_height = 15
+        self.optimal_line_processing_height = 12
+        self.min_downsample = 1
+        self.max_downsample = 8
+
+    def get_maps(self, img, downsample):
+        """ParseNet inference (torch_parsenet.py:37-58): uint8 [H, W, 3] -> float32 [h, w, 5]."""
+        ds = float(downsample)
+        if ds == int(ds) and ds >= 1:
+            return self.net.get_maps(img, int(ds))
+        return self.net.get_maps(resize_area(np.asarray(img), ds), 1)
+
+    def get_maps_with_optimal_resolution(self, img):
+        """The reference's memory-safe two-pass scheme (:60-93): a first pass at max(last_downsample, megapixel limit);
+        if enough line pixels were found and their median height is outside 9..15 px, the factor that would make it
+        12 px is adopted (clamped to 1..8 and to the megapixel limit) and, when it differs by more than 20 %, run."""
+        limit = np.sqrt((img.shape[0] * img.shape[1]) / (self.max_megapixels * 10e5))
+        first = max(self.last_downsample, limit)
+        net_downsample = first
+        out_map = self.get_maps(img, net_downsample)
+        if not self.adaptive_downsample:
+            return out_map, net_downsample
+        if (out_map[:, :, 2] > self.detection_threshold).sum() > self.downsample_line_pixel_adapt_threshold:
+            med_height = self.get_med_height(out_map)
+            if med_height > self.max_line_processing_height or med_height < self.min_line_processing_height:
+                second = first * (med_height / self.optimal_line_processing_height)
+                second = max(min(second, self.max_downsample), self.min_downsample)
+                self.last_downsample = second
+                second = max(self.last_downsample, limit)
+                if second / first < 0.8 or second / first > 1.2:
+                    net_downsample = second
+                    out_map = self.get_maps(img, net_downsample)
+        return out_map, net_downsample
+
+    def get_med_height(self, out_map):
+        """Median predicted line height over the detected baseline pixels (:95-103)."""
+        heights = (out_map[:, :, 2] > self.detection_threshold).astype(float) * out_map[:, :, 0]
+        return np.median(heights[heights > 0])

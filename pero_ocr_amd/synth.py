@@ -62,6 +62,27 @@ def make_crops(seed: int, widths: Sequence[int], height: int = 40, indices: Sequ
     return [make_crop(seed, int(k), int(w), height) for k, w in zip(indices, widths)]
 
 
+def make_page(seed: int, height: int, width: int, line_height: int = 40, n_lines: int = None) -> np.ndarray:
+    """A synthetic page `uint8 [height, width, 3]`: light noisy background with text lines (make_crop) pasted at seeded
+    positions - the input of the layout network and of the line cropper."""
+    noise = uniform01(seed, 0x9A6E, height * width).reshape(height, width)
+    g = np.floor(225.0 + 25.0 * noise + 0.5).astype(np.uint8)
+    page = np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))
+    pitch = int(line_height * 1.6)
+    rows = max(1, (height - line_height) // pitch)
+    n = rows if n_lines is None else min(n_lines, rows)
+    u = uniform01(seed, 0x9A6F, 2 * n)
+    for k in range(n):
+        wl = int((0.35 + 0.6 * u[2 * k]) * width)
+        wl = max(8, min(wl, width - 8))
+        x0 = int(u[2 * k + 1] * (width - wl))
+        y0 = line_height // 2 + k * pitch
+        if y0 + line_height > height:
+            break
+        page[y0:y0 + line_height, x0:x0 + wl] = make_crop(seed + 17, k, wl, line_height)
+    return page
+
+
 def make_widths(seed: int, n: int, lo: int = 128, hi: int = 1024) -> List[int]:
     """n widths uniform in [lo, hi] (BASELINE config 3's seeded width distribution)."""
     u = uniform01(seed, 0x71D7, n)
