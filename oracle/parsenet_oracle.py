@@ -69,3 +69,24 @@ def get_maps(net: ParseNetOracle, img_u8: np.ndarray) -> np.ndarray:
         x = torch.from_numpy(canvas).float().permute(0, 3, 1, 2) * (1 / 255.)
         out, _ = net(x)
     return out.permute(0, 2, 3, 1).numpy()[0, :h, :w, :]
+
+
+def area_downsample_int(img_u8: np.ndarray, ds: int) -> np.ndarray:
+    """cv2.resize(img, (0,0), fx=1/ds, fy=1/ds, INTER_AREA) for an integer ds (torch_parsenet.py:42), restated from
+    OpenCV's resize.cpp (ResizeAreaFast_Invoker, 8-bit): block sum * float(1/ds^2) rounded to nearest even, 2x2 blocks as
+    (sum + 2) >> 2, border blocks averaged over the pixels that exist; output size cvRound(size / ds).
+    PARITY UNPINNED: cv2 is not installed here."""
+    h, w = img_u8.shape[:2]
+    oh, ow = int(np.rint(h / ds)), int(np.rint(w / ds))
+    out = np.zeros((oh, ow, img_u8.shape[2]), np.uint8)
+    for y in range(oh):
+        for x in range(ow):
+            blk = img_u8[y * ds:min((y + 1) * ds, h), x * ds:min((x + 1) * ds, w)].astype(np.int64)
+            cnt = blk.shape[0] * blk.shape[1]
+            s = blk.reshape(cnt, -1).sum(axis=0) if cnt else np.zeros(img_u8.shape[2], np.int64)
+            if cnt == ds * ds:
+                v = (s + 2) >> 2 if ds == 2 else np.rint(s.astype(np.float32) * np.float32(1.0 / (ds * ds)))
+            else:
+                v = np.rint(s.astype(np.float32) / np.float32(max(cnt, 1)))
+            out[y, x] = np.clip(v, 0, 255).astype(np.uint8)
+    return out
