@@ -17,8 +17,12 @@ Workloads (--workload, default c2):
       (300+ chunks), chunk-sharded over the ranks (LPT), one all-gather of the labels per pass - STRONG scaling.
       One "step" = the whole stream; inputs come from host memory every step (that is the path).
   c4  BASELINE configs[3]: 256 x 40x768, self-attention encoder instead of the BiLSTM (W_pad 832, T 208).
+  c5  BASELINE configs[4]: end to end on a synthetic 4k x 3k page - layout network (ParseNet contract, downsample 4) ->
+      layout post-processing STUB (baselines = the page generator's ground truth; cnn_layout_engine is out of scope) ->
+      line cropper -> line OCR (c2's engine, default batch_size 8) -> strings.  One "step" = one page; pages/s.
+      With N GPUs every rank processes its own pages (pages are independent jobs: no collective in the data path).
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4]
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5]
 With --gpus N > 1 and no WORLD_SIZE in the environment bench.py starts the N ranks itself
 (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...); under torchrun it reads RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_*.  Fewer than N visible GPUs is an error, never a silent 1-GPU run.
@@ -44,6 +48,7 @@ WORKLOADS = {
     "c2": dict(fixture="c2", n_lines=256, width=512, batch_size=274, crop_seed=305),
     "c3": dict(fixture="c3", batch_size=8),
     "c4": dict(fixture="c4", n_lines=256, width=768, batch_size=410, crop_seed=501),
+    "c5": dict(fixture="c2", batch_size=8, page_h=3072, page_w=4096),
 }
 
 
@@ -170,7 +175,7 @@ def main():
     if args.steps is None:
         args.steps = 5 if args.workload == "c3" else 20
     if args.warmup is None:
-        args.warmup = 1 if args.workload == "c3" else 3
+        args.warmup = 1 if args.workload == "c3" else 3 if args.workload != "c5" else 2
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus, sys.argv[1:])
@@ -212,7 +217,80 @@ def main():
     stage_sum = {}
     extra = {}
 
-    if args.workload == "c3":
+    if args.workload == "c5":
+        # ------------------------------------------------------------------ c5: page -> layout maps -> crops -> text
+        from pero_ocr_amd import parsenet_spec
+        from pero_ocr_amd.document_ocr.page_ocr import LineCropper, PageOCR
+        from pero_ocr_amd.layout_engines import torch_parsenet
+
+        class Line:
+            def __init__(self, i, baseline, heights):
+                self.id, self.baseline, self.heights = f"r0-l{i}", np.array(baseline), heights
+                self.crop = self.transcription = self.logits = self.characters = self.logit_coords = None
+                self.transcription_confidence = None
+
+        class Layout:
+            def __init__(self, lines):
+                self.lines = lines
+
+            def lines_iterator(self):
+                return iter(self.lines)
+
+        ph, pw = wl["page_h"], wl["page_w"]
+        n_pages = 4                                  # distinct pages, cycled
+        pages = [synth.make_page(900 + 10 * rank + k, ph, pw) for k in range(n_pages)]
+        boxes = [synth.page_line_boxes(900 + 10 * rank + k, ph, pw) for k in range(n_pages)]
+        pn_path = os.path.join(tmp.name, "parsenet.pocrp")
+        torch_parsenet.save_blob(pn_path, parsenet_spec.generate_weights(20261001))
+        parsenet = torch_parsenet.TorchParseNet(pn_path, Dev(local_rank), downsample=4, adaptive_downsample=False)
+        cropper = LineCropper({"LINE_HEIGHT": str(spec.height), "INTERP": "2", "LINE_SCALE": "1.0"}, device_id=local_rank)
+        page_ocr = PageOCR({"OCR_JSON": os.path.join(tmp.name, "ocr.json")}, Dev(local_rank))
+        stage = {"layout_net": 0.0, "crop": 0.0, "ocr": 0.0}
+        lines_done = 0
+
+        def one_page(k):
+            nonlocal lines_done
+            t_a = time.perf_counter()
+            maps, ds = parsenet.get_maps_with_optimal_resolution(pages[k])
+            assert maps.shape == (ph // 4, pw // 4, 5) and ds == 4
+            # layout post-processing stub: the generator's line boxes as baselines (3 points, 30 px above / 10 px below)
+            layout = Layout([Line(i, [[x0, y0 + 30], [x0 + wd // 2, y0 + 30], [x0 + wd, y0 + 30]], [30, 10])
+                             for i, (x0, y0, wd) in enumerate(boxes[k])])
+            t_b = time.perf_counter()
+            cropper.process_page(pages[k], layout)
+            t_c = time.perf_counter()
+            page_ocr.process_page(pages[k], layout)
+            t_d = time.perf_counter()
+            stage["layout_net"] += t_b - t_a; stage["crop"] += t_c - t_b; stage["ocr"] += t_d - t_c
+            lines_done += len(layout.lines)
+            return [ln.transcription for ln in layout.lines]
+
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):      # the engine prints the reference's "Line too long" warnings
+            for i in range(args.warmup):
+                one_page(i % n_pages)
+            for k in stage:
+                stage[k] = 0.0
+            lines_done = 0
+            fence()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                texts = one_page(i % n_pages)
+            fence()
+            elapsed = time.perf_counter() - t0
+        assert all(isinstance(t, str) for t in texts)
+        lines_per_step = 1 * world                  # unit of this workload: pages
+        scaling = "weak"
+        extra["unit_note"] = "value is PAGES/s for this workload"
+        extra["lines_per_page"] = lines_done / args.steps
+        extra["lines_per_s"] = round(lines_done * world / elapsed, 1)
+        extra["stage_ms_per_page"] = {k: round(1e3 * v / args.steps, 3) for k, v in stage.items()}
+        extra["layout_net_gpu_ms"] = round(parsenet.net.last_ms(), 3)
+        workload_txt = (f"c5: {ph}x{pw} synthetic page per step per GPU: layout network (parsenet_unet64, downsample 4 -> {ph // 4}x{pw // 4}) -> "
+                        f"layout post-processing stub (ground-truth baselines of the {len(boxes[0])} pasted lines) -> GPU line cropper -> "
+                        "VGG+BiLSTM+CTC line OCR (default batch_size 8, sparse logits + confidences) -> strings; inputs: host page per step")
+        w_pad = None
+    elif args.workload == "c3":
         # ------------------------------------------------------------------ c3: sharded page stream (strong scaling)
         widths = meta["widths"]
         lines = synth.make_crops(meta["crop_seed"], widths, spec.height, meta.get("crop_indices"))
@@ -326,9 +404,10 @@ def main():
 
     if rank == 0:
         result = {
-            "metric": "text-line crops/s (CTC-decoded) at 40x512" if args.workload != "c4" else "text-line crops/s (CTC-decoded) at 40x768",
-            "value": round(lines_per_step * args.steps / elapsed, 1),
-            "unit": "lines/s",
+            "metric": {"c4": "text-line crops/s (CTC-decoded) at 40x768", "c5": "pages/s end to end (4k x 3k page: layout net + crop + line OCR)"}.get(
+                args.workload, "text-line crops/s (CTC-decoded) at 40x512"),
+            "value": round(lines_per_step * args.steps / elapsed, 2 if args.workload == "c5" else 1),
+            "unit": "pages/s" if args.workload == "c5" else "lines/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
@@ -372,7 +451,7 @@ def main():
                                      "what": "LayerNorm+PE, encoder layers (QKV / attention / out / FFN) and the head, stage events"}
             result["stage_ms"] = {k: round(v, 4) for k, v in ms.items()}
         result.update(extra)
-        if world == 1 and not args.no_cpu_baseline and args.workload != "c3":
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("c2", "c4"):
             result["cpu_baseline"] = cpu_baseline(spec, weights, crops, wl["width"], wl["batch_size"])
         print(json.dumps(result), flush=True)
     if transport is not None:

@@ -62,16 +62,14 @@ def make_crops(seed: int, widths: Sequence[int], height: int = 40, indices: Sequ
     return [make_crop(seed, int(k), int(w), height) for k, w in zip(indices, widths)]
 
 
-def make_page(seed: int, height: int, width: int, line_height: int = 40, n_lines: int = None) -> np.ndarray:
-    """A synthetic page `uint8 [height, width, 3]`: light noisy background with text lines (make_crop) pasted at seeded
-    positions - the input of the layout network and of the line cropper."""
-    noise = uniform01(seed, 0x9A6E, height * width).reshape(height, width)
-    g = np.floor(225.0 + 25.0 * noise + 0.5).astype(np.uint8)
-    page = np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))
+def page_line_boxes(seed: int, height: int, width: int, line_height: int = 40, n_lines: int = None):
+    """(x0, y0, width) of the text lines make_page pastes: the ground truth a layout post-processing stub can hand to
+    the line cropper (baseline at 3/4 of the line height)."""
     pitch = int(line_height * 1.6)
     rows = max(1, (height - line_height) // pitch)
     n = rows if n_lines is None else min(n_lines, rows)
     u = uniform01(seed, 0x9A6F, 2 * n)
+    boxes = []
     for k in range(n):
         wl = int((0.35 + 0.6 * u[2 * k]) * width)
         wl = max(8, min(wl, width - 8))
@@ -79,6 +77,17 @@ def make_page(seed: int, height: int, width: int, line_height: int = 40, n_lines
         y0 = line_height // 2 + k * pitch
         if y0 + line_height > height:
             break
+        boxes.append((x0, y0, wl))
+    return boxes
+
+
+def make_page(seed: int, height: int, width: int, line_height: int = 40, n_lines: int = None) -> np.ndarray:
+    """A synthetic page `uint8 [height, width, 3]`: light noisy background with text lines (make_crop) pasted at seeded
+    positions - the input of the layout network and of the line cropper."""
+    noise = uniform01(seed, 0x9A6E, height * width).reshape(height, width)
+    g = np.floor(225.0 + 25.0 * noise + 0.5).astype(np.uint8)
+    page = np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))
+    for k, (x0, y0, wl) in enumerate(page_line_boxes(seed, height, width, line_height, n_lines)):
         page[y0:y0 + line_height, x0:x0 + wl] = make_crop(seed + 17, k, wl, line_height)
     return page
 
