@@ -1,0 +1,292 @@
+// conv_bf16x3.hpp — 3x3 implicit-GEMM convolution with fp32-level accuracy on the bf16 matrix pipe.
+//
+// v_mfma_f32_16x16x4_f32 (conv_igemm.hpp) runs at the fp32 VECTOR rate, 1/16 of the bf16 MFMA rate, and the conv
+// backbone sits at 85-89 % of that 157.3 TFLOP/s peak: the only way up is a different arithmetic.  Every fp32 operand is
+// split EXACTLY into three bf16 values (8 significand bits each, by truncation: x = hi + mid + lo, all of x's sign):
+//     a*b = ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh) + O(2^-24 |a*b|)
+// i.e. six v_mfma_f32_16x16x32_bf16 per 32-deep product block instead of eight f32 MFMAs: 6 x 16 cycles instead of
+// 8 x 32 per wave -> 2.67x the fp32-MFMA rate.  Products of two bf16 values are exact in fp32, accumulation is fp32 inside
+// the MFMA, the three dropped terms are each <= 2^-24 of the product: the same error class as one fp32 rounding.
+//
+// Layout / tiling as conv_igemm_kernel: M = 16 consecutive pixels of an image row, N = output channels, the 4 waves of
+// a workgroup split N, each wave keeps TH*MW row tiles x NS channel tiles of accumulators (same D layout -> same fused
+// bias / activation / BatchNorm / max-pool epilogue).  K chunk = 32 input channels:
+//   A: the halo tile is split by the stager, once per 32-channel chunk, into three bf16 planes in LDS
+//      ([plane][channel octet][pixel][8 bf16]); a lane's A operands (pixel, 8 channels) are three conflict-free ds_read_b128;
+//      the tile is single-buffered (one extra barrier per chunk = per 9 steps) to leave LDS for two workgroups per CU;
+//   B: weights split on the host, fragment order wsplit[tap][cin/32][cout/16][plane 3][lane][8 bf16]
+//      = W[cout = 16 s + (lane & 15)][cin = 32 g + 8 (lane >> 4) + j][tap], streamed through a double-buffered LDS tile.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "conv_igemm.hpp"
+
+namespace pocr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// exact three-way split of 8 floats into packed bf16 (truncation keeps the sign and makes hi + mid + lo == x bit for bit)
+__device__ __forceinline__ void split3_bf16(const f32x4 &p, const f32x4 &q, u32x4 &hi, u32x4 &mid, u32x4 &lo) {
+    float x[8] = {p[0], p[1], p[2], p[3], q[0], q[1], q[2], q[3]};
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned xb = __builtin_bit_cast(unsigned, x[i]);
+        h[i] = xb & 0xffff0000u;
+        const float r1 = x[i] - __builtin_bit_cast(float, h[i]);
+        m[i] = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, m[i]);
+        l[i] = __builtin_bit_cast(unsigned, r2) & 0xffff0000u;       // r2 has <= 8 significant bits left: exact
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (h[2 * i] >> 16) | h[2 * i + 1];
+        mid[i] = (m[2 * i] >> 16) | m[2 * i + 1];
+        lo[i] = (l[2 * i] >> 16) | l[2 * i + 1];
+    }
+}
+
+#define POCR_MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+
+// split of one float4 (4 consecutive channels) into three pairs of packed bf16 (8 bytes per plane)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_quad(const f32x4 p, u32x2 &hi, u32x2 &mid, u32x2 &lo) {
+    unsigned h[4], m[4], l[4];
+    const float x[4] = {p[0], p[1], p[2], p[3]};        // (bit-casting the vector element expression p[i] itself reads element 0: hipcc 7.2)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned xb = __builtin_bit_cast(unsigned, x[i]);
+        h[i] = xb & 0xffff0000u;
+        const float r1 = x[i] - __builtin_bit_cast(float, h[i]);
+        m[i] = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, m[i]);
+        l[i] = __builtin_bit_cast(unsigned, r2) & 0xffff0000u;
+    }
+    hi = (u32x2){(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+    mid = (u32x2){(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+    lo = (u32x2){(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
+}
+
+// WM waves split the pixel tile (column strips), 4 / WM waves split the output channels; the B tile (weights of one
+// (chunk, tap) step for NT channels) is shared through LDS by the WM waves that need it, the A halo tile - already split
+// into its three bf16 planes by the stager, once per 32-channel chunk - by all of them.
+template <int TH, int MW, int NS, int WM, int POOLH, int POOLW, int ACT, bool BN, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
+    constexpr int NWAVE = 4, WN = NWAVE / WM, KC = 32;
+    static_assert(MW % WM == 0, "column strips must divide among the M waves");
+    constexpr int TW = 16 * MW, MWW = MW / WM, MS = TH * MWW, NT = NS * WN * 16, NTHR = 256;
+    constexpr int HH = TH + 2, HW = TW + 2, NP = HH * HW, NPPAD = (NP + 15) / 16 * 16;
+    constexpr int CQ = KC / 4;
+    constexpr int PS = 4 * NPPAD;                       // 16-byte units per bf16 plane of the A tile ([octet][pixel])
+    constexpr int A_U = 3 * PS;                         // A tile, single-buffered (refilled once per chunk)
+    constexpr int B_F4 = (NT / 16) * 3 * 64;            // 16-byte units per B buffer (one (chunk, tap) step)
+    constexpr int A_LD = (CQ * NP + NTHR - 1) / NTHR;
+    constexpr int B_LD = (B_F4 + NTHR - 1) / NTHR;
+    static_assert(POOLH == 1 || TH % 2 == 0, "H-pool needs an even tile height");
+    __shared__ u32x4 lds[A_U + 2 * B_F4];               // one scalar type (unsigned) for every access: no type punning
+    u32x4 *ldsA = lds;
+    u32x4 *ldsB = lds + A_U;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int wm = wave % WM, wn = wave / WM;
+
+    // block -> tile mapping (as conv_igemm_kernel)
+    int nt, ptile;
+    {
+        const int tn = a.tiles_n;
+        const int P = a.tiles ? a.n_ptiles : a.tiles_w * a.tiles_h * a.n;
+        if (tn >= 2 && tn <= 8 && (tn & (tn - 1)) == 0) {
+            const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, groups = 8 / tn;
+            nt = xcd % tn;
+            ptile = k * groups + xcd / tn;
+            if (ptile >= P) return;
+        } else {
+            int b = blockIdx.x;
+            const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
+            b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+            nt = b % tn;
+            ptile = b / tn;
+        }
+    }
+    int wt, ht, img, Win;
+    size_t img_base, out_base;
+    if (a.tiles) {
+        const PixelTile pt = a.tiles[ptile];
+        img = pt.line; ht = pt.ht_wt >> 16; wt = pt.ht_wt & 0xffff;
+        Win = a.line_w[img];
+        img_base = (size_t)a.in_off[img];
+        out_base = (size_t)a.out_off[img];
+    } else {
+        wt = ptile % a.tiles_w;
+        ht = (ptile / a.tiles_w) % a.tiles_h;
+        img = ptile / (a.tiles_w * a.tiles_h);
+        Win = a.W;
+        img_base = (size_t)img * a.H * a.W * a.cin;
+        out_base = (size_t)img * (a.Ho / POOLH) * (a.Wo / POOLW) * a.out_stride;
+    }
+    const int h0 = ht * TH, w0 = wt * TW;
+
+    f32x4 acc[MS][NS], acc2[MS][NS];                    // main term / the five small terms
+#pragma unroll
+    for (int m = 0; m < MS; ++m)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { acc[m][s] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[m][s] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int nchunks = a.cin / KC;
+    unsigned a_off[A_LD];
+    bool a_ok[A_LD];
+    int a_lds[A_LD];                                    // index (8-byte units) of the quad's slot inside plane 0, -1 = none
+#pragma unroll
+    for (int r = 0; r < A_LD; ++r) {
+        const int e = tid + r * NTHR;
+        const int cq = e % CQ, p = e / CQ;
+        const int hr = p / HW, wc = p % HW;
+        const int hi = h0 - 1 + hr, wi = w0 - 1 + wc;
+        a_ok[r] = e < CQ * NP && hi >= 0 && hi < a.H && wi >= 0 && wi < Win;
+        a_off[r] = a_ok[r] ? (unsigned)((hi * Win + wi) * a.cin + cq * 4) : 0u;
+        a_lds[r] = e < CQ * NP ? ((cq >> 1) * NPPAD + p) * 2 + (cq & 1) : -1;
+    }
+    const float *ximg = a.x + img_base;
+    const f32x4 *wt4 = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * (NT / 16) * 192;     // 192 x 16 B per cout tile
+    const size_t chunk_stride = (size_t)a.cout16 * 192, tap_stride = (size_t)nchunks * chunk_stride;
+    f32x4 ra[A_LD], rb[B_LD];
+    auto ldA = [&](int chunk) {
+#pragma unroll
+        for (int r = 0; r < A_LD; ++r)
+            ra[r] = a_ok[r] ? *reinterpret_cast<const f32x4 *>(ximg + chunk * KC + a_off[r]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto stA = [&]() {                                  // split into the three bf16 planes on the way into LDS
+        u32x2 *base = reinterpret_cast<u32x2 *>(ldsA);
+#pragma unroll
+        for (int r = 0; r < A_LD; ++r)
+            if (a_lds[r] >= 0) {
+                u32x2 hi, mid, lo;
+                split3_quad(ra[r], hi, mid, lo);
+                base[a_lds[r]] = hi;
+                base[a_lds[r] + 2 * PS] = mid;
+                base[a_lds[r] + 4 * PS] = lo;
+            }
+    };
+    auto ldB = [&](const f32x4 *tile) {
+#pragma unroll
+        for (int r = 0; r < B_LD; ++r) {
+            const int f = tid + r * NTHR;
+            if (B_F4 % NTHR == 0 || f < B_F4) rb[r] = tile[f];
+        }
+    };
+    auto stB = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < B_LD; ++r) {
+            const int f = tid + r * NTHR;
+            if (B_F4 % NTHR == 0 || f < B_F4) ldsB[buf * B_F4 + f] = __builtin_bit_cast(u32x4, rb[r]);
+        }
+    };
+    ldA(0);
+    ldB(wt4);
+    stA();
+    stB(0);
+    __syncthreads();
+    int step = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool next_chunk = chunk + 1 < nchunks;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++step) {
+            const bool last = tap == 8, more = !last || next_chunk;
+            const int bcur = step & 1;
+            if (more) ldB(wt4 + (size_t)(last ? 0 : tap + 1) * tap_stride + (size_t)(last ? chunk + 1 : chunk) * chunk_stride);
+            if (tap == 0 && next_chunk) ldA(chunk + 1);
+            const int dy = tap / 3, dx = tap % 3;
+            const u32x4 *Ab = ldsA + dy * HW + dx + li + kq * NPPAD + wm * MWW * 16;
+            const u32x4 *Bb = ldsB + bcur * B_F4 + (wn * NS) * 192 + lane;
+            u32x4 bh[NS], bm[NS], bl[NS];
+#pragma unroll
+            for (int n = 0; n < NS; ++n) { bh[n] = Bb[n * 192]; bm[n] = Bb[n * 192 + 64]; bl[n] = Bb[n * 192 + 128]; }
+#pragma unroll
+            for (int m = 0; m < MS; ++m) {
+                const int o = (m / MWW) * HW + (m % MWW) * 16;
+                const u32x4 ah = Ab[o], am = Ab[o + PS], al = Ab[o + 2 * PS];
+                // The main term (hi x hi) and the five small terms run in SEPARATE accumulators, added once in the epilogue:
+                // the running sum of the main term sees one rounding per 32-deep block (the fp32-MFMA chain: 32), and the
+                // small terms round at their own magnitude, 2^-8 of the main one.  Measured against float64: 3x closer than
+                // the fp32-MFMA chain.  Terms outermost, so consecutive MFMAs never depend on each other.
+#pragma unroll
+                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(al, bh[n], acc2[m][n]);
+#pragma unroll
+                for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_BF16(ah, bh[n], acc[m][n]);
+#pragma unroll
+                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bm[n], acc2[m][n]);
+#pragma unroll
+                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bl[n], acc2[m][n]);
+#pragma unroll
+                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bh[n], acc2[m][n]);
+#pragma unroll
+                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bm[n], acc2[m][n]);
+            }
+            if (more) stB(bcur ^ 1);
+            if (last && next_chunk) {
+                __syncthreads();                        // every wave has read the last tap of this chunk's halo tile
+                stA();
+            }
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int m = 0; m < MS; ++m)
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc[m][n] += acc2[m][n];
+    // ---- epilogue (identical to conv_igemm_kernel: same D layout)
+    const int Wo = Win, Wout = Wo / POOLW;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        const int co = (nt * (NT / 16) + wn * NS + n) * 16 + li;
+        const float bias = a.bias[co];
+        float sc = 1.f, sh = 0.f;
+        if constexpr (BN) { sc = a.bn_scale[co]; sh = a.bn_shift[co]; }
+        const bool co_ok = co < a.cout_valid;
+#pragma unroll
+        for (int th = 0; th < TH; th += POOLH) {
+#pragma unroll
+            for (int mw = 0; mw < MWW; ++mw) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = apply_act(acc[th * MWW + mw][n][r] + bias, ACT);
+                    if constexpr (BN) t = t * sc + sh;
+                    if constexpr (POOLH == 2) {
+                        float u = apply_act(acc[(th + 1) * MWW + mw][n][r] + bias, ACT);
+                        if constexpr (BN) u = u * sc + sh;
+                        t = fmaxf(t, u);
+                    }
+                    v[r] = t;
+                }
+                const int ho = (h0 + th) / POOLH;
+                const int wbase = w0 + (wm * MWW + mw) * 16 + kq * 4;
+                float *yrow = a.y + out_base + ((size_t)ho * Wout) * a.out_stride + co;
+                if constexpr (POOLW == 2) {
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int wc = wbase + 2 * rr;
+                        if (co_ok && h0 + th < a.Ho && wc + 1 < Wo) yrow[(size_t)(wc / 2) * a.out_stride] = fmaxf(v[2 * rr], v[2 * rr + 1]);
+                    }
+                } else {
+                    quad_transpose(v, lane);
+                    const int wc = wbase + (li & 3);
+                    float *dst = yrow - (li & 3) + (size_t)wc * a.out_stride;
+                    const int c4 = co - (li & 3);
+                    if (wc < Wo && h0 + th < a.Ho) {
+                        if (c4 + 3 < a.cout_valid && (a.out_stride & 3) == 0) {
+                            *reinterpret_cast<f32x4 *>(dst) = (f32x4){v[0], v[1], v[2], v[3]};
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (c4 + k < a.cout_valid) dst[k] = v[k];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace pocr

@@ -16,6 +16,7 @@
 #include "../../include/pocr.h"
 #include "conv_igemm.hpp"
 #include "conv1_u8.hpp"
+#include "conv_bf16x3.hpp"
 #include "ctc.hpp"
 #include "encoder.hpp"
 #include "decoder.hpp"
@@ -128,6 +129,22 @@ POCR_CONV(gemm128_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_NONE, false, STAGE_F3
 POCR_CONV(gemm64_k,  1, 1, 0, 0, 1, 8, 1, 4, 16, 1, 1, ACT_NONE, false, STAGE_F32_NHWC, PIPE_DEEP)   // rows x 64 cols per WG
 POCR_CONV(gemm128_relu_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_F32_NHWC, PIPE_DEEP)   // FFN first linear
 const int kConvNT[9] = {64, 64, 128, 128, 128, 128, 128, 256, 256};
+// The same layers on the bf16 matrix pipe with fp32-level accuracy (conv_bf16x3.hpp: three-way exact operand split, six
+// bf16 MFMAs per product block); tile configurations from tools/conv_bench_bf16.hip.  (TH, MW, NS, WM, POOLH, POOLW, ACT, BN)
+#define POCR_CONV3(name, TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW)                                              \
+    int name(ConvArgs a, hipStream_t st) {                                                                         \
+        return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW>, TH, 16 * MW,         \
+                           NS * (4 / WM) * 16, 256, a, st);                                                        \
+    }
+// pixel tiles as in the fp32 table below (same tile tables); measured per layer in profiles/r02_conv_bf16x3_bench.txt
+POCR_CONV3(conv2_b3,  4, 4, 4, 4, 2, 2, ACT_RELU, false, 2)    // 64->64 + pool 2x2: 4x64 px, NT 64, waves split M
+POCR_CONV3(conv3_b3,  4, 2, 2, 1, 1, 1, ACT_RELU, false, 1)    // 64->128: 4x32 px, NT 128
+POCR_CONV3(conv4_b3,  4, 2, 2, 1, 2, 2, ACT_RELU, false, 1)    // 128->128 + pool 2x2
+POCR_CONV3(conv56_b3, 10, 1, 2, 1, 1, 1, ACT_RELU, false, 1)   // ->256: 10x16 px, NT 128
+POCR_CONV3(conv7_b3,  10, 1, 2, 1, 2, 1, ACT_RELU, false, 1)   // 256->256 + pool 2x1
+POCR_CONV3(conv8_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2)   // 256->512: 5x16 px, NT 128, two workgroups per CU
+POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2)    // 512->512 + BN
+const int kConvNT3[9] = {64, 64, 128, 128, 128, 128, 128, 128, 128};
 // pixel-tile shape (TH, 16*MW) of conv1..conv9 and of the aggregation conv - the same numbers as in the table above
 const int kConvTH[10] = {4, 4, 4, 4, 10, 10, 10, 5, 5, 1};
 const int kConvTW[10] = {32, 64, 32, 32, 16, 16, 16, 16, 16, 48};
@@ -250,6 +267,7 @@ struct pocr_engine {
     std::vector<DecLayer> dec;
     DevBuf dec_embed, dec_out_w, dec_out_b;
     int dec_out_cout16 = 0;
+    bool bf16x3 = true;              // conv2..conv9 on the bf16 matrix pipe with the exact 3-way operand split (POCR_CONV_FP32=1: fp32 MFMA)
     DevBuf cconst[9];                // per conv layer: the output column [H_out][cout] far inside zero padding
     bool pad_skip = false;           // skip + fill constant padding tiles (POCR_NO_PAD_SKIP=1 turns it off)
     bool cconst_ready = false;       // the constants are computed when a launch first needs them
@@ -355,6 +373,17 @@ int run_network(pocr_engine *e, Slot &s) {
         } else {
             a.x = s.act[i - 1].as<float>(); a.cin = L.cin;
             if (i == 8) { a.bn_scale = e->bn_scale.as<float>(); a.bn_shift = e->bn_shift.as<float>(); }
+            if (e->bf16x3) {
+                switch (i) {
+                    case 1: rc = conv2_b3(a, st); break;
+                    case 2: rc = conv3_b3(a, st); break;
+                    case 3: rc = conv4_b3(a, st); break;
+                    case 4: case 5: rc = conv56_b3(a, st); break;
+                    case 6: rc = conv7_b3(a, st); break;
+                    case 7: rc = conv8_b3(a, st); break;
+                    default: rc = conv9_b3(a, st); break;
+                }
+            } else {
             switch (i) {
                 case 1: rc = conv2_k(a, st); break;
                 case 2: rc = conv3_k(a, st); break;
@@ -363,6 +392,7 @@ int run_network(pocr_engine *e, Slot &s) {
                 case 6: rc = conv7_k(a, st); break;
                 case 7: rc = conv8_k(a, st); break;
                 default: rc = conv9_k(a, st); break;
+            }
             }
         }
         if (rc) return rc;
@@ -852,6 +882,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     e->cfg = *cfg;
     if (const char *env = getenv("POCR_NO_GRAPHS")) e->use_graphs = atoi(env) == 0;
     if (const char *env = getenv("POCR_LSTM_PERSIST")) e->lstm_persist = atoi(env) != 0;
+    if (const char *env = getenv("POCR_CONV_FP32")) e->bf16x3 = atoi(env) == 0;
     e->device = device_id;
     auto bail = [&](int rc) { pocr_destroy(e); return rc; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
@@ -882,8 +913,37 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         const ConvLayer &L = kConvPlan[i];
         const float *w = cur.take((size_t)L.cout * L.cin * 9);
         const float *b = cur.take(L.cout);
-        const int cout16 = round_up(L.cout, kConvNT[i]) / 16;
+        const bool b3 = e->bf16x3 && i > 0;
+        const int cout16 = round_up(L.cout, b3 ? kConvNT3[i] : kConvNT[i]) / 16;
         e->conv_cout16[i] = cout16;
+        if (b3) {
+            // wsplit[tap][cin/32][cout16][plane][lane][8 bf16] = plane of W[co = 16 s + (lane & 15)][ci = 32 g + 8 (lane >> 4) + j][tap];
+            // hi / mid / lo = the exact truncation split of conv_bf16x3.hpp
+            std::vector<uint16_t> wsp((size_t)9 * (L.cin / 32) * cout16 * 3 * 64 * 8);
+            size_t o = 0;
+            for (int tap = 0; tap < 9; ++tap)
+                for (int g = 0; g < L.cin / 32; ++g)
+                    for (int sg = 0; sg < cout16; ++sg)
+                        for (int pl = 0; pl < 3; ++pl)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 8; ++j, ++o) {
+                                    const int co = 16 * sg + (lane & 15), ci = 32 * g + 8 * (lane >> 4) + j;
+                                    const float wv = co < L.cout ? w[((size_t)co * L.cin + ci) * 9 + tap] : 0.f;
+                                    uint32_t wb; memcpy(&wb, &wv, 4);
+                                    const uint32_t hb = wb & 0xffff0000u; float hf; memcpy(&hf, &hb, 4);
+                                    const float r1 = wv - hf; uint32_t r1b; memcpy(&r1b, &r1, 4);
+                                    const uint32_t mb = r1b & 0xffff0000u; float mf; memcpy(&mf, &mb, 4);
+                                    const float r2 = r1 - mf; uint32_t r2b; memcpy(&r2b, &r2, 4);
+                                    const uint32_t parts[3] = {hb, mb, r2b & 0xffff0000u};
+                                    wsp[o] = (uint16_t)(parts[pl] >> 16);
+                                }
+            std::vector<float> bias(cout16 * 16, 0.f);
+            for (int k = 0; k < L.cout; ++k) bias[k] = b[k];
+            if (e->conv_w[i].reserve(wsp.size() * 2)) return bail(1);
+            if (hipMemcpy(e->conv_w[i].p, wsp.data(), wsp.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return bail(fail("weight upload failed"));
+            if (upload(e->conv_b[i], bias, st)) return bail(1);
+            continue;
+        }
         std::vector<float> frag;
         if (i == 0) {   // im2col form: one tap, "cin" k = (ky*3+kx)*3 + c, padded 27 -> 32
             frag = build_wfrag(1, 32, cout16, [&](int co, int k, int) { const int tap = k / 3, c = k % 3; return w[((size_t)co * 3 + c) * 9 + tap]; }, 27, L.cout);
