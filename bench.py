@@ -42,6 +42,12 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # same guide: dense bf16 MFMA peak (v_mfma_f32_32x32x16 / 16x16x32_bf16)
+# conv2..conv9 run on the bf16 pipe with fp32-level accuracy (csrc/conv_bf16x3.hpp): every fp32 operand is split exactly into
+# three bf16 values and a 32-deep product block costs SIX bf16 MFMAs, so the ceiling for ALGORITHMIC conv FLOPs is
+# 2500 / 6 = 416.7 TFLOP/s.  POCR_CONV_FP32=1 selects the fp32-MFMA kernels (ceiling 157.3).
+BF16X3 = os.environ.get("POCR_CONV_FP32", "0") in ("", "0")
+CONV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0 if BF16X3 else F32_MFMA_PEAK_TFLOPS
 HEIGHT = 40
 WORKLOADS = {
     # fixture = tests/golden/<name>: weight seed / kwargs / calibrated head bias (and, for c3, the page stream itself)
@@ -411,7 +417,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (convs: fp32 values as exact sums of three bf16, fp32 accumulate)" if BF16X3 else "f32", "data": "synthetic",
             "config": {"workload": workload_txt, "lines_per_step": lines_per_step,
                        "parallelism": f"chunk-sharded x{world}, one RCCL all-gather of labels per step (C ABI)"
                                       if transport is not None else "single GPU, no collective",
@@ -420,9 +426,10 @@ def main():
         if w_pad is not None:
             traffic = None          # HBM bytes per launch of the dominant kernel, from the committed PMC passes
             try:
-                pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_summary.json")))
+                pmc = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_summary.json" if BF16X3 else "pmc_summary.json")))
                 for kname, ctr in pmc.items():
-                    if "5, 1, 4, 4, 16, 1, 1, 2, true" in kname and "hbm_bytes_per_launch" in ctr and args.workload == "c2":
+                    if ("bf16x3" in kname) == BF16X3 and ("5, 1, 4, 4, 16, 1, 1, 2, true" in kname or "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true" in kname) \
+                            and "hbm_bytes_per_launch" in ctr and args.workload == "c2":
                         traffic = ctr["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
@@ -431,17 +438,24 @@ def main():
             dom_tf = fl[dom] * n_lines / (ms[dom] * 1e-3) / 1e12
             conv_ms = sum(ms[k] for k in fl)
             conv_tf = sum(fl.values()) * n_lines / (conv_ms * 1e-3) / 1e12
+            kname = ("conv3x3_bf16x3_kernel<TH5,MW1,NS2,leaky+BN>" if BF16X3 else "conv_igemm_kernel<3x3,TH5,NT256,leaky+BN>")
             result["roofline"] = {
-                "bound": "mfma", "kernel": f"conv_igemm_kernel<3x3,TH5,NT256,leaky+BN> ({dom}, 512->512 @5x{w_pad // 4})",
-                "achieved": round(dom_tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(dom_tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "bound": "mfma", "kernel": f"{kname} ({dom}, 512->512 @5x{w_pad // 4})",
+                "achieved": round(dom_tf, 2), "peak": round(CONV_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
+                "frac": round(dom_tf / CONV_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (KiB -> B; gfx950 FETCH_SIZE x2 correction) from "
-                                "separate rocprofv3 --pmc passes of this bench, profiles/pmc_summary.json",
+                                "separate rocprofv3 --pmc passes of this bench, profiles/r02_pmc_summary.json",
                 "flops_per_launch": fl[dom] * n_lines, "avg_launch_ms": round(ms[dom], 4),
-                "peak_dtype": "fp32 MFMA (v_mfma_f32_16x16x4_f32), dense"}
-            result["conv_backbone"] = {"achieved": round(conv_tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": round(conv_tf / F32_MFMA_PEAK_TFLOPS, 4),
-                                       "gflop_per_line": round(sum(fl.values()) / 1e9, 3), "ms_per_step": round(conv_ms, 3)}
+                "peak_dtype": ("algorithmic fp32 FLOPs on the bf16 MFMA pipe: exact 3-way bf16 split, 6 v_mfma_f32_16x16x32_bf16 per "
+                               "32-deep block -> ceiling = 2500 TFLOP/s dense bf16 / 6; executed MFMA rate = 6 x achieved"
+                               if BF16X3 else "fp32 MFMA (v_mfma_f32_16x16x4_f32), dense"),
+                "mfma_pipe_frac": round((6.0 if BF16X3 else 1.0) * dom_tf / (BF16_MFMA_PEAK_TFLOPS if BF16X3 else F32_MFMA_PEAK_TFLOPS), 4),
+                "vs_fp32_mfma_peak_157.3": round(dom_tf / F32_MFMA_PEAK_TFLOPS, 4)}
+            result["conv_backbone"] = {"achieved": round(conv_tf, 2), "peak": round(CONV_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
+                                       "frac": round(conv_tf / CONV_PEAK_TFLOPS, 4),
+                                       "vs_fp32_mfma_peak_157.3": round(conv_tf / F32_MFMA_PEAK_TFLOPS, 4),
+                                       "gflop_per_line": round(sum(fl.values()) / 1e9, 3), "ms_per_step": round(conv_ms, 3),
+                                       "note": "conv1 (K = 27) and the aggregation conv stay on the fp32-MFMA kernels" if BF16X3 else ""}
             if spec.arch == netspec.ARCH_SA:
                 E, FF, Tn = spec.conv_out, spec.sa_ff, (w_pad // 2) // 2
                 enc_fl = spec.sa_layers * (2.0 * Tn * (4 * E * E + 2 * E * FF) + 4.0 * Tn * Tn * E) + 2.0 * Tn * E * spec.num_classes
