@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define POCR_ABI_VERSION 8
+#define POCR_ABI_VERSION 9
 #define POCR_NUM_SLOTS 2
 
 typedef struct pocr_engine pocr_engine;
@@ -234,6 +234,46 @@ int pocr_crop_lines(int device_id, const uint8_t *page_hwc, int32_t H, int32_t W
 int pocr_crop_curves(int device_id, const uint8_t *page_hwc, int32_t H, int32_t W, int32_t C, const double *curves,
                      const double *rows, const double *rot, const int32_t *widths, int32_t n, int32_t line_height,
                      uint8_t *crops, const int64_t *crop_off, float *grid_out);
+
+/* ---- resident line cropper: the whole of EngineLineCropper.crop (pero_ocr/core/crop_engine.py:16-30) for all lines of a
+ * page with the page in HBM and the per-column mathematics of get_crop_inputs (:73-89: walk the interpolated baseline at
+ * unit steps, arc length, resample at the target resolution, normals) on the device in float64, bit-identical to the
+ * reference's numpy / scipy sequence.  The host keeps the per-LINE scalars (:54-72): integer baseline, rotation R, and
+ * the interpolant f - scipy.interpolate.interp1d(kind="cubic") as its B-spline (knots t, coefficients c), or np.poly1d. */
+typedef struct pocr_cropper pocr_cropper;
+typedef struct pocr_crop_spec {
+    double x_min, x_max;   /* np.arange(x_min, x_max): the rotated baseline's extent (:73) */
+    double lo, hi;         /* interp1d's domain: outside it the reference raises and crop() returns its fallback (mode 0 only) */
+    double zoom;           /* target_height / (up + down) (:76) */
+    double above, below;   /* scaled line heights: rows = np.linspace(-above, below, line_height) (:90) */
+    double rot[4];         /* R row-major (:57) */
+    int32_t mode;          /* 0: cubic B-spline; 1: polynomial, np.poly1d coefficient order (highest power first) */
+    int32_t n_coef;        /* mode 0: number of B-spline coefficients (knots: n_coef + 4); mode 1: degree + 1 */
+    int32_t coef_off, knot_off;   /* first coefficient / knot of this line in the arrays handed to pocr_cropper_measure */
+    int32_t n_x;           /* len(np.arange(x_min, x_max)) */
+    int32_t pad_;
+} pocr_crop_spec;
+int pocr_cropper_create(int device_id, pocr_cropper **out);
+void pocr_cropper_destroy(pocr_cropper *c);
+/* Starts the upload of the page (uint8 [H][W][C], C <= 4) on a helper thread and returns at once: the caller computes its
+ * per-line splines meanwhile.  page_hwc must stay valid until pocr_cropper_wait_page / pocr_cropper_crop returns.
+ * The page stays resident for any number of measure / crop calls. */
+int pocr_cropper_set_page(pocr_cropper *c, const uint8_t *page_hwc, int32_t H, int32_t W, int32_t C);
+int pocr_cropper_wait_page(pocr_cropper *c);
+/* Arc length of every line -> widths[i] = int(arc[-1] * zoom) (the crop's width, :76); status[i] != 0: the evaluation left
+ * the interpolant's domain (the reference raises -> fallback crop).  width 0 = empty grid (also the fallback). */
+int pocr_cropper_measure(pocr_cropper *c, const pocr_crop_spec *specs, int32_t n, const double *knots, int64_t n_knots,
+                         const double *coefs, int64_t n_coefs, int32_t *widths, int32_t *status);
+/* Crops of the lines measured last: line i uint8 [line_height][widths[i]][C] at crop_off[i] - copied to `crops`, or, when
+ * crops is NULL, left in the cropper's pinned host buffer (pocr_cropper_pinned_crops, valid until the next crop call).
+ * grid_out (or NULL): the float32 [line_height][width][2] sampling grids back to back (lines with status 0), for tests.
+ * status [n]: final per-line status. */
+int pocr_cropper_crop(pocr_cropper *c, int32_t line_height, const int64_t *crop_off, uint8_t *crops, float *grid_out, int32_t *status);
+const uint8_t *pocr_cropper_pinned_crops(pocr_cropper *c);
+/* Test hook: the float64 per-column curves of the last crop call - line i (status 0 at measure time): [4][widths[i]]
+ * (base_x, base_y, normal_x, normal_y), lines back to back - for bit-comparison with the numpy / scipy sequence. */
+int pocr_cropper_read_curves(pocr_cropper *c, double *out, int64_t cap);
+float pocr_cropper_last_ms(pocr_cropper *c);
 
 /* Host-side helper (no GPU): find_best_overlap of the transformer branch (line_ocr_engine.py:196-211, edit distance
  * pero_ocr/sequence_alignment.py:4-13) on two symbol-id sequences: the overlap length i in 1..min(na, nb) whose

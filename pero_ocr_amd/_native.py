@@ -14,7 +14,7 @@ import numpy as np
 from .netspec import NetSpec
 
 LIB_NAME = "libpocr_hip.so"
-ABI_VERSION = 8
+ABI_VERSION = 9
 UNIQUE_ID_BYTES = 128
 STAGE_NAMES = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv8", "conv9",
                "agg", "lstm", "head", "ctc", "total")
@@ -28,6 +28,18 @@ class PocrConfig(C.Structure):
                 ("arch", C.c_int32), ("sa_layers", C.c_int32), ("sa_heads", C.c_int32), ("sa_ff", C.c_int32),
                 ("dec_layers", C.c_int32)]
 
+
+class CropSpec(C.Structure):
+    """pocr_crop_spec (include/pocr.h): one line of the resident cropper."""
+    _fields_ = [("x_min", C.c_double), ("x_max", C.c_double), ("lo", C.c_double), ("hi", C.c_double), ("zoom", C.c_double),
+                ("above", C.c_double), ("below", C.c_double), ("rot", C.c_double * 4), ("mode", C.c_int32), ("n_coef", C.c_int32),
+                ("coef_off", C.c_int32), ("knot_off", C.c_int32), ("n_x", C.c_int32), ("pad_", C.c_int32)]
+
+
+CROP_SPEC_DTYPE = np.dtype([("x_min", "<f8"), ("x_max", "<f8"), ("lo", "<f8"), ("hi", "<f8"), ("zoom", "<f8"), ("above", "<f8"),
+                            ("below", "<f8"), ("rot", "<f8", (4,)), ("mode", "<i4"), ("n_coef", "<i4"), ("coef_off", "<i4"),
+                            ("knot_off", "<i4"), ("n_x", "<i4"), ("pad_", "<i4")])
+assert CROP_SPEC_DTYPE.itemsize == C.sizeof(CropSpec)
 
 ARCH_IDS = {"vgg_blstm_ctc": 0, "vgg_sa_ctc": 1, "vgg_sa_s2s": 2}
 
@@ -55,6 +67,16 @@ SYMBOLS = {
     "pocr_crop_lines": (C.c_int, [C.c_int, _u8p, C.c_int32, C.c_int32, C.c_int32, _f32p, _i64p, _i32p, C.c_int32, C.c_int32, _u8p, _i64p]),
     "pocr_crop_curves": (C.c_int, [C.c_int, _u8p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double), _i32p, C.c_int32, C.c_int32, _u8p, _i64p, _f32p]),
+    "pocr_cropper_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "pocr_cropper_destroy": (None, [C.c_void_p]),
+    "pocr_cropper_set_page": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, C.c_int32]),
+    "pocr_cropper_wait_page": (C.c_int, [C.c_void_p]),
+    "pocr_cropper_measure": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double),
+                                       C.c_int64, _i32p, _i32p]),
+    "pocr_cropper_crop": (C.c_int, [C.c_void_p, C.c_int32, _i64p, _u8p, _f32p, _i32p]),
+    "pocr_cropper_pinned_crops": (C.c_void_p, [C.c_void_p]),
+    "pocr_cropper_read_curves": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64]),
+    "pocr_cropper_last_ms": (C.c_float, [C.c_void_p]),
     "pocr_num_slots": (C.c_int, []),
     "pocr_slot_stage_lines": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, C.c_int32, C.c_int32, C.c_int32]),
     "pocr_slot_stage_ragged": (C.c_int, [C.c_void_p, C.c_int32, _u8p, _i64p, _i32p, _i32p, C.c_int32, C.c_int32]),
@@ -443,6 +465,121 @@ class NativeParseNet:
         ms = C.c_float(0)
         self._lib.pocr_parsenet_last_ms(self._h, C.byref(ms))
         return float(ms.value)
+
+
+class NativeCropper:
+    """Owns one pocr_cropper handle: the resident line cropper of one GPU (include/pocr.h "resident line cropper")."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        self._page = None
+        self._n = 0
+        self._widths = None
+        if self._lib.pocr_cropper_create(int(device_id), C.byref(self._h)):
+            raise RuntimeError("pocr_cropper_create: " + self._err())
+
+    def _err(self) -> str:
+        return (self._lib.pocr_last_error() or b"").decode("utf8", "replace")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pocr_cropper_destroy(self._h)
+            self._h = C.c_void_p()
+            self._page = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_page(self, page: np.ndarray):
+        """Starts the upload of a uint8 [H, W(, C)] page and returns; the page stays resident for every later crop."""
+        img = np.ascontiguousarray(page, dtype=np.uint8)
+        if img.ndim == 2:
+            img = img[:, :, None]
+        if img.ndim != 3:
+            raise ValueError(f"expected a [H, W, C] page, got {img.shape}")
+        if self._lib.pocr_cropper_set_page(self._h, _ptr(img, _u8p), img.shape[0], img.shape[1], img.shape[2]):
+            raise RuntimeError("pocr_cropper_set_page: " + self._err())
+        self._page = img                   # keeps the buffer alive while the helper thread reads it
+        self.channels = int(img.shape[2])
+
+    def wait_page(self):
+        if self._lib.pocr_cropper_wait_page(self._h):
+            raise RuntimeError("pocr_cropper_wait_page: " + self._err())
+
+    def measure(self, specs: np.ndarray, knots: np.ndarray, coefs: np.ndarray):
+        """specs: CROP_SPEC_DTYPE [n]; -> (widths int32 [n], status int32 [n])."""
+        sp = np.ascontiguousarray(specs, dtype=CROP_SPEC_DTYPE)
+        kn = np.ascontiguousarray(knots, dtype=np.float64)
+        cf = np.ascontiguousarray(coefs, dtype=np.float64)
+        n = int(sp.shape[0])
+        widths, status = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        dp = C.POINTER(C.c_double)
+        if self._lib.pocr_cropper_measure(self._h, sp.ctypes.data_as(C.c_void_p), n, kn.ctypes.data_as(dp), kn.size, cf.ctypes.data_as(dp),
+                                          cf.size, _ptr(widths, _i32p), _ptr(status, _i32p)):
+            raise RuntimeError("pocr_cropper_measure: " + self._err())
+        self._n, self._widths, self._status0 = n, widths, status.copy()
+        return widths, status
+
+    def crop(self, line_height: int, copy: bool = True, want_grids: bool = False):
+        """Crops of the lines measured last -> (list of uint8 [line_height, w_i, C] (None where the line failed), status[, grids]).
+        copy=False: the arrays are views of the cropper's pinned buffer, valid until the next crop call."""
+        n, widths = self._n, self._widths
+        ch = self.channels
+        sizes = widths.astype(np.int64) * int(line_height) * ch
+        crop_off = np.zeros(n, dtype=np.int64)
+        np.cumsum(sizes[:-1], out=crop_off[1:])
+        total = int(sizes.sum())
+        status = np.zeros(n, dtype=np.int32)
+        grid = np.zeros(max(1, 2 * total // ch), dtype=np.float32) if want_grids else None
+        if self._lib.pocr_cropper_crop(self._h, int(line_height), _ptr(crop_off, _i64p), None, _ptr(grid, _f32p), _ptr(status, _i32p)):
+            raise RuntimeError("pocr_cropper_crop: " + self._err())
+        flat = None
+        if total:
+            addr = self._lib.pocr_cropper_pinned_crops(self._h)
+            flat = np.ctypeslib.as_array(C.cast(addr, _u8p), shape=(total,))
+            if copy:
+                flat = flat.copy()
+        crops = []
+        for i in range(n):
+            if status[i] or widths[i] == 0:
+                crops.append(None)
+            else:
+                o = int(crop_off[i])
+                crops.append(flat[o:o + int(sizes[i])].reshape(int(line_height), int(widths[i]), ch))
+        if not want_grids:
+            return crops, status
+        grids, g = [], 0
+        for i in range(n):
+            if self._status0[i] or widths[i] == 0:
+                grids.append(None)
+                continue
+            m = 2 * int(line_height) * int(widths[i])          # (a line that failed in the column kernel keeps its slot)
+            grids.append(None if status[i] else grid[g:g + m].reshape(int(line_height), int(widths[i]), 2).copy())
+            g += m
+        return crops, status, grids
+
+    def read_curves(self):
+        """Test hook: float64 [4, w_i] per line measured with status 0 (None otherwise), after crop()."""
+        total = int(4 * self._widths[self._status0 == 0].astype(np.int64).sum())
+        buf = np.zeros(max(1, total), dtype=np.float64)
+        if self._lib.pocr_cropper_read_curves(self._h, buf.ctypes.data_as(C.POINTER(C.c_double)), buf.size):
+            raise RuntimeError("pocr_cropper_read_curves: " + self._err())
+        out, o = [], 0
+        for i in range(self._n):
+            if self._status0[i]:
+                out.append(None)
+                continue
+            w = int(self._widths[i])
+            out.append(buf[o:o + 4 * w].reshape(4, w).copy())
+            o += 4 * w
+        return out
+
+    def last_ms(self) -> float:
+        return float(self._lib.pocr_cropper_last_ms(self._h))
 
 
 def ctc_greedy(logits_ntc: np.ndarray, device_id: int = 0):

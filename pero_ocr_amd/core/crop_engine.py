@@ -1,13 +1,15 @@
 """Line cropper on the GPU: counterpart of the reference's EngineLineCropper
 (pero_ocr/core/crop_engine.py:8-30, 54-111, 146-163) - same class name, constructor and `crop` contract.
 
-The sampling grid (a few hundred 1-D operations per line: rotate the baseline, fit it, walk it at the target
-resolution, add the normals) stays on the host in numpy/scipy, exactly as the reference computes it; the
-per-pixel work - extending every column along its normal, rotating back, and the bilinear remap of
-height x width x 3 samples per line - runs in a HIP kernel (`pocr_crop_curves`, csrc/crop.hpp), for all lines of
-a page in one call (`crop_lines`).
+`crop_lines` crops all lines of a page in three launches with the page resident in HBM (`pocr_cropper_*`,
+csrc/crop.hpp + crop_host.hpp).  The host keeps the per-LINE scalars of get_crop_inputs (:54-72: integer baseline,
+rotation, and the interpolant - scipy's cubic B-spline through a lean constructor that calls the same collocation and
+LAPACK routines interp1d does, or np.polyfit); everything per column (walking the interpolated baseline, arc length,
+resampling, normals: :73-89) and per pixel (:90-99, 146-163) runs on the device in float64, bit-identical to the
+numpy / scipy sequence.  `line_curves` / `get_crop_inputs` are the host statement of the same mathematics
+(return_forward_mapping, parity tests, and the older `pocr_crop_curves` entry point).
 
-`return_mapping` (the reverse mapping used for blending crops back into the page, :113-145) is not built.
+`return_mapping` (reverse mapping for blend_in, :113-145) is not built: nothing in the reference calls it.
 """
 from __future__ import annotations
 
@@ -19,6 +21,68 @@ from scipy import interpolate
 
 from .. import _native
 
+try:                                                   # the routines scipy.interpolate.make_interp_spline itself calls
+    from scipy.interpolate import _dierckx as _sp_dierckx
+    from scipy.linalg.lapack import dgbsv as _sp_dgbsv
+except Exception:                                      # another scipy: interp1d does the work (slower, same numbers)
+    _sp_dierckx = _sp_dgbsv = None
+
+_LEAN_OK: Optional[bool] = None
+
+
+def _lean_cubic(x: np.ndarray, y: np.ndarray):
+    """Knots / coefficients of scipy.interpolate.interp1d(x, y, kind="cubic")._spline without interp1d's ~100 us of
+    argument handling: the same steps with the same routines (mergesort, not-a-knot knot vector, `_coloc`, LAPACK gbsv
+    - scipy/interpolate/_bsplines.py make_interp_spline), so the same bits.  Returns None when the input is not the
+    plain case (fewer than 4 points, repeated or non-finite abscissae, singular system): the caller then lets interp1d
+    itself decide (it raises, and the reference falls back to a straight line)."""
+    n = x.size
+    if n < 4 or not (np.isfinite(x).all() and np.isfinite(y).all()):
+        return None
+    ind = np.argsort(x, kind="mergesort")
+    x, y = x[ind], y[ind]
+    if np.any(x[1:] == x[:-1]):
+        return None
+    t = np.empty(n + 4)
+    t[:4] = x[0]
+    t[4:n] = x[2:-2]
+    t[n:] = x[-1]
+    ab = np.zeros((10, n), dtype=np.float64, order="F")
+    _sp_dierckx._coloc(x, t, 3, ab.T, 0)
+    _lu, _piv, c, info = _sp_dgbsv(3, 3, ab, y.reshape(-1, 1).copy(), overwrite_ab=True, overwrite_b=True)
+    if info != 0:
+        return None
+    return t, c.ravel(), x[0], x[-1]
+
+
+def cubic_interpolant(x: np.ndarray, y: np.ndarray):
+    """(knots, coefficients, lo, hi) of interp1d(x, y, kind="cubic"); raises what interp1d raises."""
+    global _LEAN_OK
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    if _LEAN_OK is None:                               # once: the lean constructor must reproduce interp1d bit for bit
+        _LEAN_OK = False
+        if _sp_dierckx is not None and hasattr(_sp_dierckx, "_coloc"):
+            px = np.array([3.0, 410.25, 977.5, 1502.0, 2101.75, 2600.1])
+            py = np.array([7.0, 1.5, -3.25, 4.0, 2.0, -6.5])
+            try:
+                ref = interpolate.interp1d(px, py, kind="cubic")._spline
+                got = _lean_cubic(px, py)
+                _LEAN_OK = got is not None and np.array_equal(got[0], ref.t) and np.array_equal(got[1], ref.c.ravel())
+            except Exception:
+                _LEAN_OK = False
+    if _LEAN_OK:
+        got = _lean_cubic(x, y)
+        if got is not None:
+            return got
+    f = interpolate.interp1d(x, y, kind="cubic")
+    return f._spline.t, np.ascontiguousarray(f._spline.c).ravel(), f.x[0], f.x[-1]
+
+
+def _poly1d_coeffs(c) -> np.ndarray:
+    """np.poly1d(c).coeffs without the object (28 us): leading zeros trimmed, [0.] when nothing is left."""
+    c = np.trim_zeros(np.atleast_1d(c), "f")
+    return c if c.size else np.zeros(1)
+
 
 class EngineLineCropper:
     def __init__(self, correct_slant=False, line_height=32, poly=0, scale=1, blend_border=4, device_id: int = 0):
@@ -28,6 +92,31 @@ class EngineLineCropper:
         self.scale = scale
         self.blend_border = blend_border
         self.device_id = device_id
+        self._cropper: Optional[_native.NativeCropper] = None
+
+    # ---- host part of the resident cropper: the per-line scalars -----------------------------------------------------
+    def line_spec(self, baseline, line_heights, target_height):
+        """What crop_engine.py:54-72 computes per line, and the extent of :73: (fields of pocr_crop_spec, knots,
+        coefficients).  Raises what the reference's statements raise (the caller turns that into the fallback crop)."""
+        above, below = line_heights[0] * self.scale, line_heights[1] * self.scale
+        p = np.asarray(baseline).copy().astype(int)
+        alpha = math.atan2(p[-1, 1] - p[0, 1], p[-1, 0] - p[0, 0])
+        R = np.array([[np.cos(alpha), np.sin(alpha)], [-np.sin(alpha), np.cos(alpha)]])
+        p = np.dot(p, np.linalg.inv(R))
+        knots = None
+        lo, hi = -np.inf, np.inf
+        if self.poly:
+            coefs = _poly1d_coeffs(np.polyfit(p[:, 0], p[:, 1], self.poly if p.shape[0] > 2 else 1))
+        else:
+            try:
+                p[-1, 0] += 0.1
+                knots, coefs, lo, hi = cubic_interpolant(p[:, 0], p[:, 1])
+            except Exception:
+                coefs = _poly1d_coeffs(np.polyfit(p[:, 0], p[:, 1], 1))
+        x_min, x_max = p[:, 0].min(), p[:, 0].max()
+        n_x = max(0, int(math.ceil(x_max - x_min)))       # len(np.arange(x_min, x_max))
+        zoom = target_height / (above + below)
+        return (x_min, x_max, lo, hi, zoom, above, below, R.reshape(-1), 0 if knots is not None else 1, n_x), knots, np.asarray(coefs, dtype=np.float64)
 
     # ---- host part: the line's 1-D curves --------------------------------------------------------------------
     def line_curves(self, baseline, line_heights, target_height):
@@ -82,33 +171,72 @@ class EngineLineCropper:
         return (1 - da) * sampled_values[-1] + da * sampled_values[0]
 
     # ---- device part ---------------------------------------------------------------------------------------
-    def crop_lines(self, img: np.ndarray, lines: Sequence[Tuple[object, Sequence[float]]]) -> List[np.ndarray]:
-        """All lines of a page in one GPU call.  lines: (baseline, heights) pairs.  A line whose grid cannot be
-        computed gets the reference's fallback crop: zeros [line_height, 32, C] (crop_engine.py:20-22)."""
-        parts: List[Optional[tuple]] = []
-        for baseline, heights in lines:
+    def set_page(self, img: np.ndarray):
+        """Starts the upload of a page; `crop_lines(None, lines)` then crops from the resident copy, any number of times."""
+        if self._cropper is None:
+            self._cropper = _native.NativeCropper(self.device_id)
+        self._cropper.set_page(img)
+        self._page_ndim = img.ndim
+        self._page_channels = img.shape[2] if img.ndim == 3 else 1
+
+    def crop_lines(self, img: Optional[np.ndarray], lines: Sequence[Tuple[object, Sequence[float]]], copy: bool = True,
+                   want_grids: bool = False):
+        """All lines of a page: upload (behind the host's per-line work), three launches, one download.
+        lines: (baseline, heights) pairs.  img None: the page of the last set_page.  A line whose grid cannot be
+        computed gets the reference's fallback crop: zeros [line_height, 32, C] (crop_engine.py:20-22).
+        copy=False: the crops are views of a pinned buffer that the next call overwrites."""
+        if img is not None:
+            self.set_page(img)
+        elif self._cropper is None:
+            raise ValueError("crop_lines(None, ...) needs set_page first")
+        n = len(lines)
+        specs = np.zeros(n, dtype=_native.CROP_SPEC_DTYPE)
+        knots: List[np.ndarray] = []
+        coefs: List[np.ndarray] = []
+        nk = nc = 0
+        failed = np.zeros(n, dtype=bool)
+        rows = []
+        for i, (baseline, heights) in enumerate(lines):
             try:
-                part = self.line_curves(baseline, heights, self.line_height)
-                if part[0].shape[1] == 0:
-                    # a grid without columns (arc length * zoom < 1): the reference's fast_remap raises on np.amin of the
-                    # empty grid (crop_engine.py:147) and crop() falls back to the zero crop like for any other failure
-                    raise ValueError("empty sampling grid")
-                parts.append(part)
+                head, kn, cf = self.line_spec(baseline, heights, self.line_height)
             except Exception:
-                print("ERROR: line crop failed.", heights, baseline)
-                parts.append(None)
-        channels = img.shape[2] if img.ndim == 3 else 1
-        good = [p for p in parts if p is not None]
-        crops = iter(_native.crop_curves(img, [p[0] for p in good], [p[1] for p in good], [p[2] for p in good],
-                                         self.device_id)) if good else iter(())
-        out = []
-        for p in parts:
-            if p is None:
-                out.append(np.zeros([self.line_height, 32, channels], dtype=np.uint8))
-            else:
-                c = next(crops)
-                out.append(c if img.ndim == 3 else c[:, :, 0])
-        return out
+                failed[i] = True
+                rows.append(None)
+                continue
+            rows.append((head, len(cf), nc, nk))
+            coefs.append(cf)
+            nc += len(cf)
+            if kn is not None:
+                knots.append(kn)
+                nk += len(kn)
+        good = [i for i in range(n) if not failed[i]]
+        if good:
+            g = specs[:len(good)]
+            for k, i in enumerate(good):
+                head, ncf, co, ko = rows[i]
+                g[k] = head[:7] + (head[7], head[8], ncf, co, ko, head[9], 0)
+        channels = self._page_channels
+        out: List[Optional[np.ndarray]] = [None] * n
+        grids: List[Optional[np.ndarray]] = [None] * n
+        if good:
+            widths, _ = self._cropper.measure(specs[:len(good)], np.concatenate(knots) if knots else np.zeros(0),
+                                               np.concatenate(coefs))
+            res = self._cropper.crop(self.line_height, copy=copy, want_grids=want_grids)
+            for k, i in enumerate(good):
+                out[i] = res[0][k]
+                if want_grids:
+                    grids[i] = res[2][k]
+        else:
+            self._cropper.wait_page()
+        for i in range(n):
+            if out[i] is None:
+                # the reference's crop() catches every failure of get_crop_inputs / fast_remap (an empty grid raises in
+                # np.amin, crop_engine.py:147; interp1d raises outside its domain) and returns the zero crop
+                print("ERROR: line crop failed.", lines[i][1], lines[i][0])
+                out[i] = np.zeros([self.line_height, 32, channels], dtype=np.uint8)
+            if self._page_ndim == 2:
+                out[i] = out[i][:, :, 0]
+        return (out, grids) if want_grids else out
 
     def crop(self, img, baseline, heights, return_mapping=False, return_forward_mapping=False):
         if return_mapping:

@@ -1,0 +1,217 @@
+// crop_host.hpp — host side + C ABI of the resident line cropper (included by pocr_hip.hip, which provides DevBuf /
+// fail / HIP_TRY).  Replaces EngineLineCropper.crop per line (pero_ocr/core/crop_engine.py:16-30, 54-99, 146-163) by
+// three launches per PAGE: the page is uploaded once (helper thread: pageable -> pinned -> DMA in 8 MB chunks, behind
+// the caller's per-line host work) and stays in HBM for every line; the only host<->device traffic per page besides
+// the page itself is ~100 B of spline per line up, 4 B of width per line back, and the crops.
+#include <atomic>
+#include <thread>
+
+struct pocr_cropper {
+    int device = 0;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    DevBuf page, specs, knots, coefs, state, curves, out, grid;
+    void *pin_page = nullptr, *pin_out = nullptr, *pin_small = nullptr;
+    size_t pin_page_cap = 0, pin_out_cap = 0, pin_small_cap = 0;
+    int H = 0, W = 0, C = 0;
+    std::thread uploader;
+    std::atomic<int> upload_rc{0};
+    std::string upload_err;
+    int n = 0;                                 // lines of the last measure
+    std::vector<pocr::CropState> hstate;
+    float last_ms = 0.f;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+static_assert(sizeof(pocr_crop_spec) == sizeof(pocr::CropSpec), "pocr_crop_spec (include/pocr.h) and CropSpec (csrc/crop.hpp) differ");
+static_assert(offsetof(pocr_crop_spec, rot) == offsetof(pocr::CropSpec, rot) && offsetof(pocr_crop_spec, n_x) == offsetof(pocr::CropSpec, n_x),
+              "pocr_crop_spec layout");
+
+int cropper_join(pocr_cropper *c) {
+    if (c->uploader.joinable()) c->uploader.join();
+    if (c->upload_rc.load()) return fail("page upload failed: %s", c->upload_err.c_str());
+    return 0;
+}
+
+int pin_reserve(void **p, size_t *cap, size_t bytes) {
+    if (bytes <= *cap) return 0;
+    if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
+    const size_t want = bytes + bytes / 8;
+    HIP_TRY(hipHostMalloc(p, want, hipHostMallocDefault));
+    *cap = want;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pocr_cropper_create(int device_id, pocr_cropper **out) {
+    if (!out) return fail("out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available: this library has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail("device_id %d out of range (%d devices)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    auto *c = new pocr_cropper();
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return fail("cannot create the cropper's streams");
+    }
+    *out = c;
+    return 0;
+}
+
+void pocr_cropper_destroy(pocr_cropper *c) {
+    if (!c) return;
+    if (c->uploader.joinable()) c->uploader.join();
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (DevBuf *b : {&c->page, &c->specs, &c->knots, &c->coefs, &c->state, &c->curves, &c->out, &c->grid}) b->release();
+    for (void *p : {c->pin_page, c->pin_out, c->pin_small}) if (p) (void)hipHostFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+int pocr_cropper_set_page(pocr_cropper *c, const uint8_t *page_hwc, int32_t H, int32_t W, int32_t C) {
+    if (!c || !page_hwc) return fail("NULL pointer");
+    if (H <= 0 || W <= 0 || C < 1 || C > 4) return fail("bad page geometry (H %d, W %d, C %d)", H, W, C);
+    if (cropper_join(c)) return 1;
+    HIP_TRY(hipSetDevice(c->device));
+    // no kernel of an earlier page may still read the buffer the upload is about to overwrite
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t bytes = (size_t)H * W * C;
+    if (c->page.reserve(bytes) || pin_reserve(&c->pin_page, &c->pin_page_cap, bytes)) return 1;
+    c->H = H; c->W = W; c->C = C;
+    c->upload_rc.store(0);
+    c->uploader = std::thread([c, page_hwc, bytes]() {
+        const size_t chunk = (size_t)8 << 20;
+        hipError_t e = hipSetDevice(c->device);
+        for (size_t o = 0; o < bytes && e == hipSuccess; o += chunk) {
+            const size_t nb = std::min(chunk, bytes - o);
+            std::memcpy(static_cast<uint8_t *>(c->pin_page) + o, page_hwc + o, nb);
+            e = hipMemcpyAsync(static_cast<uint8_t *>(c->page.p) + o, static_cast<uint8_t *>(c->pin_page) + o, nb, hipMemcpyHostToDevice, c->copy_stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+        if (e != hipSuccess) { c->upload_err = hipGetErrorString(e); c->upload_rc.store(1); }
+    });
+    return 0;
+}
+
+int pocr_cropper_wait_page(pocr_cropper *c) {
+    if (!c) return fail("cropper is NULL");
+    return cropper_join(c);
+}
+
+int pocr_cropper_measure(pocr_cropper *c, const pocr_crop_spec *specs, int32_t n, const double *knots, int64_t n_knots,
+                         const double *coefs, int64_t n_coefs, int32_t *widths, int32_t *status) {
+    if (!c || !specs || !widths || !status || (n_knots > 0 && !knots) || (n_coefs > 0 && !coefs)) return fail("NULL pointer");
+    if (n <= 0) return fail("no lines");
+    for (int i = 0; i < n; ++i) {
+        const pocr_crop_spec &s = specs[i];
+        const int need_k = s.mode == 0 ? s.n_coef + 4 : 0;
+        if ((s.mode != 0 && s.mode != 1) || s.n_coef < (s.mode == 0 ? 4 : 1) || s.coef_off < 0 || s.coef_off + (int64_t)s.n_coef > n_coefs ||
+            s.knot_off < 0 || s.knot_off + (int64_t)need_k > n_knots || s.n_x < 0)
+            return fail("line %d: bad interpolant description (mode %d, %d coefficients)", i, s.mode, s.n_coef);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t sb = (size_t)n * sizeof(pocr::CropSpec), kb = (size_t)std::max<int64_t>(1, n_knots) * 8, cb = (size_t)std::max<int64_t>(1, n_coefs) * 8;
+    const size_t stb = (size_t)n * sizeof(pocr::CropState);
+    if (c->specs.reserve(sb) || c->knots.reserve(kb) || c->coefs.reserve(cb) || c->state.reserve(stb) ||
+        pin_reserve(&c->pin_small, &c->pin_small_cap, sb + kb + cb + stb))
+        return 1;
+    HIP_TRY(hipStreamSynchronize(c->stream));              // pin_small is reused
+    uint8_t *ps = static_cast<uint8_t *>(c->pin_small);
+    std::memcpy(ps, specs, sb);
+    if (n_knots > 0) std::memcpy(ps + sb, knots, (size_t)n_knots * 8);
+    if (n_coefs > 0) std::memcpy(ps + sb + kb, coefs, (size_t)n_coefs * 8);
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->specs.p, ps, sb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->knots.p, ps + sb, kb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->coefs.p, ps + sb + kb, cb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->state.p, 0, stb, c->stream));
+    hipLaunchKernelGGL(pocr::crop_arc_kernel, dim3(n), dim3(256), 0, c->stream, c->specs.as<pocr::CropSpec>(), c->knots.as<double>(),
+                       c->coefs.as<double>(), c->state.as<pocr::CropState>());
+    HIP_TRY(hipGetLastError());
+    pocr::CropState *hs = reinterpret_cast<pocr::CropState *>(ps + sb + kb + cb);
+    HIP_TRY(hipMemcpyAsync(hs, c->state.p, stb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->hstate.assign(hs, hs + n);
+    c->n = n;
+    for (int i = 0; i < n; ++i) { widths[i] = hs[i].width; status[i] = hs[i].status; }
+    return 0;
+}
+
+int pocr_cropper_crop(pocr_cropper *c, int32_t line_height, const int64_t *crop_off, uint8_t *crops, float *grid_out, int32_t *status) {
+    if (!c || !crop_off || !status) return fail("NULL pointer");
+    if (c->n <= 0) return fail("pocr_cropper_measure has not run");
+    if (line_height <= 0) return fail("bad line height %d", line_height);
+    if (c->H == 0) return fail("pocr_cropper_set_page has not run");
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = c->n;
+    int64_t n_curve = 0, n_out = 0, n_grid = 0;
+    int w_max = 0;
+    for (int i = 0; i < n; ++i) {
+        pocr::CropState &s = c->hstate[i];
+        if (crop_off[i] < 0) return fail("line %d: negative offset", i);
+        s.curve_off = n_curve; s.out_off = crop_off[i]; s.grid_off = n_grid;
+        if (s.status) continue;
+        n_curve += (int64_t)4 * s.width;
+        n_grid += (int64_t)2 * line_height * s.width;
+        n_out = std::max<int64_t>(n_out, crop_off[i] + (int64_t)line_height * s.width * c->C);
+        w_max = std::max(w_max, s.width);
+    }
+    const size_t stb = (size_t)n * sizeof(pocr::CropState);
+    if (w_max > 0) {
+        if (c->curves.reserve((size_t)n_curve * 8) || c->out.reserve((size_t)n_out) || (grid_out && c->grid.reserve((size_t)n_grid * 4)) ||
+            pin_reserve(&c->pin_out, &c->pin_out_cap, (size_t)n_out))
+            return 1;
+        pocr::CropState *hs = reinterpret_cast<pocr::CropState *>(c->pin_small);      // measure has synchronised: the block is free
+        std::memcpy(hs, c->hstate.data(), stb);
+        HIP_TRY(hipMemcpyAsync(c->state.p, hs, stb, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(pocr::crop_columns_kernel, dim3((w_max + 255) / 256, n), dim3(256), 0, c->stream, c->specs.as<pocr::CropSpec>(),
+                           c->knots.as<double>(), c->coefs.as<double>(), c->state.as<pocr::CropState>(), c->curves.as<double>());
+        HIP_TRY(hipGetLastError());
+        if (cropper_join(c)) return 1;                     // the page must have landed before the pixel kernel
+        hipLaunchKernelGGL(pocr::remap_spec_u8_kernel, dim3((line_height * w_max + 255) / 256, n), dim3(256), 0, c->stream, c->page.as<uint8_t>(),
+                           c->H, c->W, c->C, c->specs.as<pocr::CropSpec>(), c->state.as<pocr::CropState>(), c->curves.as<double>(), line_height,
+                           c->out.as<uint8_t>(), grid_out ? c->grid.as<float>() : (float *)nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(hs, c->state.p, stb, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->pin_out, c->out.p, (size_t)n_out, hipMemcpyDeviceToHost, c->stream));
+        if (grid_out) HIP_TRY(hipMemcpyAsync(grid_out, c->grid.p, (size_t)n_grid * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1);
+        for (int i = 0; i < n; ++i) c->hstate[i].status = hs[i].status;
+        if (crops) std::memcpy(crops, c->pin_out, (size_t)n_out);
+    } else if (cropper_join(c)) {
+        return 1;
+    }
+    for (int i = 0; i < n; ++i) status[i] = c->hstate[i].status;
+    return 0;
+}
+
+int pocr_cropper_read_curves(pocr_cropper *c, double *out, int64_t cap) {
+    if (!c || !out) return fail("NULL pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    int64_t total = 0;
+    for (int i = 0; i < c->n; ++i) if (!c->hstate[i].status || c->hstate[i].curve_off + 4 * (int64_t)c->hstate[i].width > total)
+        total = std::max<int64_t>(total, c->hstate[i].curve_off + 4 * (int64_t)c->hstate[i].width);
+    if (total > cap) return fail("curve buffer holds %lld doubles, caller offers %lld", (long long)total, (long long)cap);
+    if (total > 0) HIP_TRY(hipMemcpy(out, c->curves.p, (size_t)total * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+const uint8_t *pocr_cropper_pinned_crops(pocr_cropper *c) { return c ? static_cast<const uint8_t *>(c->pin_out) : nullptr; }
+
+float pocr_cropper_last_ms(pocr_cropper *c) { return c ? c->last_ms : 0.f; }
+
+}  // extern "C"

@@ -2154,3 +2154,4 @@ int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t
 }  // extern "C"
 
 #include "parsenet_host.hpp"
+#include "crop_host.hpp"

@@ -166,3 +166,118 @@ def test_gpu_grid_generation_matches_host_bit_exactly():
         host = eng.get_crop_inputs(baseline, heights, line_h)
         assert np.array_equal(grid, host)
         assert np.array_equal(crop, crop_oracle.remap_bilinear_u8(page, host[..., 0], host[..., 1]))
+
+
+def test_lean_cubic_constructor_equals_interp1d():
+    """The resident cropper's host half builds interp1d's B-spline through the routines make_interp_spline itself calls;
+    knots and coefficients must be interp1d's bit for bit, and the irregular inputs must raise like interp1d."""
+    from scipy import interpolate
+    from pero_ocr_amd.core import crop_engine
+    rng = np.random.RandomState(11)
+    n_ok = 0
+    for trial in range(400):
+        n = int(rng.randint(4, 14))
+        xs = rng.uniform(0, 4000, n)
+        if trial % 2:
+            xs = np.sort(xs)
+        if np.any(np.abs(np.diff(np.sort(xs))) < 0.5):
+            continue
+        ys = rng.uniform(-30, 30, n) + 1000
+        t, c, lo, hi = crop_engine.cubic_interpolant(xs, ys)
+        f = interpolate.interp1d(xs, ys, kind="cubic")
+        assert np.array_equal(t, f._spline.t) and np.array_equal(c, f._spline.c.ravel()) and lo == f.x[0] and hi == f.x[-1]
+        n_ok += 1
+    assert n_ok > 300 and crop_engine._LEAN_OK is True          # this image's scipy: the lean path is the one that ran
+    for xs, ys in (([1.0, 2.0, 3.0], [1.0, 2.0, 3.0]), ([1.0, 2.0, 2.0, 3.0, 4.0], [1.0, 2.0, 3.0, 4.0, 5.0])):
+        with pytest.raises(Exception):
+            interpolate.interp1d(xs, ys, kind="cubic")
+        with pytest.raises(Exception):
+            crop_engine.cubic_interpolant(np.array(xs), np.array(ys))
+
+
+def test_line_spec_describes_the_same_line_as_line_curves():
+    for c, _ref in cases():
+        eng = EngineLineCropper(line_height=c["line_height"], poly=c["poly"], scale=c["scale"])
+        head, knots, coefs = eng.line_spec(np.array(c["baseline"]), c["heights"], c["line_height"])
+        curves, rows, R = eng.line_curves(np.array(c["baseline"]), c["heights"], c["line_height"])
+        assert np.array_equal(head[7], R.reshape(-1)) and rows[0] == -head[5] and rows[-1] == head[6]
+        assert (knots is None) == (head[8] == 1) and head[9] == len(np.arange(head[0], head[1]))
+
+
+def _random_lines(rng, n, width, height):
+    out = []
+    for _ in range(n):
+        k = int(rng.randint(2, 9))
+        xs = np.sort(rng.choice(np.arange(20, width - 20), size=k, replace=False))
+        ys = 60 + rng.randint(0, height - 120) + rng.randint(-12, 13, size=k)
+        if rng.rand() < 0.2:
+            xs = xs[::-1]                                           # right-to-left baselines rotate by ~180 degrees
+        out.append((np.stack([xs, ys], axis=1), [int(rng.randint(10, 40)), int(rng.randint(4, 20))]))
+    return out
+
+
+@pytest.mark.gpu
+def test_gpu_resident_cropper_grid_is_the_host_grid_bit_for_bit():
+    """The device's float64 walk along the interpolated baseline (arc length, resampling, normals - csrc/crop.hpp) must give
+    the float32 sampling grid of the host's numpy / scipy sequence (= the reference's, pinned by crop_coords.npz) bit for
+    bit, for spline and polynomial interpolants, and the crop must be the remap of that grid."""
+    rng = np.random.RandomState(16)
+    page = rng.randint(0, 256, size=(900, 1300, 3)).astype(np.uint8)
+    groups = {}
+    for c, ref in cases():
+        groups.setdefault((c["line_height"], c["poly"], c["scale"]), []).append((np.array(c["baseline"]), c["heights"], ref))
+    for baseline, heights in _random_lines(rng, 60, 1300, 900):
+        groups.setdefault((40, 0, 1), []).append((baseline, heights, None))
+    for baseline, heights in _random_lines(rng, 20, 1300, 900):
+        groups.setdefault((32, 2, 1), []).append((baseline, heights, None))
+    n_checked = 0
+    for (line_h, poly, scale), items in groups.items():
+        eng = EngineLineCropper(line_height=line_h, poly=poly, scale=scale)
+        crops, grids = eng.crop_lines(page, [(b, h) for b, h, _ in items], want_grids=True)
+        curves64 = eng._cropper.read_curves()                     # float64 [4, w] per line the device measured
+        k = 0
+        for b, h, _ in items:                                      # (lines whose host half raised never reach the device)
+            try:
+                eng.line_spec(b, h, line_h)
+            except Exception:
+                continue
+            want64 = eng.line_curves(b, h, line_h)[0]
+            if want64.shape[1]:
+                assert curves64[k].shape == want64.shape and np.array_equal(curves64[k], want64)       # every float64, bit for bit
+            k += 1
+        for (b, h, ref), crop, grid in zip(items, crops, grids):
+            try:
+                host = eng.get_crop_inputs(b, h, line_h)
+            except Exception:
+                host = None
+            if host is None or host.shape[1] == 0:
+                assert grid is None and crop.shape == (line_h, 32, 3) and not crop.any()
+                continue
+            if ref is not None:
+                assert np.array_equal(host, ref)
+            assert grid is not None and grid.shape == host.shape and np.array_equal(grid, host)
+            assert np.array_equal(crop, crop_oracle.remap_bilinear_u8(page, host[..., 0], host[..., 1]))
+            n_checked += 1
+    assert n_checked >= 80
+
+
+@pytest.mark.gpu
+def test_gpu_resident_cropper_long_lines_and_page_reuse():
+    """Lines longer than one arc tile (2048 unit steps), a page that stays resident across calls, views of the pinned buffer."""
+    rng = np.random.RandomState(17)
+    page = rng.randint(0, 256, size=(1200, 6000, 3)).astype(np.uint8)
+    lines = []
+    for i in range(6):
+        xs = np.array([30, 1500, 3100, 4400, 5900]) + rng.randint(-20, 20, size=5)
+        ys = 100 + 180 * i + rng.randint(-8, 9, size=5)
+        lines.append((np.stack([xs, ys], axis=1), [30, 10]))
+    eng = EngineLineCropper(line_height=40)
+    first = eng.crop_lines(page, lines)
+    again = eng.crop_lines(None, lines[::-1], copy=False)            # the resident page, no upload
+    for (b, h), crop, crop2 in zip(lines, first, again[::-1]):
+        host = eng.get_crop_inputs(b, h, 40)
+        assert host.shape[1] > 4096
+        assert np.array_equal(crop, crop_oracle.remap_bilinear_u8(page, host[..., 0], host[..., 1]))
+        assert np.array_equal(crop, crop2)
+    gray = eng.crop_lines(page[:, :, 0], lines[:2])
+    assert gray[0].ndim == 2 and np.array_equal(gray[0], first[0][:, :, 0])
