@@ -177,6 +177,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--head-temperature", type=float, default=8.0,
+                    help="c5: scale of the CTC head of the synthetic weights (8: ~8 classes per frame above p = 1e-4; 1: 219 of 232)")
+    ap.add_argument("--pages-per-batch", type=int, default=4, help="c5: pages whose lines share one process_lines call")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 5 if args.workload == "c3" else 20
@@ -200,6 +203,13 @@ def main():
     wl = WORKLOADS[args.workload]
     meta, spec, weights = fixture_model(wl["fixture"])
     chars = meta["characters"]
+    if args.workload == "c5" and args.head_temperature != 1.0:
+        # seeded random weights give nearly flat posteriors: 219 of 232 classes per frame stay above the reference's
+        # p >= 1e-4 sparsification threshold (line_ocr_engine.py:168-171) and the "sparse" logits of a page are 59 MB.
+        # A trained recogniser is peaked; scaling the head restores that regime (nnz per frame is reported).
+        weights = dict(weights)
+        weights["head.weight"] = weights["head.weight"] * np.float32(args.head_temperature)
+        weights["head.bias"] = weights["head.bias"] * np.float32(args.head_temperature)
     tmp = tempfile.TemporaryDirectory(prefix="pocr_bench_")
     netspec.save_blob(os.path.join(tmp.name, "weights.pocrw"), spec, weights)
     with open(os.path.join(tmp.name, "ocr.json"), "w", encoding="utf8") as f:
@@ -271,17 +281,54 @@ def main():
             lines_done += len(layout.lines)
             return [ln.transcription for ln in layout.lines]
 
+        from pero_ocr_amd.document_ocr.page_stream import PageStream
+
+        def layout_front(img):
+            k = page_index[id(img)]
+            maps, ds = parsenet.get_maps_with_optimal_resolution(img)
+            assert maps.shape == (ph // 4, pw // 4, 5) and ds == 4
+            return Layout([Line(i, [[x0, y0 + 30], [x0 + wd // 2, y0 + 30], [x0 + wd, y0 + 30]], [30, 10])
+                           for i, (x0, y0, wd) in enumerate(boxes[k])])
+
+        page_index = {id(pg): k for k, pg in enumerate(pages)}
+        ppb = args.pages_per_batch
+        stream = PageStream(layout_front, cropper, page_ocr, pages_per_batch=ppb)
+
+        def run_stream(n):
+            nonlocal lines_done
+            texts = None
+            for _img, layout in stream.process(pages[i % n_pages] for i in range(n)):
+                lines_done += len(layout.lines)
+                texts = [ln.transcription for ln in layout.lines]
+                nnz_frames[0] += sum(ln.logits.nnz for ln in layout.lines)
+                nnz_frames[1] += sum(ln.logits.shape[0] for ln in layout.lines)
+            return texts
+
+        nnz_frames = [0, 0]
+
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):      # the engine prints the reference's "Line too long" warnings
-            for i in range(args.warmup):
+            # (1) one page at a time, stage after stage: what a single PageParser.process_page call costs (latency)
+            for i in range(max(1, args.warmup)):
                 one_page(i % n_pages)
             for k in stage:
                 stage[k] = 0.0
+            fence()
+            t0 = time.perf_counter()
+            n_lat = min(args.steps, 8)
+            for i in range(n_lat):
+                one_page(i % n_pages)
+            fence()
+            lat = (time.perf_counter() - t0) / n_lat
+            extra["page_at_a_time"] = {"pages_per_s": round(1.0 / lat, 2), "ms_per_page": round(1e3 * lat, 3),
+                                        "stage_ms_per_page": {k: round(1e3 * v / n_lat, 3) for k, v in stage.items()}}
+            # (2) the page stream (the figure `value` reports): front of the next pages on a helper thread, the
+            # recogniser fed with the lines of `ppb` pages per call
+            run_stream(max(ppb, args.warmup))
             lines_done = 0
             fence()
             t0 = time.perf_counter()
-            for i in range(args.steps):
-                texts = one_page(i % n_pages)
+            texts = run_stream(args.steps)
             fence()
             elapsed = time.perf_counter() - t0
         assert all(isinstance(t, str) for t in texts)
@@ -290,11 +337,13 @@ def main():
         extra["unit_note"] = "value is PAGES/s for this workload"
         extra["lines_per_page"] = lines_done / args.steps
         extra["lines_per_s"] = round(lines_done * world / elapsed, 1)
-        extra["stage_ms_per_page"] = {k: round(1e3 * v / args.steps, 3) for k, v in stage.items()}
         extra["layout_net_gpu_ms"] = round(parsenet.net.last_ms(), 3)
-        workload_txt = (f"c5: {ph}x{pw} synthetic page per step per GPU: layout network (parsenet_unet64, downsample 4 -> {ph // 4}x{pw // 4}) -> "
-                        f"layout post-processing stub (ground-truth baselines of the {len(boxes[0])} pasted lines) -> GPU line cropper -> "
-                        "VGG+BiLSTM+CTC line OCR (default batch_size 8, sparse logits + confidences) -> strings; inputs: host page per step")
+        extra["sparse_logits_nnz_per_frame"] = round(nnz_frames[0] / max(1, nnz_frames[1]), 2)
+        extra["head_temperature"] = args.head_temperature
+        workload_txt = (f"c5: stream of {ph}x{pw} synthetic pages, one per step per GPU: layout network (parsenet_unet64, downsample 4 -> {ph // 4}x{pw // 4}) -> "
+                        f"layout post-processing stub (ground-truth baselines of the {len(boxes[0])} pasted lines) -> resident GPU line cropper -> "
+                        f"VGG+BiLSTM+CTC line OCR (default batch_size 8, sparse logits + confidences) -> strings; inputs: host page per step; "
+                        f"layout + crop of the next pages on a helper thread, the recogniser gets the lines of {ppb} pages per process_lines call")
         w_pad = None
     elif args.workload == "c3":
         # ------------------------------------------------------------------ c3: sharded page stream (strong scaling)

@@ -48,7 +48,16 @@ class PageOCR:
             self.ocr_engine = PytorchEngineLineOCR(json_file, self.device)
 
     def process_page(self, img, page_layout):
-        lines = list(page_layout.lines_iterator())
+        self.process_pages([page_layout])
+        return page_layout
+
+    def process_pages(self, page_layouts):
+        """The lines of SEVERAL pages through one `process_lines` call.  The recurrent layers advance one frame per
+        dependent kernel whatever the number of lines (a page of 47 long lines keeps the GPU ~20 % busy there), and lines
+        are recognised independently given their chunk's padded width - which is a function of the sorted widths, so
+        the chunks of a page stream differ from the per-page ones exactly as they do when the reference's
+        `process_lines` is handed more lines.  Results are written to the lines as process_page does."""
+        lines = [line for layout in page_layouts for line in layout.lines_iterator()]
         for line in lines:
             if line.crop is None:
                 raise Exception(f"Missing crop in line {line.id}.")
@@ -63,7 +72,7 @@ class PageOCR:
         for line, conf in zip(lines, getattr(self.ocr_engine, "line_confidences", None) or []):
             if conf is not None:
                 line.transcription_confidence = conf
-        return page_layout
+        return page_layouts
 
     @property
     def provides_ctc_logits(self):

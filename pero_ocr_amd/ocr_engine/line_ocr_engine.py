@@ -84,6 +84,14 @@ class Launch:
 LAUNCH_WORK_TARGET = 256 * 576          # padded pixel columns per launch (= one BASELINE config-2 chunk)
 
 
+def launch_target(engine=None) -> int:
+    """Work per launch: the engine's `launch_work_target` attribute, else POCR_LAUNCH_TARGET, else LAUNCH_WORK_TARGET."""
+    t = getattr(engine, "launch_work_target", None)
+    if t is None:
+        t = int(os.environ.get("POCR_LAUNCH_TARGET", LAUNCH_WORK_TARGET))
+    return max(1, int(t))
+
+
 def plan_launches(chunks: Sequence[Chunk], target: int = LAUNCH_WORK_TARGET) -> List[Launch]:
     """Greedy merge of consecutive chunks (plan order = descending width) up to `target` work."""
     out: List[Launch] = []
@@ -213,7 +221,7 @@ class BaseEngineLineOCR:
         pending = None
         max_sparse_frames = getattr(self, "device_sparsify_max_frames", 0)
         try:
-            for k, launch in enumerate(plan_launches(chunks)):
+            for k, launch in enumerate(plan_launches(chunks, launch_target(self))):
                 rows = None
                 frames = [(wp // 2) // 2 for wp in launch.w_pads]
                 # the GPU sparsification kernels hold one line's frames per workgroup pass: launches with longer lines

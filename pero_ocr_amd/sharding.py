@@ -223,7 +223,7 @@ def engine_recogniser(engine) -> Callable:
     def many(lines, chunks):
         """All of this rank's chunks: merged into ragged launches and software-pipelined over the
         engine's two slots (the same path PytorchEngineLineOCR.process_lines uses)."""
-        from .ocr_engine.line_ocr_engine import plan_launches
+        from .ocr_engine.line_ocr_engine import launch_target, plan_launches
         out = {}
 
         def finish(launch, handle):
@@ -237,7 +237,7 @@ def engine_recogniser(engine) -> Callable:
 
         pending = None
         try:
-            for j, launch in enumerate(plan_launches(chunks)):
+            for j, launch in enumerate(plan_launches(chunks, launch_target(None))):
                 handle = engine._submit_launch(lines, launch, False, j % 2)
                 if pending is not None:
                     finish(*pending)
