@@ -24,10 +24,12 @@ class PageStream:
         self.pages_per_batch = max(1, int(pages_per_batch))
         self.depth = max(1, int(depth))
 
-    def _front(self, pages: Iterable, out: "queue.Queue"):
+    def _front(self, pages: Iterable, out: "queue.Queue", stop: threading.Event):
         try:
             batch: List[Tuple[object, object]] = []
             for img in pages:
+                if stop.is_set():
+                    break
                 layout = self.layout_front(img)
                 self.cropper.process_page(img, layout)
                 batch.append((img, layout))
@@ -43,7 +45,8 @@ class PageStream:
     def process(self, pages: Iterable) -> Iterator[Tuple[object, object]]:
         """Yields (img, layout) in page order, every line carrying its transcription / logits / coords."""
         q: "queue.Queue" = queue.Queue(maxsize=self.depth)
-        worker = threading.Thread(target=self._front, args=(pages, q), daemon=True)
+        stop = threading.Event()
+        worker = threading.Thread(target=self._front, args=(pages, q, stop), daemon=True)
         worker.start()
         try:
             while True:
@@ -55,6 +58,7 @@ class PageStream:
                 self.page_ocr.process_pages([layout for _img, layout in item])
                 yield from item
         finally:
+            stop.set()
             while worker.is_alive():          # a consumer that stops early must not leave the producer blocked on put()
                 try:
                     q.get(timeout=0.05)
