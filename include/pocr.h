@@ -43,6 +43,8 @@ typedef struct pocr_config {
     int32_t sa_heads;      /* POCR_ARCH_SA: heads, conv_out/heads in {32, 64, 128} */
     int32_t sa_ff;         /* POCR_ARCH_SA: feed-forward width, multiple of 16 */
     int32_t dec_layers;    /* POCR_ARCH_S2S: decoder layers (transformer.py:13-47, JSON decoder_layers) */
+    int32_t embed_num;     /* 0: no embeddings layer; > 0: style embeddings, table [embed_num + 1][2 * conv_out] after the
+                              head in the weight blob (the engine JSON's embed_num, line_ocr_engine.py:32-35) */
 } pocr_config;
 
 /* Sequence model after the conv backbone: BiLSTM stack, or the self-attention encoder
@@ -52,6 +54,13 @@ typedef struct pocr_config {
  * (pero_ocr/ocr_engine/transformer_ocr_engine.py); num_classes then = symbols + boundary + ignore,
  * the sa_* fields describe encoder and decoder alike.  Only the pocr_s2s_* calls run such an engine. */
 enum { POCR_ARCH_BLSTM = 0, POCR_ARCH_SA = 1, POCR_ARCH_S2S = 2 };
+
+/* Style-embedding models (replaces `ids_embedding = LongTensor([embed_id] * N); model(batch_data, ids_embedding)`,
+ * pytorch_ocr_engine.py:64-66): every line of every later launch is recognised with row `embed_id` of the embeddings
+ * table, 0 <= embed_id <= embed_num; embed_num itself is the "mean" embedding (get_mean_embed_id, :49-50).
+ * An engine whose config has embed_num > 0 refuses to launch until an id is set (the reference's TorchScript call
+ * fails without the second argument); one without an embeddings layer refuses the call. */
+int pocr_set_embed_id(pocr_engine *e, int32_t embed_id);
 
 /* Number of float32 values pocr_create() expects (tensor order = netspec.tensor_table). */
 size_t pocr_num_weight_floats(const pocr_config *cfg);

@@ -77,6 +77,27 @@ class RefTopologyNet(nn.Module):
         return self.head(y).permute(0, 2, 1)
 
 
+class RefTopologyNetEmbed(nn.Module):
+    """The same with a style-embeddings layer: called as model(batch, ids) by the reference engine when the engine JSON
+    carries embed_id (pytorch_ocr_engine.py:64-66); `embeddings_layer` is the attribute get_mean_embed_id reads (:49-50)."""
+
+    def __init__(self, blocks_2d, aggregation_conv, lstm, head, embeddings_layer, e: int):
+        super().__init__()
+        self.blocks_2d = blocks_2d
+        self.aggregation_conv = aggregation_conv
+        self.lstm = lstm
+        self.head = head
+        self.embeddings_layer = embeddings_layer
+        self.e = e
+
+    def forward(self, x, ids):
+        f = self.aggregation_conv(self.blocks_2d(x)).squeeze(2)
+        emb = self.embeddings_layer(ids)
+        f = f * (1.0 + emb[:, :self.e]).unsqueeze(2) + emb[:, self.e:].unsqueeze(2)
+        y, _ = self.lstm(f.permute(0, 2, 1))
+        return self.head(y).permute(0, 2, 1)
+
+
 def build_reference_model(transformer, spec: netspec.NetSpec, weights):
     with contextlib.redirect_stdout(io.StringIO()):
         enc = transformer.ConvolutionalEncoder(in_height=spec.height, in_channels=3,
@@ -88,6 +109,10 @@ def build_reference_model(transformer, spec: netspec.NetSpec, weights):
     head = nn.Linear(2 * spec.lstm_hidden, spec.num_classes)
     head.weight.data = torch.from_numpy(weights["head.weight"].copy())
     head.bias.data = torch.from_numpy(weights["head.bias"].copy())
+    if spec.embed_num:
+        emb = nn.Embedding(spec.embed_num + 1, 2 * spec.conv_out)
+        emb.weight.data = torch.from_numpy(weights["embeddings_layer.weight"].copy())
+        return RefTopologyNetEmbed(enc.blocks_2d, enc.aggregation_conv, lstm, head, emb, spec.conv_out).eval()
     return RefTopologyNet(enc.blocks_2d, enc.aggregation_conv, lstm, head).eval()
 
 
@@ -170,6 +195,12 @@ CONFIGS = {
     "c3": dict(n_symbols=231, weight_seed=20260929, crop_seed=306, widths="make_widths(33, 2048)", batch_size=8,
                store_dense=False, calibrate=True, calib_width=512, weight_kwargs=dict(blank_bias=4.0), select_margin=2e-3,
                modes=("dense",), sample_rows=2),
+    # style-embedding models (pytorch_ocr_engine.py:46-50, 64-66): the engine JSON carries embed_num / embed_id and the
+    # reference calls model(batch, ids); one fixture with a numeric id, one with "mean" (= the last row of the table)
+    "embed": dict(n_symbols=99, weight_seed=20260932, crop_seed=602, widths=[300, 120, 517, 64, 300, 800, 33, 256, 411, 96],
+                  batch_size=8, store_dense=True, embed_num=3, embed_id=1),
+    "embed_mean": dict(n_symbols=99, weight_seed=20260932, crop_seed=602, widths=[300, 120, 517, 64, 300, 800, 33, 256, 411, 96],
+                       batch_size=8, store_dense=True, embed_num=3, embed_id="mean"),
     # self-attention encoder variant (BASELINE.json configs[3] topology) on ragged widths
     "sa_ragged": dict(n_symbols=99, weight_seed=20260930, crop_seed=401, arch="vgg_sa_ctc",
                       widths=[300, 17, 641, 640, 300, 1, 1290, 96, 33, 512, 300, 1000, 64, 257], batch_size=8,
@@ -248,7 +279,7 @@ def run_config(name: str, out_dir: str):
         cfg["widths"] = eval("synth." + cfg["widths"])
     engine_mod, transformer = import_reference()
     chars = synth.make_charset(cfg["n_symbols"])
-    spec = netspec.NetSpec(num_classes=len(chars) + 1, arch=cfg.get("arch", netspec.ARCH))
+    spec = netspec.NetSpec(num_classes=len(chars) + 1, arch=cfg.get("arch", netspec.ARCH), embed_num=cfg.get("embed_num", 0))
     torch.set_num_threads(os.cpu_count() or 1)
     weights, overrides = calibrated_weights(spec, cfg, cfg.get("calib_width", max(cfg["widths"])))
     crop_indices = None
@@ -265,8 +296,11 @@ def run_config(name: str, out_dir: str):
         scripted = torch.jit.script(model)
         scripted.save(os.path.join(td, "model.pt.cpu"))          # CPU path appends ".cpu" (pytorch_ocr_engine.py:53-54)
         with open(os.path.join(td, "ocr.json"), "w", encoding="utf8") as f:
-            json.dump({"line_px_height": spec.height, "line_vertical_scale": 1.0, "checkpoint": "model.pt",
-                       "characters": chars, "net_name": "VGG_BLSTM_CTC"}, f)
+            engine_json = {"line_px_height": spec.height, "line_vertical_scale": 1.0, "checkpoint": "model.pt",
+                           "characters": chars, "net_name": "VGG_BLSTM_CTC"}
+            if "embed_id" in cfg:
+                engine_json.update(embed_num=cfg["embed_num"], embed_id=cfg["embed_id"])
+            json.dump(engine_json, f)
         engine = engine_mod.PytorchEngineLineOCR(os.path.join(td, "ocr.json"), torch.device("cpu"),
                                                  batch_size=cfg["batch_size"])
         sink = io.StringIO()
@@ -285,11 +319,12 @@ def run_config(name: str, out_dir: str):
                 assert t_nolog == t_dense
                 assert all(x is None for x in l_nolog) and all(x is None for x in c_nolog)
         ref_characters = list(engine.characters)
+        ref_embed_id = engine.embed_id                       # "mean" resolved by the reference (pytorch_ocr_engine.py:46-50)
 
     # ---- restatement check: this repo's oracle must reproduce the reference run
     onet = model_oracle.OracleNet(spec, weights)
     o_t, o_l, o_c, extras = engine_oracle.process_lines(
-        lambda b: model_oracle.forward_logits(onet, b), crops, ref_characters, spec.height,
+        lambda b: model_oracle.forward_logits(onet, b, ref_embed_id), crops, ref_characters, spec.height,
         480 * cfg["batch_size"], sparse_logits=False)
     assert o_t == t_dense, "oracle transcriptions differ from the reference"
     assert o_c == c_dense
@@ -331,6 +366,8 @@ def run_config(name: str, out_dir: str):
         "torch": torch.__version__, "numpy": np.__version__,
         "stdout_warnings": [ln for ln in sink.getvalue().splitlines() if "WARNING" in ln][:4],
     }
+    if "embed_id" in cfg:
+        meta["embed_num"], meta["embed_id"], meta["resolved_embed_id"] = cfg["embed_num"], cfg["embed_id"], int(ref_embed_id)
     if "sparse" in modes:
         meta["nnz_sparse"] = [int(x.nnz) for x in l_sparse]
     if "tight" in modes:

@@ -56,6 +56,10 @@ class OracleNet(nn.Module):
         self.agg.weight.data = torch.from_numpy(weights["agg.weight"].copy())
         self.agg.bias.data = torch.from_numpy(weights["agg.bias"].copy())
         self.agg_act = nn.LeakyReLU(LEAKY_SLOPE)
+        self.embeddings_layer = None
+        if spec.embed_num:                   # pytorch_ocr_engine.py:49-50 reads model.embeddings_layer.weight.shape[0]
+            self.embeddings_layer = nn.Embedding(spec.embed_num + 1, 2 * spec.conv_out)
+            self.embeddings_layer.weight.data = torch.from_numpy(weights["embeddings_layer.weight"].copy())
         self.sa = None
         if spec.arch == ARCH_S2S:            # encoder only; the decoder lives in oracle/s2s_oracle.py
             self.sa = {k: torch.from_numpy(v.copy()) for k, v in weights.items() if k.startswith("sa")}
@@ -111,12 +115,19 @@ class OracleNet(nn.Module):
             outs.append(x)
         return outs
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, ids=None) -> torch.Tensor:
         f = self.features(x)
+        if self.embeddings_layer is not None:                # `model(batch_data, ids_embedding)`, pytorch_ocr_engine.py:64-66
+            f = apply_style_embedding(f, self.embeddings_layer(ids), self.spec.conv_out)
         if self.sa is not None:
             return self.head(self.encoder_stages(f)[-1]).permute(0, 2, 1)
         y, _ = self.lstm(f.permute(0, 2, 1))
         return self.head(y).permute(0, 2, 1)
+
+
+def apply_style_embedding(f: torch.Tensor, emb: torch.Tensor, e: int) -> torch.Tensor:
+    """f [N, E, T], emb [N, 2E] -> f * (1 + scale) + shift, per line and channel (netspec.NetSpec.embed_num)."""
+    return f * (1.0 + emb[:, :e]).unsqueeze(2) + emb[:, e:].unsqueeze(2)
 
 
 def load_lstm_weights(lstm: nn.LSTM, spec: NetSpec, weights: Dict[str, np.ndarray]) -> None:
@@ -128,8 +139,11 @@ def load_lstm_weights(lstm: nn.LSTM, spec: NetSpec, weights: Dict[str, np.ndarra
                     weights[f"lstm{l}.{d}.{ours}"].copy())
 
 
-def forward_logits(net: OracleNet, batch_u8_nhwc: np.ndarray) -> np.ndarray:
-    """u8 [n,H,W,3] -> f32 [n,C,T], normalised exactly as pytorch_ocr_engine.py:61-62."""
+def forward_logits(net: OracleNet, batch_u8_nhwc: np.ndarray, embed_id=None) -> np.ndarray:
+    """u8 [n,H,W,3] -> f32 [n,C,T], normalised exactly as pytorch_ocr_engine.py:61-62; embed_id as :64-66."""
     with torch.no_grad():
         x = torch.from_numpy(np.ascontiguousarray(batch_u8_nhwc)).float() / 255.0
+        if embed_id is not None:
+            ids = torch.LongTensor([int(embed_id)] * x.shape[0])
+            return net(x.permute(0, 3, 1, 2), ids).numpy()
         return net(x.permute(0, 3, 1, 2)).numpy()

@@ -26,7 +26,7 @@ class PocrConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("height", C.c_int32), ("num_classes", C.c_int32),
                 ("conv_out", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_layers", C.c_int32),
                 ("arch", C.c_int32), ("sa_layers", C.c_int32), ("sa_heads", C.c_int32), ("sa_ff", C.c_int32),
-                ("dec_layers", C.c_int32)]
+                ("dec_layers", C.c_int32), ("embed_num", C.c_int32)]
 
 
 class CropSpec(C.Structure):
@@ -46,7 +46,8 @@ ARCH_IDS = {"vgg_blstm_ctc": 0, "vgg_sa_ctc": 1, "vgg_sa_s2s": 2}
 
 def make_config(spec: NetSpec) -> "PocrConfig":
     return PocrConfig(ABI_VERSION, spec.height, spec.num_classes, spec.conv_out, spec.lstm_hidden,
-                      spec.lstm_layers, ARCH_IDS[spec.arch], spec.sa_layers, spec.sa_heads, spec.sa_ff, spec.dec_layers)
+                      spec.lstm_layers, ARCH_IDS[spec.arch], spec.sa_layers, spec.sa_heads, spec.sa_ff, spec.dec_layers,
+                      spec.embed_num)
 
 
 # every symbol include/pocr.h declares: name -> (restype, argtypes)
@@ -57,6 +58,7 @@ SYMBOLS = {
     "pocr_destroy": (None, [C.c_void_p]),
     "pocr_last_error": (C.c_char_p, []),
     "pocr_abi_version": (C.c_int, []),
+    "pocr_set_embed_id": (C.c_int, [C.c_void_p, C.c_int32]),
     "pocr_device_count": (C.c_int, []),
     "pocr_run_batch": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, _f32p, _i32p, _i32p, _i32p]),
     "pocr_stage_lines": (C.c_int, [C.c_void_p, _u8p, _i64p, _i32p, C.c_int32, C.c_int32, C.c_int32]),
@@ -404,6 +406,11 @@ class NativeEngine:
         buf = np.zeros(len(STAGE_NAMES), dtype=np.float32)
         k = self._lib.pocr_slot_stage_ms(self._h, int(slot), _ptr(buf, _f32p), buf.size)
         return {STAGE_NAMES[i]: float(buf[i]) for i in range(k)}
+
+    def set_embed_id(self, embed_id: int):
+        """Row of the style-embeddings table every later launch uses (include/pocr.h pocr_set_embed_id)."""
+        if self._lib.pocr_set_embed_id(self._h, int(embed_id)):
+            raise RuntimeError("pocr_set_embed_id: " + self._err())
 
     def set_profiling(self, on: bool):
         self._lib.pocr_set_profiling(self._h, 1 if on else 0)

@@ -249,6 +249,9 @@ struct pocr_engine {
     hipStream_t stream = nullptr;    // set-up stream (weight uploads)
     // weights (device)
     DevBuf conv_w[9], conv_b[9], bn_scale, bn_shift, agg_w, agg_b, head_w, head_b, lut;
+    std::vector<float> embed_table;  // style embeddings [embed_num + 1][2E] (host copy); embed_ss = (1 + scale | shift) of the chosen row
+    DevBuf embed_ss;
+    int embed_id = -1;
     std::vector<DevBuf> proj_w, proj_b, whh;       // per LSTM layer
     std::vector<DevBuf> whh_p;                     // per LSTM layer: W_hh as wave-private register fragments (lstm_persist.hpp)
     bool lstm_persist = false;                     // POCR_LSTM_PERSIST=1: one persistent launch per layer (lstm_persist.hpp) instead
@@ -297,6 +300,7 @@ int check_cfg(const pocr_config *c) {
     const int ah = c->height / 8;
     if (ah != 4 && ah != 5 && ah != 6 && ah != 8) return fail("unsupported height %d (aggregation height %d; built for 32/40/48/64)", c->height, ah);
     if (c->num_classes < 2) return fail("num_classes must be >= 2");
+    if (c->embed_num < 0 || (c->embed_num > 0 && c->arch == POCR_ARCH_S2S)) return fail("embed_num must be >= 0 (0 for the seq2seq engine)");
     if (c->conv_out <= 0 || c->conv_out % 16) return fail("conv_out must be a positive multiple of 16");
     if (c->arch == POCR_ARCH_SA || c->arch == POCR_ARCH_S2S) {
         if (c->arch == POCR_ARCH_S2S && c->dec_layers < 1) return fail("dec_layers must be >= 1");
@@ -320,6 +324,20 @@ struct WeightCursor {
     const float *p;
     const float *take(size_t n) { const float *r = p; p += n; return r; }
 };
+
+// feat [rows][E] <- feat * ss[c] + ss[E + c]: two roundings per element like torch's `f * (1 + s) + b` (no FMA contraction)
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void style_embed_kernel(float *feat, const float *ss, size_t total, int E) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * 1024) {
+        f32x4 v = *reinterpret_cast<f32x4 *>(feat + i);
+        const int c = (int)(i % (size_t)E);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + c), sh = *reinterpret_cast<const f32x4 *>(ss + E + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float m = v[j] * sc[j]; v[j] = m + sh[j]; }
+        *reinterpret_cast<f32x4 *>(feat + i) = v;
+    }
+}
+#pragma clang fp contract(fast)
 
 int run_network(pocr_engine *e, Slot &s) {
     const pocr_config &c = e->cfg;
@@ -412,6 +430,13 @@ int run_network(pocr_engine *e, Slot &s) {
         mark(POCR_STAGE_AGG);
         int rc = AH == 4 ? agg4_k(a, st) : AH == 5 ? agg5_k(a, st) : AH == 6 ? agg6_k(a, st) : agg8_k(a, st);
         if (rc) return rc;
+        if (c.embed_num > 0) {      // f * (1 + scale) + shift, the chosen style row for every line (pytorch_ocr_engine.py:64-66)
+            if (e->embed_id < 0) return fail("this model has an embeddings layer: pocr_set_embed_id first");
+            const size_t total = (size_t)rows * E;
+            hipLaunchKernelGGL(style_embed_kernel, dim3((unsigned)std::min<size_t>(4096, (total / 4 + 255) / 256)), dim3(256), 0, st,
+                               s.feat.as<float>(), e->embed_ss.as<float>(), total, E);
+            HIP_TRY(hipGetLastError());
+        }
     }
     HIP_TRY(hipEventRecord(s.conv_done, st));
     s.conv_done_valid = true;
@@ -795,6 +820,21 @@ extern "C" {
 const char *pocr_last_error(void) { return g_err.c_str(); }
 int pocr_abi_version(void) { return POCR_ABI_VERSION; }
 
+int pocr_set_embed_id(pocr_engine *e, int32_t embed_id) {
+    if (!e) return fail("engine is NULL");
+    const int E = e->cfg.conv_out, num = e->cfg.embed_num;
+    if (num <= 0) return fail("this model has no embeddings layer (embed_num 0) but an embed_id was given");
+    if (embed_id < 0 || embed_id > num) return fail("embed_id %d outside the embeddings table (0..%d)", embed_id, num);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());                       // launches in flight read the previous row
+    std::vector<float> ss(2 * (size_t)E);
+    const float *row = e->embed_table.data() + (size_t)embed_id * 2 * E;
+    for (int k = 0; k < E; ++k) { ss[k] = 1.0f + row[k]; ss[E + k] = row[E + k]; }      // torch: (1.0 + emb[:, :E]) in float32
+    if (upload(e->embed_ss, ss, e->stream)) return 1;
+    e->embed_id = embed_id;
+    return 0;
+}
+
 int pocr_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -816,6 +856,7 @@ size_t pocr_num_weight_floats(const pocr_config *c) {
             t += (size_t)c->num_classes * E;                           // embedding
         }
         t += (size_t)c->num_classes * E + c->num_classes;             // CTC head / decoder output projection
+        if (c->embed_num > 0) t += (size_t)(c->embed_num + 1) * 2 * E;
         return t;
     }
     const size_t Hh = c->lstm_hidden;
@@ -824,6 +865,7 @@ size_t pocr_num_weight_floats(const pocr_config *c) {
         t += 2 * (4 * Hh * din + 4 * Hh * Hh + 8 * Hh);
     }
     t += (size_t)c->num_classes * 2 * Hh + c->num_classes;
+    if (c->embed_num > 0) t += (size_t)(c->embed_num + 1) * 2 * c->conv_out;
     return t;
 }
 
@@ -1073,6 +1115,11 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         std::vector<float> bias(e->head_cout16 * 16, 0.f);
         for (int k = 0; k < C; ++k) bias[k] = b[k];
         if (upload(e->head_w, frag, st) || upload(e->head_b, bias, st)) return bail(1);
+    }
+    if (cfg->embed_num > 0) {   // style embeddings: kept on the host, one row goes to the device per pocr_set_embed_id
+        const size_t nf = (size_t)(cfg->embed_num + 1) * 2 * cfg->conv_out;
+        const float *w = cur.take(nf);
+        e->embed_table.assign(w, w + nf);
     }
     {   // u8 -> f32 table, bit-exact with torch's .float() / 255.0 (true division, pytorch_ocr_engine.py:61)
         std::vector<float> lut(256);

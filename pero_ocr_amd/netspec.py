@@ -80,6 +80,12 @@ class NetSpec:
     # "vgg_sa_s2s" only: decoder layers (same width / heads / feed-forward size as the encoder,
     # transformer.build_net :13-47); num_classes then counts the symbols + sentence boundary + ignore
     dec_layers: int = 2
+    # style embeddings (pytorch_ocr_engine.py:46-50, 64-66: `model(batch, ids)` with `model.embeddings_layer`): the
+    # reference's models with an embeddings layer are opaque TorchScript, so - like the BiLSTM and the head - this build
+    # defines its own: Embedding(embed_num + 1, 2E) -> per-channel (scale, shift) of the aggregated features [N, E, T]
+    # before the sequence layers, f * (1 + s) + b.  The last row is the "mean" embedding (get_mean_embed_id, :49-50).
+    # 0 = the model has no embeddings layer.
+    embed_num: int = 0
 
     def __post_init__(self):
         if self.arch not in (ARCH, ARCH_SA, ARCH_S2S):
@@ -97,6 +103,8 @@ class NetSpec:
             raise ValueError("conv_out and lstm_hidden must be multiples of 16")
         if self.in_channels != 3:
             raise ValueError("in_channels must be 3 (BGR crops)")
+        if self.embed_num < 0 or (self.embed_num and self.arch == ARCH_S2S):
+            raise ValueError("embed_num must be >= 0 (and 0 for the seq2seq engine)")
 
     @property
     def agg_height(self) -> int:
@@ -109,7 +117,7 @@ class NetSpec:
     def from_json(d: dict) -> "NetSpec":
         return NetSpec(**{k: d[k] for k in
                           ("num_classes", "height", "in_channels", "conv_out",
-                           "lstm_hidden", "lstm_layers", "arch", "sa_layers", "sa_heads", "sa_ff", "dec_layers")
+                           "lstm_hidden", "lstm_layers", "arch", "sa_layers", "sa_heads", "sa_ff", "dec_layers", "embed_num")
                           if k in d})
 
 
@@ -168,6 +176,8 @@ def tensor_table(spec: NetSpec) -> List[Tuple[str, Tuple[int, ...], str, int]]:
             return t
         t.append(("head.weight", (spec.num_classes, e), "head_w", e))
         t.append(("head.bias", (spec.num_classes,), "head_b", e))
+        if spec.embed_num:
+            t.append(("embeddings_layer.weight", (spec.embed_num + 1, 2 * e), "style_embed", e))
         return t
     hh = spec.lstm_hidden
     for l in range(spec.lstm_layers):
@@ -179,6 +189,8 @@ def tensor_table(spec: NetSpec) -> List[Tuple[str, Tuple[int, ...], str, int]]:
             t.append((f"lstm{l}.{d}.b_hh", (4 * hh,), "lstm_b", hh))
     t.append(("head.weight", (spec.num_classes, 2 * hh), "head_w", 2 * hh))
     t.append(("head.bias", (spec.num_classes,), "head_b", 2 * hh))
+    if spec.embed_num:
+        t.append(("embeddings_layer.weight", (spec.embed_num + 1, 2 * spec.conv_out), "style_embed", spec.conv_out))
     return t
 
 
@@ -270,6 +282,8 @@ def generate_weights(spec: NetSpec, seed: int, head_gain: float = 20.0,
             v[-1] = blank_bias          # CTC nets emit blank on most frames
         elif kind == "embed":
             v = (2.0 * u - 1.0) * (embed_gain * 3.0 ** 0.5)      # variance embed_gain^2 (nn.Embedding: N(0, 1))
+        elif kind == "style_embed":
+            v = (2.0 * u - 1.0) * 0.6       # scale 1 + s in (0.4, 1.6), shift in (-0.6, 0.6): every row changes the text
         elif kind == "s2s_b":
             v = (2.0 * u - 1.0) * 0.5
             v[-2] = boundary_bias       # sentence boundary (C-2): random nets must end their lines at some point

@@ -72,9 +72,20 @@ class PytorchEngineLineOCR(BaseEngineLineOCR):
         super().__init__(json_def, device, batch_size=batch_size)
         self.net_subsampling = 4
         self.characters = list(self.characters) + [BLANK_PLACEHOLDER]
-        if self.embed_id is not None:
-            raise NotImplementedError("style-embedding models (embed_id) are not supported by this engine")
         self._load_exported_model()
+        # pytorch_ocr_engine.py:46-50: "mean" = the last row of the model's embeddings table
+        if self.embed_id == "mean":
+            self.embed_id = self.get_mean_embed_id()
+        if self.embed_id is not None:
+            self.model.set_embed_id(self.embed_id)          # every run_ocr call passes [embed_id] * N (:64-66)
+        elif self.net_spec.embed_num:
+            raise ValueError("the model has an embeddings layer but the engine JSON carries no embed_id "
+                             "(the reference's model call fails without the ids argument)")
+
+    def get_mean_embed_id(self):
+        if not self.net_spec.embed_num:
+            raise ValueError('embed_id "mean": the model has no embeddings layer')
+        return self.net_spec.embed_num                      # embeddings_layer.weight.shape[0] - 1
 
     # reference name kept (pytorch_ocr_engine.py:52)
     def _load_exported_model(self):
@@ -89,7 +100,8 @@ class PytorchEngineLineOCR(BaseEngineLineOCR):
                                    arch=net_cfg.get("arch", netspec.ARCH),
                                    sa_layers=int(net_cfg.get("sa_layers", net_cfg.get("encoder_layers", 2))),
                                    sa_heads=int(net_cfg.get("sa_heads", net_cfg.get("heads", 8))),
-                                   sa_ff=int(net_cfg.get("sa_ff", net_cfg.get("dim_ff", 2048))))
+                                   sa_ff=int(net_cfg.get("sa_ff", net_cfg.get("dim_ff", 2048))),
+                                   embed_num=int(self.embed_num or 0))
             weights = netspec.generate_weights(spec, int(net_cfg["weight_seed"]))
         else:
             raise FileNotFoundError(f"weight blob {self.checkpoint} not found and no net.weight_seed in the engine JSON")

@@ -113,12 +113,15 @@ class Golden:
             from pero_ocr_amd import netspec        # not reproducible from the seed alone: ship a weight blob
             checkpoint = "weights.pocrw"
             netspec.save_blob(os.path.join(str(tmpdir), checkpoint), self.spec(), self.weights())
+        cfg = {"line_px_height": self.meta["height"], "line_vertical_scale": 1.0,
+               "checkpoint": checkpoint, "characters": self.meta["characters"][:-1],
+               "net_name": "VGG_BLSTM_CTC",
+               "net": {"arch": self.meta["spec"].get("arch", "vgg_blstm_ctc"),
+                       "weight_seed": self.meta["weight_seed"]}}
+        if "embed_id" in self.meta:                       # the reference's own keys (line_ocr_engine.py:32-42)
+            cfg.update(embed_num=self.meta["embed_num"], embed_id=self.meta["embed_id"])
         with open(path, "w", encoding="utf8") as f:
-            json.dump({"line_px_height": self.meta["height"], "line_vertical_scale": 1.0,
-                       "checkpoint": checkpoint, "characters": self.meta["characters"][:-1],
-                       "net_name": "VGG_BLSTM_CTC",
-                       "net": {"arch": self.meta["spec"].get("arch", "vgg_blstm_ctc"),
-                               "weight_seed": self.meta["weight_seed"]}}, f)
+            json.dump(cfg, f)
         return path
 
 

@@ -97,7 +97,7 @@ def test_conv1_normalise_is_bit_exact(small):
     assert np.max(np.abs(got - ref_acts[0])) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["c1", "ragged"])
+@pytest.mark.parametrize("name", ["c1", "ragged", "embed", "embed_mean"])
 def test_engine_matches_reference_golden(golden, tmp_path, name):
     """PytorchEngineLineOCR.process_lines (ragged GPU path) vs the imported-reference fixtures."""
     from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
@@ -133,6 +133,39 @@ def test_engine_matches_reference_golden(golden, tmp_path, name):
     assert [list(np.asarray(x).shape) for x in l3] == g.tight_shapes
     t4, l4, c4 = eng.process_lines(crops, no_logits=True)
     assert t4 == texts and all(x is None for x in l4) and all(x is None for x in c4)
+
+
+@pytest.mark.gpu
+def test_embed_id_selects_the_style_row(golden, tmp_path):
+    """embed_id models (pytorch_ocr_engine.py:46-50, 64-66): "mean" resolves to the last row of the table, another id gives
+    other logits, ids outside the table and models without / with an embeddings layer are refused like the reference's
+    TorchScript call would fail."""
+    import json
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    g = golden("embed_mean")
+    path = g.write_engine_json(tmp_path)
+    eng = PytorchEngineLineOCR(path, Dev(), batch_size=g.batch_size)
+    assert eng.embed_id == g.meta["resolved_embed_id"] == g.meta["embed_num"]
+    crops = g.crops()
+    t_mean, l_mean, _ = eng.process_lines(crops, sparse_logits=False)
+    assert t_mean == g.transcriptions
+    eng.model.set_embed_id(1)
+    t_one, l_one, _ = eng.process_lines(crops, sparse_logits=False)
+    assert t_one == golden("embed").transcriptions            # same weights and crops, the fixture recorded with embed_id 1
+    assert max(float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) for a, b in zip(l_mean, l_one)) > 0.5
+    with pytest.raises(RuntimeError, match="outside the embeddings table"):
+        eng.model.set_embed_id(g.meta["embed_num"] + 1)
+    cfg = json.load(open(path, encoding="utf8"))
+    del cfg["embed_id"]
+    json.dump(cfg, open(path, "w", encoding="utf8"))
+    with pytest.raises(ValueError, match="embeddings layer"):
+        PytorchEngineLineOCR(path, Dev(), batch_size=8)
+    plain = golden("c1")
+    cfg = json.load(open(plain.write_engine_json(tmp_path), encoding="utf8"))
+    cfg["embed_id"] = 0
+    json.dump(cfg, open(os.path.join(str(tmp_path), "ocr.json"), "w", encoding="utf8"))
+    with pytest.raises(RuntimeError, match="no embeddings layer"):
+        PytorchEngineLineOCR(os.path.join(str(tmp_path), "ocr.json"), Dev(), batch_size=8)
 
 
 def _check_full_tensor_stats(g, logits):

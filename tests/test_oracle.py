@@ -72,14 +72,14 @@ def test_normalise_is_true_division():
     assert not np.array_equal(x, (b.astype(np.float32) * np.float32(1.0 / 255.0)).transpose(0, 3, 1, 2))
 
 
-@pytest.mark.parametrize("name", ["c1", "ragged"])
+@pytest.mark.parametrize("name", ["c1", "ragged", "embed", "embed_mean"])
 def test_oracle_reproduces_reference_golden(golden, name):
     """Full restated path (oracle net + numpy engine) vs the imported-reference outputs."""
     g = golden(name)
     spec, weights, crops = g.spec(), g.weights(), g.crops()
     net = model_oracle.OracleNet(spec, weights)
     texts, logits, coords, extras = engine_oracle.process_lines(
-        lambda b: model_oracle.forward_logits(net, b), crops, g.characters, spec.height,
+        lambda b: model_oracle.forward_logits(net, b, g.meta.get("resolved_embed_id")), crops, g.characters, spec.height,
         480 * g.batch_size, sparse_logits=False)
     assert texts == g.transcriptions
     assert coords == g.logit_coords
