@@ -20,6 +20,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "conv_igemm.hpp"
+#ifndef POCR_BF16X3_DBG
+#define POCR_BF16X3_DBG 0            // tools/conv_bench_bf16.hip: 1 no A reads, 2 no weight loads, 4 no A staging, 8 no barrier
+#endif
 
 namespace pocr {
 
@@ -71,7 +74,12 @@ __device__ __forceinline__ void split3_quad(const f32x4 p, u32x2 &hi, u32x2 &mid
 // WM waves split the pixel tile (column strips), 4 / WM waves split the output channels; the B tile (weights of one
 // (chunk, tap) step for NT channels) is shared through LDS by the WM waves that need it, the A halo tile - already split
 // into its three bf16 planes by the stager, once per 32-channel chunk - by all of them.
-template <int TH, int MW, int NS, int WM, int POOLH, int POOLW, int ACT, bool BN, int MINW = 1>
+// BDIR: the weights do not pass through LDS at all - every wave loads the fragments of ITS channel tiles straight from
+// L2 into registers, one (chunk, tap) step ahead (fragment order makes that one coalesced 16 B/lane load per tile and
+// plane).  LDS then carries only the A planes (double-buffered: one barrier per 32-channel chunk instead of ten), which
+// matters because the loop is LDS-bound as much as MFMA-bound: per 16-cycle MFMA a SIMD's share of the LDS pipe is 512 B,
+// and operands cost 512 B x (1/NS + 1/MS) to read plus ~100 B to write the shared weight tile.
+template <int TH, int MW, int NS, int WM, int POOLH, int POOLW, int ACT, bool BN, int MINW = 1, bool BDIR = false>
 __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     constexpr int NWAVE = 4, WN = NWAVE / WM, KC = 32;
     static_assert(MW % WM == 0, "column strips must divide among the M waves");
@@ -79,12 +87,12 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     constexpr int HH = TH + 2, HW = TW + 2, NP = HH * HW, NPPAD = (NP + 15) / 16 * 16;
     constexpr int CQ = KC / 4;
     constexpr int PS = 4 * NPPAD;                       // 16-byte units per bf16 plane of the A tile ([octet][pixel])
-    constexpr int A_U = 3 * PS;                         // A tile, single-buffered (refilled once per chunk)
-    constexpr int B_F4 = (NT / 16) * 3 * 64;            // 16-byte units per B buffer (one (chunk, tap) step)
+    constexpr int A_U = 3 * PS;                         // A tile (single-buffered, refilled once per chunk; BDIR: two of them)
+    constexpr int B_F4 = BDIR ? 0 : (NT / 16) * 3 * 64; // 16-byte units per B buffer (one (chunk, tap) step)
     constexpr int A_LD = (CQ * NP + NTHR - 1) / NTHR;
-    constexpr int B_LD = (B_F4 + NTHR - 1) / NTHR;
+    constexpr int B_LD = BDIR ? 1 : (B_F4 + NTHR - 1) / NTHR;
     static_assert(POOLH == 1 || TH % 2 == 0, "H-pool needs an even tile height");
-    __shared__ u32x4 lds[A_U + 2 * B_F4];               // one scalar type (unsigned) for every access: no type punning
+    __shared__ u32x4 lds[BDIR ? 2 * A_U : A_U + 2 * B_F4];      // one scalar type (unsigned) for every access: no type punning
     u32x4 *ldsA = lds;
     u32x4 *ldsB = lds + A_U;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
@@ -155,8 +163,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         for (int r = 0; r < A_LD; ++r)
             ra[r] = a_ok[r] ? *reinterpret_cast<const f32x4 *>(ximg + chunk * KC + a_off[r]) : (f32x4){0.f, 0.f, 0.f, 0.f};
     };
-    auto stA = [&]() {                                  // split into the three bf16 planes on the way into LDS
-        u32x2 *base = reinterpret_cast<u32x2 *>(ldsA);
+    auto stA = [&](int abuf = 0) {                      // split into the three bf16 planes on the way into LDS
+        u32x2 *base = reinterpret_cast<u32x2 *>(ldsA + abuf * A_U);
 #pragma unroll
         for (int r = 0; r < A_LD; ++r)
             if (a_lds[r] >= 0) {
@@ -181,6 +189,77 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             if (B_F4 % NTHR == 0 || f < B_F4) ldsB[buf * B_F4 + f] = __builtin_bit_cast(u32x4, rb[r]);
         }
     };
+    if constexpr (BDIR) {
+    const u32x4 *wq = reinterpret_cast<const u32x4 *>(wt4) + (wn * NS) * 192 + lane;
+    // three register sets of weight fragments, rotated with the tap (9 taps = 3 x 3, so the rotation is static): the set
+    // of step s + 2 is requested while step s computes - two steps (~2000 cycles) cover an L2 miss, one does not
+    u32x4 bw[3][NS][3];
+    auto ldW = [&](u32x4 (&dst)[NS][3], const u32x4 *tile) {
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) dst[n][p] = tile[n * 192 + p * 64];
+    };
+    ldA(0);
+    ldW(bw[0], wq);
+    ldW(bw[1], wq + tap_stride);
+    stA(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool next_chunk = chunk + 1 < nchunks;
+        const int abuf = chunk & 1;
+        // no conditionals around the prefetches (the last chunk re-reads itself): the compiler then counts the loads in
+        // flight exactly (s_waitcnt vmcnt(n)) instead of draining the queue wherever control flow merges
+        const int chunk_n = next_chunk ? chunk + 1 : chunk;
+#if !(POCR_BF16X3_DBG & 4)
+        ldA(chunk_n);
+#endif
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#if !(POCR_BF16X3_DBG & 2)
+            {
+                const int t2 = tap + 2 >= 9 ? tap + 2 - 9 : tap + 2;
+                ldW(bw[(tap + 2) % 3], wq + (size_t)t2 * tap_stride + (size_t)(tap + 2 >= 9 ? chunk_n : chunk) * chunk_stride);
+            }
+#endif
+            const int dy = tap / 3, dx = tap % 3;
+#if POCR_BF16X3_DBG & 1
+            const u32x4 *Ab = ldsA + li + kq * NPPAD;
+#else
+            const u32x4 *Ab = ldsA + abuf * A_U + dy * HW + dx + li + kq * NPPAD + wm * MWW * 16;
+#endif
+            u32x4 (&bc)[NS][3] = bw[tap % 3];
+#pragma unroll
+            for (int m = 0; m < MS; ++m) {
+                const int o = (m / MWW) * HW + (m % MWW) * 16;
+#if POCR_BF16X3_DBG & 1
+                const u32x4 ah = bc[0][0] ^ (unsigned)m, am = bc[0][1] ^ (unsigned)m, al = bc[0][2] ^ (unsigned)m;     // no LDS reads
+                (void)o; (void)Ab;
+#else
+                const u32x4 ah = Ab[o], am = Ab[o + PS], al = Ab[o + 2 * PS];
+#endif
+#pragma unroll
+                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(al, bc[n][0], acc2[m][n]);
+#pragma unroll
+                for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_BF16(ah, bc[n][0], acc[m][n]);
+#pragma unroll
+                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bc[n][1], acc2[m][n]);
+#pragma unroll
+                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bc[n][2], acc2[m][n]);
+#pragma unroll
+                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bc[n][0], acc2[m][n]);
+#pragma unroll
+                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bc[n][1], acc2[m][n]);
+            }
+#if !(POCR_BF16X3_DBG & 4)
+            if (tap == 4) stA(abuf ^ 1);                // the other A buffer: its last readers passed the barrier of the previous chunk
+#endif
+        }
+#if !(POCR_BF16X3_DBG & 8)
+        __syncthreads();
+#endif
+    }
+    } else {
     ldA(0);
     ldB(wt4);
     stA();
@@ -231,6 +310,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         }
     }
 
+    }
 #pragma unroll
     for (int m = 0; m < MS; ++m)
 #pragma unroll

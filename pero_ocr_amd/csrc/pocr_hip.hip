@@ -131,22 +131,25 @@ POCR_CONV(gemm128_relu_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_RELU, false, STA
 const int kConvNT[9] = {64, 64, 128, 128, 128, 128, 128, 256, 256};
 // The same layers on the bf16 matrix pipe with fp32-level accuracy (conv_bf16x3.hpp: three-way exact operand split, six
 // bf16 MFMAs per product block); tile configurations from tools/conv_bench_bf16.hip.  (TH, MW, NS, WM, POOLH, POOLW, ACT, BN)
-#define POCR_CONV3(name, TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW)                                              \
+#define POCR_CONV3(name, TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW, BDIR)                                        \
     int name(ConvArgs a, hipStream_t st) {                                                                         \
-        return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW>, TH, 16 * MW,         \
+        return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW, BDIR>, TH, 16 * MW,   \
                            NS * (4 / WM) * 16, 256, a, st);                                                        \
     }
-// pixel tiles as in the fp32 table below (same tile tables); measured per layer in profiles/r02_conv_bf16x3_bench.txt
-POCR_CONV3(conv2_b3,  4, 4, 4, 4, 2, 2, ACT_RELU, false, 2)    // 64->64 + pool 2x2: 4x64 px, NT 64, waves split M
-POCR_CONV3(conv3_b3,  4, 2, 2, 1, 1, 1, ACT_RELU, false, 1)    // 64->128: 4x32 px, NT 128
-POCR_CONV3(conv4_b3,  4, 2, 2, 1, 2, 2, ACT_RELU, false, 1)    // 128->128 + pool 2x2
-POCR_CONV3(conv56_b3, 10, 1, 2, 1, 1, 1, ACT_RELU, false, 1)   // ->256: 10x16 px, NT 128
-POCR_CONV3(conv7_b3,  10, 1, 2, 1, 2, 1, ACT_RELU, false, 1)   // 256->256 + pool 2x1
-POCR_CONV3(conv8_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2)   // 256->512: 5x16 px, NT 128, two workgroups per CU
-POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2)    // 512->512 + BN
+// measured per layer in profiles/r02_conv_bf16x3_bench.txt; BDIR = weights straight from L2 into registers (no LDS tile):
+// wins wherever each wave owns its channels (WM 1) and the accumulators leave room for three weight sets
+POCR_CONV3(conv2_b3,  4, 4, 4, 4, 2, 2, ACT_RELU, false, 2, false)   // 64->64 + pool 2x2: 4x64 px, NT 64, waves split M
+POCR_CONV3(conv3_b3,  4, 2, 2, 1, 1, 1, ACT_RELU, false, 1, true)    // 64->128: 4x32 px, NT 128
+POCR_CONV3(conv4_b3,  4, 2, 2, 1, 2, 2, ACT_RELU, false, 1, true)    // 128->128 + pool 2x2
+POCR_CONV3(conv56_b3, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)    // ->256: 5x16 px, NT 128, two workgroups per CU
+POCR_CONV3(conv7_b3,  10, 1, 2, 1, 2, 1, ACT_RELU, false, 1, false)  // 256->256 + pool 2x1: 10x16 px (the pool needs an even tile height)
+POCR_CONV3(conv8_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true)   // 256->512: 5x16 px, NT 128, two workgroups per CU
+POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true)    // 512->512 + BN
 const int kConvNT3[9] = {64, 64, 128, 128, 128, 128, 128, 128, 128};
-// pixel-tile shape (TH, 16*MW) of conv1..conv9 and of the aggregation conv - the same numbers as in the table above
+// pixel-tile shape (TH, 16*MW) of conv1..conv9 and of the aggregation conv - the same numbers as in the tables above
+// (kConvTH3: the bf16x3 configurations, which tile conv5 / conv6 differently)
 const int kConvTH[10] = {4, 4, 4, 4, 10, 10, 10, 5, 5, 1};
+const int kConvTH3[10] = {4, 4, 4, 4, 5, 5, 10, 5, 5, 1};
 const int kConvTW[10] = {32, 64, 32, 32, 16, 16, 16, 16, 16, 48};
 // input width level of each conv (0: W_pad, 1: W_pad/2, 2: (W_pad/2)/2) and of its output
 const int kConvLvlIn[10] = {0, 0, 1, 1, 2, 2, 2, 2, 2, 2};
@@ -1236,7 +1239,7 @@ static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n,
             zlo[1][i] = std::max(c_hi, c_lo); zhi[1][i] = w_pads[i];
         }
     for (int k = 0; k < 10; ++k) {
-        const int th = kConvTH[k], tw = kConvTW[k];
+        const int th = (e->bf16x3 ? kConvTH3 : kConvTH)[k], tw = kConvTW[k];
         const int h_in = k < 9 ? hh : hh;                       // aggregation conv: one output row
         const int rows_out = k < 9 ? h_in : 1;
         const int pw = k < 9 ? kConvPlan[k].pw : 1;

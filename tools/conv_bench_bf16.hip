@@ -23,6 +23,27 @@ struct Variant { const char *name; void (*fn)(ConvArgs, hipStream_t); int nt; bo
     launch(conv_igemm_kernel<3, 3, 1, 1, TH, MW, NS, 4, 16, PH, PW, ACT, BN, STAGE_F32_NHWC, PIPE>, TH, 16 * MW, NS * 64, a, st); }
 #define VBF(NAME, TH, MW, NS, WM, PH, PW, ACT, BN, MINW) static void NAME(ConvArgs a, hipStream_t st) { \
     launch(conv3x3_bf16x3_kernel<TH, MW, NS, WM, PH, PW, ACT, BN, MINW>, TH, 16 * MW, NS * (4 / WM) * 16, a, st); }
+#define VBD(NAME, TH, MW, NS, WM, PH, PW, ACT, BN, MINW) static void NAME(ConvArgs a, hipStream_t st) { \
+    launch(conv3x3_bf16x3_kernel<TH, MW, NS, WM, PH, PW, ACT, BN, MINW, true>, TH, 16 * MW, NS * (4 / WM) * 16, a, st); }
+VBD(d9_a, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2)      // direct weights, 5x16 px, NT128, 2 WG/CU
+VBD(d9_b, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 3)      // 3 WG/CU
+VBD(d9_c, 5, 1, 4, 1, 1, 1, ACT_LEAKY, true, 1)      // NT256
+VBD(d9_d, 10, 1, 2, 1, 1, 1, ACT_LEAKY, true, 1)     // (only H=10 layers)
+VBD(d9_e, 5, 2, 2, 1, 1, 1, ACT_LEAKY, true, 1)      // 5x32 px, N-split, NT128: MS 10
+VBD(d6_a, 10, 1, 2, 1, 1, 1, ACT_RELU, false, 1)
+VBD(d6_b, 10, 1, 2, 1, 1, 1, ACT_RELU, false, 2)
+VBD(d6_c, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2)
+VBD(d6_d, 5, 1, 4, 1, 1, 1, ACT_RELU, false, 1)
+VBD(d8_a, 5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2)
+VBD(d8_b, 5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 3)
+VBD(d7_a, 10, 1, 2, 1, 2, 1, ACT_RELU, false, 1)
+VBD(d7_b, 10, 1, 2, 1, 2, 1, ACT_RELU, false, 2)
+VBD(d4_a, 4, 2, 2, 1, 2, 2, ACT_RELU, false, 1)
+VBD(d4_b, 4, 2, 2, 1, 2, 2, ACT_RELU, false, 2)
+VBD(d3_a, 4, 2, 2, 1, 1, 1, ACT_RELU, false, 1)
+VBD(d3_b, 4, 2, 2, 1, 1, 1, ACT_RELU, false, 2)
+VBD(d2_a, 4, 4, 4, 4, 2, 2, ACT_RELU, false, 2)
+VBD(d2_b, 4, 4, 1, 1, 2, 2, ACT_RELU, false, 2)
 VF32(f9, 5, 1, 4, 1, 1, ACT_LEAKY, true, PIPE_DEEP)
 VBF(b9_a, 5, 1, 4, 1, 1, 1, ACT_LEAKY, true, 1)      // 5x16 px, NT256
 VBF(b9_b, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2)      // 5x16 px, NT128, 2 WG/CU
@@ -68,17 +89,27 @@ int main(int argc, char **argv) {
                             {"bf16x3 5x16 NT128 2WG/CU", b9_b, 128, true}, {"bf16x3 5x48 NT128 N-split", b9_c, 128, true},
                             {"bf16x3 5x32 NT128 2x2", b9_d, 128, true}, {"bf16x3 5x32 NT128 2x2 2WG/CU", b9_e, 128, true},
                             {"bf16x3 5x64 NT64 M-split", b9_f, 64, true}, {"bf16x3 5x64 NT128 M-split", b9_g, 128, true},
-                            {"bf16x3 5x32 NT256 2x2", b9_h, 256, true}};
+                            {"bf16x3 5x32 NT256 2x2", b9_h, 256, true},
+                            {"direct-B 5x16 NT128 2WG", d9_a, 128, true}, {"direct-B 5x16 NT128 3WG", d9_b, 128, true},
+                            {"direct-B 5x16 NT256", d9_c, 256, true}, {"direct-B 5x32 NT128 N-split", d9_e, 128, true}};
     else if (layer == 6) vars = {{"fp32 MFMA (shipped conv6)", f6, 128, false}, {"bf16x3 10x16 NT128", b6_a, 128, true}, {"bf16x3 5x16 NT256", b6_b, 256, true},
-                            {"bf16x3 10x32 NT64 2x2", b6_c, 64, true}, {"bf16x3 10x32 NT128 2x2", b6_d, 128, true}};
-    else if (layer == 3) vars = {{"fp32 MFMA (shipped conv3)", f3, 128, false}, {"bf16x3 4x32 NT128", b3_a, 128, true}, {"bf16x3 4x32 NT128 2WG", b3_b, 128, true}, {"bf16x3 4x64 NT128 2x2", b3_c, 128, true}};
-    else if (layer == 5) vars = {{"fp32 MFMA (shipped conv5)", f5, 128, false}, {"bf16x3 10x16 NT128", b6_a, 128, true}};
-    else if (layer == 7) vars = {{"fp32 MFMA (shipped conv7)", f7, 128, false}, {"bf16x3 10x16 NT128 pool 2x1", b7_a, 128, true}};
-    else if (layer == 8) vars = {{"fp32 MFMA (shipped conv8)", f8, 256, false}, {"bf16x3 5x16 NT128 2WG", b8_a, 128, true}, {"bf16x3 5x16 NT256", b8_b, 256, true}};
+                            {"bf16x3 10x32 NT64 2x2", b6_c, 64, true}, {"bf16x3 10x32 NT128 2x2", b6_d, 128, true},
+                            {"direct-B 10x16 NT128", d6_a, 128, true}, {"direct-B 10x16 NT128 2WG", d6_b, 128, true},
+                            {"direct-B 5x16 NT128 2WG", d6_c, 128, true}, {"direct-B 5x16 NT256", d6_d, 256, true}};
+    else if (layer == 3) vars = {{"fp32 MFMA (shipped conv3)", f3, 128, false}, {"bf16x3 4x32 NT128", b3_a, 128, true}, {"bf16x3 4x32 NT128 2WG", b3_b, 128, true}, {"bf16x3 4x64 NT128 2x2", b3_c, 128, true},
+                            {"direct-B 4x32 NT128", d3_a, 128, true}, {"direct-B 4x32 NT128 2WG", d3_b, 128, true}};
+    else if (layer == 5) vars = {{"fp32 MFMA (shipped conv5)", f5, 128, false}, {"bf16x3 10x16 NT128", b6_a, 128, true}, {"direct-B 10x16 NT128", d6_a, 128, true},
+                            {"direct-B 10x16 NT128 2WG", d6_b, 128, true}, {"direct-B 5x16 NT128 2WG", d6_c, 128, true}};
+    else if (layer == 7) vars = {{"fp32 MFMA (shipped conv7)", f7, 128, false}, {"bf16x3 10x16 NT128 pool 2x1", b7_a, 128, true},
+                            {"direct-B 10x16 NT128", d7_a, 128, true}, {"direct-B 10x16 NT128 2WG", d7_b, 128, true}};
+    else if (layer == 8) vars = {{"fp32 MFMA (shipped conv8)", f8, 256, false}, {"bf16x3 5x16 NT128 2WG", b8_a, 128, true}, {"bf16x3 5x16 NT256", b8_b, 256, true},
+                            {"direct-B 5x16 NT128 2WG", d8_a, 128, true}, {"direct-B 5x16 NT128 3WG", d8_b, 128, true}};
     else if (layer == 4) vars = {{"fp32 MFMA (shipped conv4)", f4, 128, false}, {"bf16x3 4x32 NT128 pool", b4_a, 128, true},
-                            {"bf16x3 4x64 NT128 2x2 pool", b4_b, 128, true}, {"bf16x3 4x64 NT64 2x2 2WG", b4_c, 64, true}};
+                            {"bf16x3 4x64 NT128 2x2 pool", b4_b, 128, true}, {"bf16x3 4x64 NT64 2x2 2WG", b4_c, 64, true},
+                            {"direct-B 4x32 NT128", d4_a, 128, true}, {"direct-B 4x32 NT128 2WG", d4_b, 128, true}};
     else if (layer == 2) vars = {{"fp32 MFMA (shipped conv2)", f2, 64, false}, {"bf16x3 4x64 NT64 N-split", b2_a, 64, true},
-                            {"bf16x3 4x64 NT64 M-split 2WG", b2_b, 64, true}, {"bf16x3 8x64 NT64 M-split", b2_c, 64, true}};
+                            {"bf16x3 4x64 NT64 M-split 2WG", b2_b, 64, true}, {"bf16x3 8x64 NT64 M-split", b2_c, 64, true},
+                            {"direct-B 4x64 NT64 M-split 2WG", d2_a, 64, true}, {"direct-B 4x64 NT64 N-split 2WG", d2_b, 64, true}};
     else { printf("layer %d not covered\n", layer); return 1; }
     const size_t xin = (size_t)n * s.H * s.W * s.cin;
     const int Hout = s.H / s.ph, Wout = s.W / s.pw;
