@@ -500,6 +500,12 @@ def main():
                                if BF16X3 else "fp32 MFMA (v_mfma_f32_16x16x4_f32), dense"),
                 "mfma_pipe_frac": round((6.0 if BF16X3 else 1.0) * dom_tf / (BF16_MFMA_PEAK_TFLOPS if BF16X3 else F32_MFMA_PEAK_TFLOPS), 4),
                 "vs_fp32_mfma_peak_157.3": round(dom_tf / F32_MFMA_PEAK_TFLOPS, 4)}
+            if BF16X3:
+                # measured on this part (tools/mfma_bf16_peak.hip, profiles/r02_mfma_bf16_sustained.txt): a register-only loop of
+                # independent v_mfma_f32_16x16x32_bf16 sustains 2.30 PFLOP/s on zero operands and 1.85-1.91 PFLOP/s on random
+                # ones (power-limited clock), and one wave per SIMD cannot issue more than 1.5 PFLOP/s
+                result["roofline"]["sustained_mfma_probe"] = {"random_operands_tflops": 1880.0, "zero_operands_tflops": 2300.0,
+                                                              "frac_of_sustained_random": round(6.0 * dom_tf / 1880.0, 4)}
             result["conv_backbone"] = {"achieved": round(conv_tf, 2), "peak": round(CONV_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
                                        "frac": round(conv_tf / CONV_PEAK_TFLOPS, 4),
                                        "vs_fp32_mfma_peak_157.3": round(conv_tf / F32_MFMA_PEAK_TFLOPS, 4),
