@@ -30,10 +30,12 @@ struct RcclApi {
     decltype(&ncclGetVersion) GetVersion = nullptr;
     std::string err;
 
-    // 0 on success.  POCR_RCCL_LIB overrides the library name.
+    // 0 on success.  POCR_RCCL_LIB overrides the library name.  The ROCm installation this library was built against comes
+    // first, by path: a process that has imported PyTorch already holds PyTorch's own bundled librccl.so (same SONAME)
+    // together with a second, uninitialised HSA runtime - that copy fails in ncclCommInitRank with "no ROCm-capable device".
     int load() {
         if (lib) return 0;
-        const char *names[] = {getenv("POCR_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        const char *names[] = {getenv("POCR_RCCL_LIB"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
         for (const char *nm : names) {
             if (!nm || !*nm) continue;
             lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);

@@ -515,6 +515,28 @@ def test_rccl_allgather_and_allreduce_world1():
     eng.comm_destroy()          # idempotent
 
 
+def test_rccl_through_the_c_abi_in_a_process_that_imported_pytorch():
+    """PyTorch ships its own librccl.so (same SONAME) next to a second HSA runtime; a communicator created through that
+    copy fails with "no ROCm-capable device".  The C ABI opens the ROCm installation's library by path, so the exchange
+    works whether or not the host process has imported torch (a fresh interpreter: other tests must not decide the order)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch, torch.distributed\n"
+        "import numpy as np\n"
+        "from pero_ocr_amd import _native, netspec, sharding, synth\n"
+        "chars = synth.make_charset(19)\n"
+        "spec = netspec.NetSpec(num_classes=len(chars) + 1, conv_out=64, lstm_hidden=64, lstm_layers=1)\n"
+        "eng = _native.NativeEngine(spec, netspec.pack_weights(spec, netspec.generate_weights(spec, 5)), 0)\n"
+        "tr = sharding.init_rccl_from_env(eng, rank=0, world=1)\n"
+        "out = tr.allgather_i32(np.arange(9, dtype=np.int32))\n"
+        "assert out.tolist() == [list(range(9))] and tr.allreduce_max(2.5) == 2.5\n"
+        "print('RCCL-AFTER-TORCH-OK')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "RCCL-AFTER-TORCH-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
 def test_slot_reset_recovers_an_abandoned_launch(small):
     """A launch that is never collected (exception between launch and collect) must not wedge the engine."""
     spec, weights, eng, net = small
