@@ -142,15 +142,16 @@ POCR_CONV3(conv2_b3,  4, 4, 4, 4, 2, 2, ACT_RELU, false, 2, false)   // 64->64 +
 POCR_CONV3(conv3_b3,  4, 2, 2, 1, 1, 1, ACT_RELU, false, 1, true)    // 64->128: 4x32 px, NT 128
 POCR_CONV3(conv4_b3,  4, 2, 2, 1, 2, 2, ACT_RELU, false, 1, true)    // 128->128 + pool 2x2
 POCR_CONV3(conv56_b3, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)    // ->256: 5x16 px, NT 128, two workgroups per CU
-POCR_CONV3(conv7_b3,  10, 1, 2, 1, 2, 1, ACT_RELU, false, 1, false)  // 256->256 + pool 2x1: 10x16 px (the pool needs an even tile height)
+POCR_CONV3(conv7_b3,  2, 2, 2, 1, 2, 1, ACT_RELU, false, 2, true)    // 256->256 + pool 2x1: 2x32 px (the pool needs an even tile height)
 POCR_CONV3(conv8_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true)   // 256->512: 5x16 px, NT 128, two workgroups per CU
 POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true)    // 512->512 + BN
 const int kConvNT3[9] = {64, 64, 128, 128, 128, 128, 128, 128, 128};
 // pixel-tile shape (TH, 16*MW) of conv1..conv9 and of the aggregation conv - the same numbers as in the tables above
 // (kConvTH3: the bf16x3 configurations, which tile conv5 / conv6 differently)
 const int kConvTH[10] = {4, 4, 4, 4, 10, 10, 10, 5, 5, 1};
-const int kConvTH3[10] = {4, 4, 4, 4, 5, 5, 10, 5, 5, 1};
+const int kConvTH3[10] = {4, 4, 4, 4, 5, 5, 2, 5, 5, 1};
 const int kConvTW[10] = {32, 64, 32, 32, 16, 16, 16, 16, 16, 48};
+const int kConvTW3[10] = {32, 64, 32, 32, 16, 16, 32, 16, 16, 48};
 // input width level of each conv (0: W_pad, 1: W_pad/2, 2: (W_pad/2)/2) and of its output
 const int kConvLvlIn[10] = {0, 0, 1, 1, 2, 2, 2, 2, 2, 2};
 const int kConvLvlOut[10] = {0, 1, 1, 2, 2, 2, 2, 2, 2, 2};
@@ -273,6 +274,9 @@ struct pocr_engine {
     std::vector<DecLayer> dec;
     DevBuf dec_embed, dec_out_w, dec_out_b;
     int dec_out_cout16 = 0;
+    bool lstm_wide = false;          // POCR_LSTM_WIDE=1: recurrence step with four 16-line slices per workgroup (lstm_step_wide_kernel);
+                                     // measured: a quarter of the workgroups and less disturbance of the first convs, but 18 us
+                                     // instead of 12 us per step and 64 KB of LDS that conv2's workgroups leave no room for - slower in all
     bool bf16x3 = true;              // conv2..conv9 on the bf16 matrix pipe with the exact 3-way operand split (POCR_CONV_FP32=1: fp32 MFMA)
     DevBuf cconst[9];                // per conv layer: the output column [H_out][cout] far inside zero padding
     bool pad_skip = false;           // skip + fill constant padding tiles (POCR_NO_PAD_SKIP=1 turns it off)
@@ -547,6 +551,16 @@ int run_network(pocr_engine *e, Slot &s) {
         la.c = s.cbuf.as<float>(); la.y = s.lstm_y[l].as<float>(); la.dims = dims;
         la.line_T = s.g_line_T; la.row_off = s.g_row_off; la.slice_T = s.g_slice_T;
         la.n = n; la.npad = npad; la.T = T; la.H = Hh; la.step = step;
+        if (e->lstm_wide && (Hh == 64 || Hh == 128 || Hh == 256 || Hh == 512)) {
+            const dim3 wgrid(Hh / 16, (slices + 3) / 4, 2);          // four 16-line slices per workgroup (lstm.hpp)
+            switch (Hh) {
+                case 64: hipLaunchKernelGGL(lstm_step_wide_kernel<1>, wgrid, dim3(256), 0, st, la); break;
+                case 128: hipLaunchKernelGGL(lstm_step_wide_kernel<2>, wgrid, dim3(256), 0, st, la); break;
+                case 256: hipLaunchKernelGGL(lstm_step_wide_kernel<4>, wgrid, dim3(256), 0, st, la); break;
+                default: hipLaunchKernelGGL(lstm_step_wide_kernel<8>, wgrid, dim3(256), 0, st, la); break;
+            }
+            return;
+        }
         const dim3 grid(Hh / 16, slices, 2);
         switch (Hh) {
             case 64: hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, st, la); break;
@@ -928,6 +942,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     if (const char *env = getenv("POCR_NO_GRAPHS")) e->use_graphs = atoi(env) == 0;
     if (const char *env = getenv("POCR_LSTM_PERSIST")) e->lstm_persist = atoi(env) != 0;
     if (const char *env = getenv("POCR_CONV_FP32")) e->bf16x3 = atoi(env) == 0;
+    if (const char *env = getenv("POCR_LSTM_WIDE")) e->lstm_wide = atoi(env) != 0;
     e->device = device_id;
     auto bail = [&](int rc) { pocr_destroy(e); return rc; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
@@ -1239,7 +1254,7 @@ static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n,
             zlo[1][i] = std::max(c_hi, c_lo); zhi[1][i] = w_pads[i];
         }
     for (int k = 0; k < 10; ++k) {
-        const int th = (e->bf16x3 ? kConvTH3 : kConvTH)[k], tw = kConvTW[k];
+        const int th = (e->bf16x3 ? kConvTH3 : kConvTH)[k], tw = (e->bf16x3 ? kConvTW3 : kConvTW)[k];
         const int h_in = k < 9 ? hh : hh;                       // aggregation conv: one output row
         const int rows_out = k < 9 ? h_in : 1;
         const int pw = k < 9 ? kConvPlan[k].pw : 1;

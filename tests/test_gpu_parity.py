@@ -537,6 +537,21 @@ def test_rccl_through_the_c_abi_in_a_process_that_imported_pytorch():
     assert "RCCL-AFTER-TORCH-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
+def test_lstm_wide_step_kernel_matches_the_fixture(golden, tmp_path, monkeypatch):
+    """POCR_LSTM_WIDE=1 (four 16-line slices per workgroup, full-K chains instead of split-K partial sums): same strings and
+    per-frame arg-max as the reference fixture, logits within the tolerance - on ragged widths (lines that finish early)."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    monkeypatch.setenv("POCR_LSTM_WIDE", "1")
+    g = golden("ragged")
+    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=g.batch_size)
+    texts, logits, _ = eng.process_lines(g.crops(), sparse_logits=False)
+    assert texts == g.transcriptions
+    for i in range(g.n):
+        li = np.asarray(logits[i])
+        assert np.array_equal(np.argmax(li, axis=1), g.argmax(i))
+        assert float(np.max(np.abs(li[g.sample_rows[i]] - g.rows(i)))) < LOGIT_TOL
+
+
 def test_slot_reset_recovers_an_abandoned_launch(small):
     """A launch that is never collected (exception between launch and collect) must not wedge the engine."""
     spec, weights, eng, net = small
