@@ -274,6 +274,7 @@ struct pocr_engine {
     std::vector<DecLayer> dec;
     DevBuf dec_embed, dec_out_w, dec_out_b;
     int dec_out_cout16 = 0;
+    int lstm_multi = 1;              // POCR_LSTM_MULTI=2|4: split-K step kernel with 2 / 4 slices per workgroup (lstm_step_multi_kernel)
     bool lstm_wide = false;          // POCR_LSTM_WIDE=1: recurrence step with four 16-line slices per workgroup (lstm_step_wide_kernel);
                                      // measured: a quarter of the workgroups and less disturbance of the first convs, but 18 us
                                      // instead of 12 us per step and 64 KB of LDS that conv2's workgroups leave no room for - slower in all
@@ -559,6 +560,15 @@ int run_network(pocr_engine *e, Slot &s) {
                 case 256: hipLaunchKernelGGL(lstm_step_wide_kernel<4>, wgrid, dim3(256), 0, st, la); break;
                 default: hipLaunchKernelGGL(lstm_step_wide_kernel<8>, wgrid, dim3(256), 0, st, la); break;
             }
+            return;
+        }
+        if (e->lstm_multi > 1 && (Hh == 128 || Hh == 256)) {          // SL slices per workgroup, split K (lstm.hpp)
+            const int SLn = e->lstm_multi >= 4 ? 4 : 2;
+            const dim3 mgrid(Hh / 16, (slices + SLn - 1) / SLn, 2);
+            if (Hh == 256 && SLn == 2) hipLaunchKernelGGL((lstm_step_multi_kernel<4, 2>), mgrid, dim3(256), 0, st, la);
+            else if (Hh == 256) hipLaunchKernelGGL((lstm_step_multi_kernel<4, 4>), mgrid, dim3(256), 0, st, la);
+            else if (SLn == 2) hipLaunchKernelGGL((lstm_step_multi_kernel<2, 2>), mgrid, dim3(256), 0, st, la);
+            else hipLaunchKernelGGL((lstm_step_multi_kernel<2, 4>), mgrid, dim3(256), 0, st, la);
             return;
         }
         const dim3 grid(Hh / 16, slices, 2);
@@ -943,6 +953,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     if (const char *env = getenv("POCR_LSTM_PERSIST")) e->lstm_persist = atoi(env) != 0;
     if (const char *env = getenv("POCR_CONV_FP32")) e->bf16x3 = atoi(env) == 0;
     if (const char *env = getenv("POCR_LSTM_WIDE")) e->lstm_wide = atoi(env) != 0;
+    if (const char *env = getenv("POCR_LSTM_MULTI")) e->lstm_multi = atoi(env);
     e->device = device_id;
     auto bail = [&](int rc) { pocr_destroy(e); return rc; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
@@ -952,6 +963,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically lower = higher priority
+        if (const char *env = getenv("POCR_SEQ_PRIO")) prio_hi = atoi(env) == 0 ? 0 : (atoi(env) < 0 ? prio_lo : prio_hi);   // A/B: 0 normal, -1 low
         if (hipStreamCreateWithPriority(&sl.seq_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(fail("hipStreamCreate failed"));
         for (auto &ev : sl.ev)
             if (hipEventCreate(&ev) != hipSuccess) return bail(fail("hipEventCreate failed"));
