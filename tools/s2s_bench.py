@@ -19,7 +19,7 @@ def main():
     width = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     batch_size = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     dec_layers = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-    bias = float(sys.argv[5]) if len(sys.argv) > 5 else 18.0
+    bias = float(sys.argv[5]) if len(sys.argv) > 5 else 20.0
     import torch
     from pero_ocr_amd.ocr_engine import transformer_ocr_engine as te
     if len(sys.argv) > 6:
