@@ -19,7 +19,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 #include "conv_igemm.hpp"
+#ifndef POCR_BF16X3_SCHED
+#define POCR_BF16X3_SCHED 1            // issue-order templates (sched_group_barrier) in the main loops: -2 ... -9 % per layer, same arithmetic
+#endif
 #ifndef POCR_BF16X3_DBG
 #define POCR_BF16X3_DBG 0            // tools/conv_bench_bf16.hip: 1 no A reads, 2 no weight loads, 4 no A staging, 8 no barrier
 #endif
@@ -69,6 +73,12 @@ __device__ __forceinline__ void split3_quad(const f32x4 p, u32x2 &hi, u32x2 &mid
     hi = (u32x2){(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
     mid = (u32x2){(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
     lo = (u32x2){(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
+}
+
+// Issue-order template for the scheduler (LDS-weights loop): the G operand reads of a step spread evenly between its TOT MFMAs.
+template <int G, int TOT, int... I>
+__device__ __forceinline__ void sched_template_lds(std::integer_sequence<int, I...>) {
+    ((__builtin_amdgcn_sched_group_barrier(0x008, ((I + 1) * TOT) / G - (I * TOT) / G, 0), __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)), ...);
 }
 
 // WM waves split the pixel tile (column strips), 4 / WM waves split the output channels; the B tile (weights of one
@@ -251,6 +261,19 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
                 for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bc[n][1], acc2[m][n]);
             }
+#if POCR_BF16X3_SCHED
+            // issue order of one step, as a template for the scheduler: the A reads and the weight loads of the step after
+            // next spread between the MFMAs instead of bunched where the source puts them (mask 8 MFMA, 0x100 DS read, 0x20 VMEM read)
+            {
+                constexpr int G = MS * 3, MPG = NS * 2, NV = NS * 3;      // one A read per group of NS * 2 MFMAs; NV weight loads spread over the G groups
+#pragma unroll
+                for (int gq = 0; gq < G; ++gq) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if ((gq * NV) / G != ((gq + 1) * NV) / G) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+#endif
 #if !(POCR_BF16X3_DBG & 4)
             if (tap == 4) stA(abuf ^ 1);                // the other A buffer: its last readers passed the barrier of the previous chunk
 #endif
@@ -301,6 +324,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
                 for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bm[n], acc2[m][n]);
             }
+#if POCR_BF16X3_SCHED
+            sched_template_lds<(MS + NS) * 3, MS * NS * 6>(std::make_integer_sequence<int, (MS + NS) * 3>{});
+#endif
             if (more) stB(bcur ^ 1);
             if (last && next_chunk) {
                 __syncthreads();                        // every wave has read the last tap of this chunk's halo tile
