@@ -89,12 +89,16 @@ __device__ __forceinline__ void sched_template_lds(std::integer_sequence<int, I.
 // plane).  LDS then carries only the A planes (double-buffered: one barrier per 32-channel chunk instead of ten), which
 // matters because the loop is LDS-bound as much as MFMA-bound: per 16-cycle MFMA a SIMD's share of the LDS pipe is 512 B,
 // and operands cost 512 B x (1/NS + 1/MS) to read plus ~100 B to write the shared weight tile.
-template <int TH, int MW, int NS, int WM, int POOLH, int POOLW, int ACT, bool BN, int MINW = 1, bool BDIR = false>
+// KH x KW taps with PADH / PADW rows / columns of zero padding: 3x3 pad 1 (the backbone), AH x 1 pad 0 (the aggregation
+// conv), 1x1 pad 0 (GEMM mode: "pixels" are the rows of a [rows][cin] matrix).
+template <int TH, int MW, int NS, int WM, int POOLH, int POOLW, int ACT, bool BN, int MINW = 1, bool BDIR = false,
+          int KH = 3, int KW = 3, int PADH = 1, int PADW = 1>
 __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
-    constexpr int NWAVE = 4, WN = NWAVE / WM, KC = 32;
+    constexpr int NWAVE = 4, WN = NWAVE / WM, KC = 32, NTAP = KH * KW;
+    static_assert(!BDIR || NTAP == 9, "the register-rotated weight sets assume 9 taps");
     static_assert(MW % WM == 0, "column strips must divide among the M waves");
     constexpr int TW = 16 * MW, MWW = MW / WM, MS = TH * MWW, NT = NS * WN * 16, NTHR = 256;
-    constexpr int HH = TH + 2, HW = TW + 2, NP = HH * HW, NPPAD = (NP + 15) / 16 * 16;
+    constexpr int HH = TH + KH - 1, HW = TW + KW - 1, NP = HH * HW, NPPAD = (NP + 15) / 16 * 16;
     constexpr int CQ = KC / 4;
     constexpr int PS = 4 * NPPAD;                       // 16-byte units per bf16 plane of the A tile ([octet][pixel])
     constexpr int A_U = 3 * PS;                         // A tile (single-buffered, refilled once per chunk; BDIR: two of them)
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         const int e = tid + r * NTHR;
         const int cq = e % CQ, p = e / CQ;
         const int hr = p / HW, wc = p % HW;
-        const int hi = h0 - 1 + hr, wi = w0 - 1 + wc;
+        const int hi = h0 - PADH + hr, wi = w0 - PADW + wc;
         a_ok[r] = e < CQ * NP && hi >= 0 && hi < a.H && wi >= 0 && wi < Win;
         a_off[r] = a_ok[r] ? (unsigned)((hi * Win + wi) * a.cin + cq * 4) : 0u;
         a_lds[r] = e < CQ * NP ? ((cq >> 1) * NPPAD + p) * 2 + (cq & 1) : -1;
@@ -292,12 +296,12 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool next_chunk = chunk + 1 < nchunks;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap, ++step) {
-            const bool last = tap == 8, more = !last || next_chunk;
+        for (int tap = 0; tap < NTAP; ++tap, ++step) {
+            const bool last = tap == NTAP - 1, more = !last || next_chunk;
             const int bcur = step & 1;
             if (more) ldB(wt4 + (size_t)(last ? 0 : tap + 1) * tap_stride + (size_t)(last ? chunk + 1 : chunk) * chunk_stride);
             if (tap == 0 && next_chunk) ldA(chunk + 1);
-            const int dy = tap / 3, dx = tap % 3;
+            const int dy = tap / KW, dx = tap % KW;
             const u32x4 *Ab = ldsA + dy * HW + dx + li + kq * NPPAD + wm * MWW * 16;
             const u32x4 *Bb = ldsB + bcur * B_F4 + (wn * NS) * 192 + lane;
             u32x4 bh[NS], bm[NS], bl[NS];

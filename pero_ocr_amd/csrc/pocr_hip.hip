@@ -8,6 +8,7 @@
 #include <cstring>
 #include <algorithm>
 #include <functional>
+#include <unordered_set>
 #include <map>
 #include <tuple>
 #include <string>
@@ -145,6 +146,19 @@ POCR_CONV3(conv56_b3, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)    // ->256: 5
 POCR_CONV3(conv7_b3,  2, 2, 2, 1, 2, 1, ACT_RELU, false, 2, true)    // 256->256 + pool 2x1: 2x32 px (the pool needs an even tile height)
 POCR_CONV3(conv8_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true)   // 256->512: 5x16 px, NT 128, two workgroups per CU
 POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true)    // 512->512 + BN
+// the aggregation conv (AH x 1, no padding) and the GEMM-mode layers (1 x 1: LSTM input projections, encoder linears) on the
+// same kernel: weights through LDS, 48 pixels x 256 channels / 128 rows x 128 columns per workgroup
+#define POCR_CONV3G(name, TH, MW, NS, WM, ACT, MINW, KH)                                                            \
+    int name(ConvArgs a, hipStream_t st) {                                                                         \
+        return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT, false, MINW, false, KH, 1, 0, 0>, TH,   \
+                           16 * MW, NS * (4 / WM) * 16, 256, a, st);                                               \
+    }
+POCR_CONV3G(agg4_b3, 1, 3, 4, 1, ACT_LEAKY, 1, 4)
+POCR_CONV3G(agg5_b3, 1, 3, 4, 1, ACT_LEAKY, 1, 5)
+POCR_CONV3G(agg6_b3, 1, 3, 2, 1, ACT_LEAKY, 1, 6)
+POCR_CONV3G(agg8_b3, 1, 3, 2, 1, ACT_LEAKY, 1, 8)
+POCR_CONV3G(gemm128_b3, 1, 8, 4, 2, ACT_NONE, 2, 1)
+POCR_CONV3G(gemm128_relu_b3, 1, 8, 4, 2, ACT_RELU, 2, 1)
 const int kConvNT3[9] = {64, 64, 128, 128, 128, 128, 128, 128, 128};
 // pixel-tile shape (TH, 16*MW) of conv1..conv9 and of the aggregation conv - the same numbers as in the tables above
 // (kConvTH3: the bf16x3 configurations, which tile conv5 / conv6 differently)
@@ -158,6 +172,32 @@ const int kConvLvlOut[10] = {0, 1, 1, 2, 2, 2, 2, 2, 2, 2};
 const int kAggNT = 256, kProjNT = 128, kHeadNT = 64, kSkinnyNT = 64;
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// wsplit[tap][cin/32][cout16][plane][lane][8 bf16] = plane of W(co = 16 s + (lane & 15), ci = 32 g + 8 (lane >> 4) + j, tap):
+// hi / mid / lo of the exact truncation split (conv_bf16x3.hpp), zero outside cout_valid
+std::vector<uint16_t> build_wsplit(int ntaps, int cin, int cout16, const std::function<float(int, int, int)> &W, int cout_valid) {
+    std::vector<uint16_t> wsp((size_t)ntaps * (cin / 32) * cout16 * 3 * 64 * 8);
+    size_t o = 0;
+    for (int tap = 0; tap < ntaps; ++tap)
+        for (int g = 0; g < cin / 32; ++g)
+            for (int sg = 0; sg < cout16; ++sg) {
+                uint16_t part[3][64][8];
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 16 * sg + (lane & 15), ci = 32 * g + 8 * (lane >> 4) + j;
+                        const float wv = co < cout_valid ? W(co, ci, tap) : 0.f;
+                        uint32_t wb; memcpy(&wb, &wv, 4);
+                        const uint32_t hb = wb & 0xffff0000u; float hf; memcpy(&hf, &hb, 4);
+                        const float r1 = wv - hf; uint32_t r1b; memcpy(&r1b, &r1, 4);
+                        const uint32_t mb = r1b & 0xffff0000u; float mf; memcpy(&mf, &mb, 4);
+                        const float r2 = r1 - mf; uint32_t r2b; memcpy(&r2b, &r2, 4);
+                        part[0][lane][j] = (uint16_t)(hb >> 16); part[1][lane][j] = (uint16_t)(mb >> 16); part[2][lane][j] = (uint16_t)(r2b >> 16);
+                    }
+                memcpy(&wsp[o], part, sizeof(part));
+                o += 3 * 64 * 8;
+            }
+    return wsp;
+}
 
 }  // namespace
 
@@ -256,6 +296,7 @@ struct pocr_engine {
     std::vector<float> embed_table;  // style embeddings [embed_num + 1][2E] (host copy); embed_ss = (1 + scale | shift) of the chosen row
     DevBuf embed_ss;
     int embed_id = -1;
+    std::unordered_set<const void *> b3_weights;   // weight buffers laid out for the bf16x3 kernels (wsplit): the GEMM-mode / aggregation launches ask
     std::vector<DevBuf> proj_w, proj_b, whh;       // per LSTM layer
     std::vector<DevBuf> whh_p;                     // per LSTM layer: W_hh as wave-private register fragments (lstm_persist.hpp)
     bool lstm_persist = false;                     // POCR_LSTM_PERSIST=1: one persistent launch per layer (lstm_persist.hpp) instead
@@ -293,6 +334,13 @@ struct pocr_engine {
 };
 
 namespace {
+
+int upload_u16(DevBuf &b, const std::vector<uint16_t> &v, hipStream_t st) {
+    if (b.reserve(v.size() * sizeof(uint16_t))) return 1;
+    HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
 
 int upload(DevBuf &b, const std::vector<float> &v, hipStream_t st) {
     if (b.reserve(v.size() * sizeof(float))) return 1;
@@ -436,7 +484,9 @@ int run_network(pocr_engine *e, Slot &s) {
         a.cout16 = e->agg_cout16; a.cout_valid = E; a.out_stride = E;
         a.wfrag = e->agg_w.as<float>(); a.bias = e->agg_b.as<float>(); a.y = s.feat.as<float>();
         mark(POCR_STAGE_AGG);
-        int rc = AH == 4 ? agg4_k(a, st) : AH == 5 ? agg5_k(a, st) : AH == 6 ? agg6_k(a, st) : agg8_k(a, st);
+        int rc;
+        if (e->b3_weights.count(e->agg_w.p)) rc = AH == 4 ? agg4_b3(a, st) : AH == 5 ? agg5_b3(a, st) : AH == 6 ? agg6_b3(a, st) : agg8_b3(a, st);
+        else rc = AH == 4 ? agg4_k(a, st) : AH == 5 ? agg5_k(a, st) : AH == 6 ? agg6_k(a, st) : agg8_k(a, st);
         if (rc) return rc;
         if (c.embed_num > 0) {      // f * (1 + scale) + shift, the chosen style row for every line (pytorch_ocr_engine.py:64-66)
             if (e->embed_id < 0) return fail("this model has an embeddings layer: pocr_set_embed_id first");
@@ -483,6 +533,7 @@ int run_network(pocr_engine *e, Slot &s) {
         g.x = x_; g.n = 1; g.H = 1; g.W = rows; g.Ho = 1; g.Wo = rows; g.cin = cin_;
         g.cout16 = round_up(cout_, kProjNT) / 16; g.cout_valid = cout_; g.out_stride = cout_;
         g.wfrag = w_.as<float>(); g.bias = b_.as<float>(); g.y = y_;
+        if (e->b3_weights.count(w_.p)) return relu ? gemm128_relu_b3(g, st) : gemm128_b3(g, st);
         return relu ? gemm128_relu_k(g, st) : gemm128_k(g, st);
     };
     ln(s.feat.as<float>(), nullptr, e->sa_nw, e->sa_nb, e->pe.as<float>(), s.sa_x.as<float>());
@@ -600,7 +651,7 @@ int run_network(pocr_engine *e, Slot &s) {
         a.x = layer_in; a.n = 1; a.H = 1; a.W = rows; a.Ho = 1; a.Wo = rows; a.cin = din;
         a.cout16 = e->proj_cout16; a.cout_valid = 8 * Hh; a.out_stride = 8 * Hh;
         a.wfrag = e->proj_w[l].as<float>(); a.bias = e->proj_b[l].as<float>(); a.y = s.xproj.as<float>();
-        if (gemm128_k(a, st)) return 1;
+        if (e->b3_weights.count(e->proj_w[l].p) ? gemm128_b3(a, st) : gemm128_k(a, st)) return 1;
         if (persist) {
             // the serial part in ONE launch: 2 x H/16 resident workgroups walk (step, 16-line slice) items (lstm_persist.hpp)
             LstmPersistArgs pa{};
@@ -1041,10 +1092,16 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         const float *w = cur.take((size_t)E * 512 * AH);
         const float *b = cur.take(E);
         e->agg_cout16 = round_up(E, kAggNT) / 16;
-        auto frag = build_wfrag(AH, 512, e->agg_cout16, [&](int co, int ci, int tap) { return w[((size_t)co * 512 + ci) * AH + tap]; }, 512, E);
         std::vector<float> bias(e->agg_cout16 * 16, 0.f);
         for (int k = 0; k < E; ++k) bias[k] = b[k];
-        if (upload(e->agg_w, frag, st) || upload(e->agg_b, bias, st)) return bail(1);
+        if (e->bf16x3) {
+            auto wsp = build_wsplit(AH, 512, e->agg_cout16, [&](int co, int ci, int tap) { return w[((size_t)co * 512 + ci) * AH + tap]; }, E);
+            if (upload_u16(e->agg_w, wsp, st) || upload(e->agg_b, bias, st)) return bail(1);
+            e->b3_weights.insert(e->agg_w.p);
+        } else {
+            auto frag = build_wfrag(AH, 512, e->agg_cout16, [&](int co, int ci, int tap) { return w[((size_t)co * 512 + ci) * AH + tap]; }, 512, E);
+            if (upload(e->agg_w, frag, st) || upload(e->agg_b, bias, st)) return bail(1);
+        }
     }
     int head_in = 2 * cfg->lstm_hidden;
     if (cfg->arch == POCR_ARCH_SA || cfg->arch == POCR_ARCH_S2S) {   // self-attention encoder weights
@@ -1054,9 +1111,15 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         // rows [r0, r0 + cout_) of a [*, cin_] matrix at w / b -> fragment order, cout padded to a multiple of nt
         auto lin_rows = [&](DevBuf &wbuf, DevBuf &bbuf, const float *w, const float *b, int r0, int cout_, int cin_, int nt) {
             const int c16 = round_up(cout_, nt) / 16;
-            auto frag = build_wfrag(1, cin_, c16, [&](int co, int ci, int) { return w[(size_t)(r0 + co) * cin_ + ci]; }, cin_, cout_);
             std::vector<float> bias(c16 * 16, 0.f);
             for (int k = 0; k < cout_; ++k) bias[k] = b[r0 + k];
+            if (e->bf16x3 && nt == kProjNT && cin_ % 32 == 0) {          // runs on gemm128_b3
+                auto wsp = build_wsplit(1, cin_, c16, [&](int co, int ci, int) { return w[(size_t)(r0 + co) * cin_ + ci]; }, cout_);
+                if (upload_u16(wbuf, wsp, st) || upload(bbuf, bias, st)) return true;
+                e->b3_weights.insert(wbuf.p);
+                return false;
+            }
+            auto frag = build_wfrag(1, cin_, c16, [&](int co, int ci, int) { return w[(size_t)(r0 + co) * cin_ + ci]; }, cin_, cout_);
             return upload(wbuf, frag, st) || upload(bbuf, bias, st);
         };
         auto lin = [&](DevBuf &wbuf, DevBuf &bbuf, int cout_, int cin_) {
@@ -1106,7 +1169,11 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
                 wih[d] = cur.take((size_t)4 * Hh * din); whh[d] = cur.take((size_t)4 * Hh * Hh);
                 bih[d] = cur.take(4 * Hh); bhh[d] = cur.take(4 * Hh);
             }
-            auto frag = build_wfrag(1, din, e->proj_cout16, [&](int co, int ci, int) { const int d = co / (4 * Hh), r = co % (4 * Hh); return wih[d][(size_t)r * din + ci]; }, din, 8 * Hh);
+            const bool proj_b3 = e->bf16x3 && din % 32 == 0;
+            std::vector<float> frag;
+            std::vector<uint16_t> proj_split;
+            if (proj_b3) proj_split = build_wsplit(1, din, e->proj_cout16, [&](int co, int ci, int) { const int d = co / (4 * Hh), r = co % (4 * Hh); return wih[d][(size_t)r * din + ci]; }, 8 * Hh);
+            else frag = build_wfrag(1, din, e->proj_cout16, [&](int co, int ci, int) { const int d = co / (4 * Hh), r = co % (4 * Hh); return wih[d][(size_t)r * din + ci]; }, din, 8 * Hh);
             std::vector<float> bias(e->proj_cout16 * 16, 0.f);
             for (int d = 0; d < 2; ++d)
                 for (int r = 0; r < 4 * Hh; ++r) bias[d * 4 * Hh + r] = bih[d][r] + bhh[d][r];
@@ -1120,7 +1187,8 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
                             for (int lane = 0; lane < 64; ++lane)
                                 for (int j = 0; j < 4; ++j)
                                     wf[o++] = whh[d][(size_t)(g * Hh + 16 * ug + (lane & 15)) * Hh + 16 * kg + 4 * (lane >> 4) + j];
-            if (upload(e->proj_w[l], frag, st) || upload(e->proj_b[l], bias, st) || upload(e->whh[l], wf, st)) return bail(1);
+            if ((proj_b3 ? upload_u16(e->proj_w[l], proj_split, st) : upload(e->proj_w[l], frag, st)) || upload(e->proj_b[l], bias, st) || upload(e->whh[l], wf, st)) return bail(1);
+            if (proj_b3) e->b3_weights.insert(e->proj_w[l].p);
             // whh_p[dir][unit quad][kg][lane][j] = W_hh[(lane & 15) / 4 * H + 4 * quad + (lane & 3)][16 kg + 4 (lane >> 4) + j]:
             // the 16 gate columns (gate-major) of 4 hidden units, the B operand a wave of lstm_persist_kernel keeps in registers
             std::vector<float> wpf((size_t)2 * (Hh / 4) * KGT * 256);
