@@ -91,8 +91,10 @@ __device__ __forceinline__ void sched_template_lds(std::integer_sequence<int, I.
 // and operands cost 512 B x (1/NS + 1/MS) to read plus ~100 B to write the shared weight tile.
 // KH x KW taps with PADH / PADW rows / columns of zero padding: 3x3 pad 1 (the backbone), AH x 1 pad 0 (the aggregation
 // conv), 1x1 pad 0 (GEMM mode: "pixels" are the rows of a [rows][cin] matrix).
+// UPCAT: the input is the virtual tensor cat([nearest-upsample-x2(x), x2], channels) of the layout network's decoder
+// (conv_igemm.hpp STAGE_UPCAT): 32-channel chunks below cin_up come from x at half resolution, the rest from the skip tensor.
 template <int TH, int MW, int NS, int WM, int POOLH, int POOLW, int ACT, bool BN, int MINW = 1, bool BDIR = false,
-          int KH = 3, int KW = 3, int PADH = 1, int PADW = 1>
+          int KH = 3, int KW = 3, int PADH = 1, int PADW = 1, bool UPCAT = false>
 __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     constexpr int NWAVE = 4, WN = NWAVE / WM, KC = 32, NTAP = KH * KW;
     static_assert(!BDIR || NTAP == 9, "the register-rotated weight sets assume 9 taps");
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 
     const int nchunks = a.cin / KC;
     unsigned a_off[A_LD];
+    unsigned a_off2[UPCAT ? A_LD : 1];                  // UPCAT: offsets into the skip tensor (a_off: into the half-resolution one)
     bool a_ok[A_LD];
     int a_lds[A_LD];                                    // index (8-byte units) of the quad's slot inside plane 0, -1 = none
 #pragma unroll
@@ -165,17 +168,27 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         const int hr = p / HW, wc = p % HW;
         const int hi = h0 - PADH + hr, wi = w0 - PADW + wc;
         a_ok[r] = e < CQ * NP && hi >= 0 && hi < a.H && wi >= 0 && wi < Win;
-        a_off[r] = a_ok[r] ? (unsigned)((hi * Win + wi) * a.cin + cq * 4) : 0u;
+        if constexpr (UPCAT) {
+            a_off[r] = a_ok[r] ? (unsigned)(((hi >> 1) * (Win >> 1) + (wi >> 1)) * a.cin_up + cq * 4) : 0u;
+            a_off2[r] = a_ok[r] ? (unsigned)((hi * Win + wi) * (a.cin - a.cin_up) + cq * 4) : 0u;
+        } else {
+            a_off[r] = a_ok[r] ? (unsigned)((hi * Win + wi) * a.cin + cq * 4) : 0u;
+        }
         a_lds[r] = e < CQ * NP ? ((cq >> 1) * NPPAD + p) * 2 + (cq & 1) : -1;
     }
-    const float *ximg = a.x + img_base;
+    const float *ximg = UPCAT ? a.x + (size_t)img * (a.H >> 1) * (Win >> 1) * a.cin_up : a.x + img_base;
+    const float *ximg2 = UPCAT ? a.x2 + (size_t)img * a.H * Win * (a.cin - a.cin_up) : nullptr;
+    const int nch_up = UPCAT ? a.cin_up / KC : 0;
     const f32x4 *wt4 = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * (NT / 16) * 192;     // 192 x 16 B per cout tile
     const size_t chunk_stride = (size_t)a.cout16 * 192, tap_stride = (size_t)nchunks * chunk_stride;
     f32x4 ra[A_LD], rb[B_LD];
     auto ldA = [&](int chunk) {
 #pragma unroll
-        for (int r = 0; r < A_LD; ++r)
-            ra[r] = a_ok[r] ? *reinterpret_cast<const f32x4 *>(ximg + chunk * KC + a_off[r]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < A_LD; ++r) {
+            const float *src = ximg + chunk * KC + a_off[r];
+            if constexpr (UPCAT) { if (chunk >= nch_up) src = ximg2 + (chunk - nch_up) * KC + a_off2[r]; }
+            ra[r] = a_ok[r] ? *reinterpret_cast<const f32x4 *>(src) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     };
     auto stA = [&](int abuf = 0) {                      // split into the three bf16 planes on the way into LDS
         u32x2 *base = reinterpret_cast<u32x2 *>(ldsA + abuf * A_U);

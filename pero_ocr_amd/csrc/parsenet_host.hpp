@@ -11,7 +11,7 @@ POCR_CONV(pn_up_small_k, 3, 3, 1, 1, 10, 1, 2, 4, 16, 1, 1, ACT_RELU, false, STA
 POCR_CONV(pn_up_mid_k,   3, 3, 1, 1, 4, 2, 2, 4, 16, 1, 1, ACT_RELU, false, STAGE_UPCAT, PIPE_INTERLEAVED)     // decoder @1/4 (NT 128)
 POCR_CONV(pn_up_big_k,   3, 3, 1, 1, 4, 4, 1, 4, 16, 1, 1, ACT_RELU, false, STAGE_UPCAT, PIPE_DEEP)            // decoder @1/2, 1/1 (NT 64)
 
-struct PnLayer { int cin, cout, nt; DevBuf w, b; int cout16; };
+struct PnLayer { int cin, cout, nt; DevBuf w, b; int cout16; bool b3; };
 
 }  // namespace
 
@@ -94,6 +94,14 @@ int pocr_parsenet_create(const float *weights, size_t n_floats, int device_id, p
         L.cin = kPnEnc[i][0]; L.cout = kPnEnc[i][1]; L.nt = enc_nt[i];
         const float *w = cur.take((size_t)L.cout * L.cin * 9), *b = cur.take(L.cout);
         L.cout16 = round_up(L.cout, L.nt) / 16;
+        L.b3 = i > 0 && getenv("POCR_CONV_FP32") == nullptr;          // e0 (3 input channels, fused uint8 staging) stays on the fp32 kernel
+        if (L.b3) {
+            auto wsp = build_wsplit(9, L.cin, L.cout16, [&](int co, int ci, int tap) { return w[((size_t)co * L.cin + ci) * 9 + tap]; }, L.cout);
+            std::vector<float> bias(L.cout16 * 16, 0.f);
+            for (int k = 0; k < L.cout; ++k) bias[k] = b[k];
+            if (upload_u16(L.w, wsp, st) || upload(L.b, bias, st)) return bail(1);
+            continue;
+        }
         std::vector<float> frag;
         if (i == 0) frag = build_wfrag(1, 32, L.cout16, [&](int co, int k, int) { const int tap = k / 3, c = k % 3; return w[((size_t)co * 3 + c) * 9 + tap]; }, 27, L.cout);
         else frag = build_wfrag(9, L.cin, L.cout16, [&](int co, int ci, int tap) { return w[((size_t)co * L.cin + ci) * 9 + tap]; }, L.cin, L.cout);
@@ -107,9 +115,15 @@ int pocr_parsenet_create(const float *weights, size_t n_floats, int device_id, p
         L.cin = kPnDec[i][0] + kPnDec[i][1]; L.cout = kPnDec[i][2]; L.nt = dec_nt[i];
         const float *w = cur.take((size_t)L.cout * L.cin * 9), *b = cur.take(L.cout);
         L.cout16 = round_up(L.cout, L.nt) / 16;
-        auto frag = build_wfrag(9, L.cin, L.cout16, [&](int co, int ci, int tap) { return w[((size_t)co * L.cin + ci) * 9 + tap]; }, L.cin, L.cout);
+        L.b3 = getenv("POCR_CONV_FP32") == nullptr;
         std::vector<float> bias(L.cout16 * 16, 0.f);
         for (int k = 0; k < L.cout; ++k) bias[k] = b[k];
+        if (L.b3) {
+            auto wsp = build_wsplit(9, L.cin, L.cout16, [&](int co, int ci, int tap) { return w[((size_t)co * L.cin + ci) * 9 + tap]; }, L.cout);
+            if (upload_u16(L.w, wsp, st) || upload(L.b, bias, st)) return bail(1);
+            continue;
+        }
+        auto frag = build_wfrag(9, L.cin, L.cout16, [&](int co, int ci, int tap) { return w[((size_t)co * L.cin + ci) * 9 + tap]; }, L.cin, L.cout);
         if (upload(L.w, frag, st) || upload(L.b, bias, st)) return bail(1);
     }
     {
@@ -209,6 +223,10 @@ int pocr_parsenet_get_maps(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, 
     // ---- encoder: e{k} at level k (skip x_k), e{k}p pools into level k+1
     int (*enc_fn[13])(ConvArgs, hipStream_t) = {nullptr, conv2_k, conv3_k, conv4_k, conv56_k, pn_pool256_k, conv56_k, pn_pool256_k,
                                                  conv56_k, pn_pool256_k, conv56_k, pn_pool256_k, conv56_k};
+    // the same layers on the bf16x3 kernels (conv_bf16x3.hpp): 64->64 + pool, 64->128, 128->128 + pool, ->256, 256->256 + pool
+    int (*enc_fn3[13])(ConvArgs, hipStream_t) = {nullptr, conv2_b3, conv3_b3, conv4_b3, conv56_b3, conv4_b3, conv56_b3, conv4_b3,
+                                                  conv56_b3, conv4_b3, conv56_b3, conv4_b3, conv56_b3};
+    for (int i = 1; i < 13; ++i) if (p->enc[i].b3) enc_fn[i] = enc_fn3[i];
     for (int i = 1; i < 13; ++i) {
         const int k = i / 2;                          // level of the conv's INPUT: e{k}p (odd i) reads x_k, e{k} (even i) reads p_k
         const bool pool = i & 1;
@@ -218,6 +236,8 @@ int pocr_parsenet_get_maps(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, 
     }
     // ---- decoder: y_k = ReLU(conv(cat(up2(y_{k+1}), x_k))), k = 5 .. 0 (up-sampling and concatenation happen in the conv's staging)
     int (*dec_fn[6])(ConvArgs, hipStream_t) = {pn_up_small_k, pn_up_small_k, pn_up_small_k, pn_up_mid_k, pn_up_big_k, pn_up_big_k};
+    int (*dec_fn3[6])(ConvArgs, hipStream_t) = {pn_up128_b3, pn_up128_b3, pn_up128_b3, pn_up128_b3, pn_up64_b3, pn_up64_b3};
+    for (int i = 0; i < 6; ++i) if (p->dec[i].b3) dec_fn[i] = dec_fn3[i];
     for (int i = 0; i < 6; ++i) {
         const int k = 5 - i;
         const float *up = i == 0 ? p->x[6].as<float>() : p->y[i - 1].as<float>();

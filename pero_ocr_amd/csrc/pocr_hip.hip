@@ -153,6 +153,14 @@ POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true)    // 512->512
         return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT, false, MINW, false, KH, 1, 0, 0>, TH,   \
                            16 * MW, NS * (4 / WM) * 16, 256, a, st);                                               \
     }
+// decoder convs of the layout network: virtual cat(up2(x), skip) input
+#define POCR_CONV3U(name, TH, MW, NS, WM, MINW, BDIR)                                                               \
+    int name(ConvArgs a, hipStream_t st) {                                                                         \
+        return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT_RELU, false, MINW, BDIR, 3, 3, 1, 1, true>, \
+                           TH, 16 * MW, NS * (4 / WM) * 16, 256, a, st);                                           \
+    }
+POCR_CONV3U(pn_up128_b3, 5, 1, 2, 1, 2, true)       // NT 128
+POCR_CONV3U(pn_up64_b3, 4, 4, 4, 4, 2, false)       // NT 64 (d1, d0: 64 output channels), waves split the pixels
 POCR_CONV3G(agg4_b3, 1, 3, 4, 1, ACT_LEAKY, 1, 4)
 POCR_CONV3G(agg5_b3, 1, 3, 4, 1, ACT_LEAKY, 1, 5)
 POCR_CONV3G(agg6_b3, 1, 3, 2, 1, ACT_LEAKY, 1, 6)
