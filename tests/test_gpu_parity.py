@@ -552,6 +552,35 @@ def test_lstm_wide_step_kernel_matches_the_fixture(golden, tmp_path, monkeypatch
         assert float(np.max(np.abs(li[g.sample_rows[i]] - g.rows(i)))) < LOGIT_TOL
 
 
+@pytest.mark.parametrize("kw", [
+    dict(height=32, conv_out=64, lstm_hidden=64, lstm_layers=1),       # aggregation 4 x 1, H = 64 recurrence
+    dict(height=48, conv_out=128, lstm_hidden=128, lstm_layers=2),     # aggregation 6 x 1
+    dict(height=64, conv_out=256, lstm_hidden=64, lstm_layers=1),      # aggregation 8 x 1
+    dict(height=40, conv_out=48, lstm_hidden=48, lstm_layers=2),       # widths that are not multiples of 32: fp32-MFMA projections
+    dict(height=40, conv_out=128, sa_heads=4, sa_ff=272, sa_layers=1, arch=netspec.ARCH_SA),   # encoder, feed-forward width not a multiple of 32
+])
+def test_other_geometries_against_oracle(kw, tmp_path):
+    """Line heights 32 / 48 / 64 (the other aggregation kernels), other widths of the recurrent and encoder layers (which decide
+    whether a linear layer runs on the bf16x3 kernel in GEMM mode or on the fp32-MFMA one): engine vs the reference-pinned oracle."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    chars = synth.make_charset(40)
+    spec = netspec.NetSpec(num_classes=len(chars) + 1, **kw)
+    weights = netspec.generate_weights(spec, 4242)
+    netspec.save_blob(os.path.join(str(tmp_path), "w.pocrw"), spec, weights)
+    path = os.path.join(str(tmp_path), "ocr.json")
+    with open(path, "w", encoding="utf8") as f:
+        json.dump({"line_px_height": spec.height, "line_vertical_scale": 1.0, "checkpoint": "w.pocrw", "characters": chars, "net_name": "t"}, f)
+    eng = PytorchEngineLineOCR(path, Dev(), batch_size=8)
+    crops = synth.make_crops(77, [200, 64, 333, 517, 90, 33, 700], spec.height)
+    net = model_oracle.OracleNet(spec, weights)
+    want_t, want_l, want_c, _ = engine_oracle.process_lines(lambda b: model_oracle.forward_logits(net, b), crops, eng.characters,
+                                                            spec.height, 480 * 8, sparse_logits=False)
+    got_t, got_l, got_c = eng.process_lines(crops, sparse_logits=False)
+    assert got_t == want_t and got_c == want_c
+    worst = max(float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) for a, b in zip(got_l, want_l))
+    assert worst < LOGIT_TOL, worst
+
+
 def test_slot_reset_recovers_an_abandoned_launch(small):
     """A launch that is never collected (exception between launch and collect) must not wedge the engine."""
     spec, weights, eng, net = small
