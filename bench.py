@@ -153,6 +153,25 @@ def cpu_baseline(spec, weights, crops, width, batch_size):
             "thread_sweep_lines_per_s": {str(k): round(v, 2) for k, v in sweep.items()}}
 
 
+class c_stdout_to_stderr:
+    """librccl prints a version banner through C stdio on stdout; the contract is ONE JSON line there.  File descriptor 1 points
+    at stderr while the communicator is set up, and C stdio is flushed before it is restored."""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self._libc = ctypes.CDLL(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def spawn_ranks(n, argv):
     """--gpus N without a launcher: start the N ranks ourselves, one process per GPU."""
     import socket
@@ -228,7 +247,9 @@ def main():
     if world > 1 or os.environ.get("POCR_FORCE_DIST") == "1":
         collective = "rccl (pocr_allgather_labels, C ABI)"
         if world == 1:
-            transport = sharding.init_rccl_from_env(eng, rank, world)
+            with c_stdout_to_stderr():
+                transport = sharding.init_rccl_from_env(eng, rank, world)
+                transport.barrier()                   # (the banner comes with the first collective)
         else:
             # N ranks: RCCL through the C ABI is the product's exchange.  The bench must still print its line if that
             # cannot be set up on the box it lands on, so the ranks first agree (over a gloo group used for nothing else)
@@ -243,8 +264,15 @@ def main():
                 except BaseException as exc:          # noqa: BLE001
                     box["err"] = f"{type(exc).__name__}: {exc}"
             th = threading.Thread(target=_init, daemon=True)
-            th.start()
-            th.join(timeout=float(os.environ.get("POCR_RCCL_INIT_TIMEOUT", "180")))
+            with c_stdout_to_stderr():
+                th.start()
+                th.join(timeout=float(os.environ.get("POCR_RCCL_INIT_TIMEOUT", "180")))
+                if "t" in box:
+                    try:
+                        box["t"].barrier()            # (the banner comes with the first collective)
+                    except BaseException as exc:      # noqa: BLE001
+                        box["err"] = f"{type(exc).__name__}: {exc}"
+                        del box["t"]
             import torch.distributed as dist           # only now: PyTorch brings its own librccl / HSA runtime into the process
             dist.init_process_group("gloo", rank=rank, world_size=world)
             import torch
