@@ -273,11 +273,12 @@ def main():
                     except BaseException as exc:      # noqa: BLE001
                         box["err"] = f"{type(exc).__name__}: {exc}"
                         del box["t"]
-            import torch.distributed as dist           # only now: PyTorch brings its own librccl / HSA runtime into the process
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            import torch
-            ok = torch.tensor([1 if "t" in box else 0], dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            with c_stdout_to_stderr():                 # (gloo announces its peers on stdout)
+                import torch.distributed as dist       # only now: PyTorch brings its own librccl / HSA runtime into the process
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                import torch
+                ok = torch.tensor([1 if "t" in box else 0], dtype=torch.int32)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:
                 transport = box["t"]
             else:
