@@ -97,7 +97,6 @@ template <int TH, int MW, int NS, int WM, int POOLH, int POOLW, int ACT, bool BN
           int KH = 3, int KW = 3, int PADH = 1, int PADW = 1, bool UPCAT = false>
 __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     constexpr int NWAVE = 4, WN = NWAVE / WM, KC = 32, NTAP = KH * KW;
-    static_assert(!BDIR || NTAP == 9, "the register-rotated weight sets assume 9 taps");
     static_assert(MW % WM == 0, "column strips must divide among the M waves");
     constexpr int TW = 16 * MW, MWW = MW / WM, MS = TH * MWW, NT = NS * WN * 16, NTHR = 256;
     constexpr int HH = TH + KH - 1, HW = TW + KW - 1, NP = HH * HW, NPPAD = (NP + 15) / 16 * 16;
@@ -218,8 +217,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     };
     if constexpr (BDIR) {
     const u32x4 *wq = reinterpret_cast<const u32x4 *>(wt4) + (wn * NS) * 192 + lane;
-    // three register sets of weight fragments, rotated with the tap (9 taps = 3 x 3, so the rotation is static): the set
-    // of step s + 2 is requested while step s computes - two steps (~2000 cycles) cover an L2 miss, one does not
+    // three register sets of weight fragments, rotated with the step (statically: 9 taps = 3 x 3; other tap counts unroll
+    // three chunks): the set of step s + 2 is requested while step s computes - two steps (~2000 cycles) cover an L2
+    // miss, one does not
     u32x4 bw[3][NS][3];
     auto ldW = [&](u32x4 (&dst)[NS][3], const u32x4 *tile) {
 #pragma unroll
@@ -227,77 +227,86 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) dst[n][p] = tile[n * 192 + p * 64];
     };
+    // step s = chunk * NTAP + tap uses set s % 3; the chunk loop is unrolled U-fold so that s % 3 is static
+    constexpr int U = NTAP % 3 == 0 ? 1 : 3;
+    auto wstep = [&](int s_) {                           // weights of global step s_ (clamped to the last step: re-read, never used)
+        const int sc = min(s_, nchunks * NTAP - 1);
+        return wq + (size_t)(sc % NTAP) * tap_stride + (size_t)(sc / NTAP) * chunk_stride;
+    };
     ldA(0);
-    ldW(bw[0], wq);
-    ldW(bw[1], wq + tap_stride);
+    ldW(bw[0], wstep(0));
+    ldW(bw[1], wstep(1));
     stA(0);
     __syncthreads();
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const bool next_chunk = chunk + 1 < nchunks;
-        const int abuf = chunk & 1;
-        // no conditionals around the prefetches (the last chunk re-reads itself): the compiler then counts the loads in
-        // flight exactly (s_waitcnt vmcnt(n)) instead of draining the queue wherever control flow merges
-        const int chunk_n = next_chunk ? chunk + 1 : chunk;
+    for (int c0 = 0; c0 < nchunks; c0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int chunk = c0 + u;
+            if (U > 1 && chunk >= nchunks) break;        // (uniform)
+            const bool next_chunk = chunk + 1 < nchunks;
+            const int abuf = chunk & 1;
+            // no conditionals around the prefetches (the last chunk re-reads itself): the compiler then counts the loads in
+            // flight exactly (s_waitcnt vmcnt(n)) instead of draining the queue wherever control flow merges
+            const int chunk_n = next_chunk ? chunk + 1 : chunk;
 #if !(POCR_BF16X3_DBG & 4)
-        ldA(chunk_n);
+            ldA(chunk_n);
 #endif
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+            for (int tap = 0; tap < NTAP; ++tap) {
+                const int sl = u * NTAP + tap;            // step within the unrolled body: static
 #if !(POCR_BF16X3_DBG & 2)
-            {
-                const int t2 = tap + 2 >= 9 ? tap + 2 - 9 : tap + 2;
-                ldW(bw[(tap + 2) % 3], wq + (size_t)t2 * tap_stride + (size_t)(tap + 2 >= 9 ? chunk_n : chunk) * chunk_stride);
-            }
+                ldW(bw[(sl + 2) % 3], wstep(chunk * NTAP + tap + 2));
 #endif
-            const int dy = tap / 3, dx = tap % 3;
+                const int dy = tap / KW, dx = tap % KW;
 #if POCR_BF16X3_DBG & 1
-            const u32x4 *Ab = ldsA + li + kq * NPPAD;
+                const u32x4 *Ab = ldsA + li + kq * NPPAD;
 #else
-            const u32x4 *Ab = ldsA + abuf * A_U + dy * HW + dx + li + kq * NPPAD + wm * MWW * 16;
+                const u32x4 *Ab = ldsA + abuf * A_U + dy * HW + dx + li + kq * NPPAD + wm * MWW * 16;
 #endif
-            u32x4 (&bc)[NS][3] = bw[tap % 3];
+                u32x4 (&bc)[NS][3] = bw[sl % 3];
 #pragma unroll
-            for (int m = 0; m < MS; ++m) {
-                const int o = (m / MWW) * HW + (m % MWW) * 16;
+                for (int m = 0; m < MS; ++m) {
+                    const int o = (m / MWW) * HW + (m % MWW) * 16;
 #if POCR_BF16X3_DBG & 1
-                const u32x4 ah = bc[0][0] ^ (unsigned)m, am = bc[0][1] ^ (unsigned)m, al = bc[0][2] ^ (unsigned)m;     // no LDS reads
-                (void)o; (void)Ab;
+                    const u32x4 ah = bc[0][0] ^ (unsigned)m, am = bc[0][1] ^ (unsigned)m, al = bc[0][2] ^ (unsigned)m;     // no LDS reads
+                    (void)o; (void)Ab;
 #else
-                const u32x4 ah = Ab[o], am = Ab[o + PS], al = Ab[o + 2 * PS];
+                    const u32x4 ah = Ab[o], am = Ab[o + PS], al = Ab[o + 2 * PS];
 #endif
 #pragma unroll
-                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(al, bc[n][0], acc2[m][n]);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(al, bc[n][0], acc2[m][n]);
 #pragma unroll
-                for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_BF16(ah, bc[n][0], acc[m][n]);
+                    for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_BF16(ah, bc[n][0], acc[m][n]);
 #pragma unroll
-                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bc[n][1], acc2[m][n]);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bc[n][1], acc2[m][n]);
 #pragma unroll
-                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bc[n][2], acc2[m][n]);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bc[n][2], acc2[m][n]);
 #pragma unroll
-                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bc[n][0], acc2[m][n]);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bc[n][0], acc2[m][n]);
 #pragma unroll
-                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bc[n][1], acc2[m][n]);
-            }
-#if POCR_BF16X3_SCHED
-            // issue order of one step, as a template for the scheduler: the A reads and the weight loads of the step after
-            // next spread between the MFMAs instead of bunched where the source puts them (mask 8 MFMA, 0x100 DS read, 0x20 VMEM read)
-            {
-                constexpr int G = MS * 3, MPG = NS * 2, NV = NS * 3;      // one A read per group of NS * 2 MFMAs; NV weight loads spread over the G groups
-#pragma unroll
-                for (int gq = 0; gq < G; ++gq) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if ((gq * NV) / G != ((gq + 1) * NV) / G) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bc[n][1], acc2[m][n]);
                 }
-            }
+#if POCR_BF16X3_SCHED
+                // issue order of one step, as a template for the scheduler: the A reads and the weight loads of the step after
+                // next spread between the MFMAs instead of bunched where the source puts them (mask 8 MFMA, 0x100 DS read, 0x20 VMEM read)
+                {
+                    constexpr int G = MS * 3, MPG = NS * 2, NV = NS * 3;      // one A read per group of NS * 2 MFMAs; NV weight loads spread over the G groups
+#pragma unroll
+                    for (int gq = 0; gq < G; ++gq) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if ((gq * NV) / G != ((gq + 1) * NV) / G) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
 #endif
 #if !(POCR_BF16X3_DBG & 4)
-            if (tap == 4) stA(abuf ^ 1);                // the other A buffer: its last readers passed the barrier of the previous chunk
+                if (tap == NTAP / 2) stA(abuf ^ 1);       // the other A buffer: its last readers passed the barrier of the previous chunk
+#endif
+            }
+#if !(POCR_BF16X3_DBG & 8)
+            __syncthreads();
 #endif
         }
-#if !(POCR_BF16X3_DBG & 8)
-        __syncthreads();
-#endif
     }
     } else {
     ldA(0);

@@ -148,9 +148,9 @@ POCR_CONV3(conv8_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true)   // 256->512
 POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true)    // 512->512 + BN
 // the aggregation conv (AH x 1, no padding) and the GEMM-mode layers (1 x 1: LSTM input projections, encoder linears) on the
 // same kernel: weights through LDS, 48 pixels x 256 channels / 128 rows x 128 columns per workgroup
-#define POCR_CONV3G(name, TH, MW, NS, WM, ACT, MINW, KH)                                                            \
+#define POCR_CONV3G(name, TH, MW, NS, WM, ACT, MINW, KH, BDIR)                                                      \
     int name(ConvArgs a, hipStream_t st) {                                                                         \
-        return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT, false, MINW, false, KH, 1, 0, 0>, TH,   \
+        return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT, false, MINW, BDIR, KH, 1, 0, 0>, TH,    \
                            16 * MW, NS * (4 / WM) * 16, 256, a, st);                                               \
     }
 // decoder convs of the layout network: virtual cat(up2(x), skip) input
@@ -161,12 +161,13 @@ POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true)    // 512->512
     }
 POCR_CONV3U(pn_up128_b3, 5, 1, 2, 1, 2, true)       // NT 128
 POCR_CONV3U(pn_up64_b3, 4, 4, 4, 4, 2, false)       // NT 64 (d1, d0: 64 output channels), waves split the pixels
-POCR_CONV3G(agg4_b3, 1, 3, 4, 1, ACT_LEAKY, 1, 4)
-POCR_CONV3G(agg5_b3, 1, 3, 4, 1, ACT_LEAKY, 1, 5)
-POCR_CONV3G(agg6_b3, 1, 3, 2, 1, ACT_LEAKY, 1, 6)
-POCR_CONV3G(agg8_b3, 1, 3, 2, 1, ACT_LEAKY, 1, 8)
-POCR_CONV3G(gemm128_b3, 1, 8, 4, 2, ACT_NONE, 2, 1)
-POCR_CONV3G(gemm128_relu_b3, 1, 8, 4, 2, ACT_RELU, 2, 1)
+POCR_CONV3G(agg4_b3, 1, 3, 4, 1, ACT_LEAKY, 1, 4, false)
+POCR_CONV3G(agg5_b3, 1, 3, 4, 1, ACT_LEAKY, 1, 5, false)
+POCR_CONV3G(agg6_b3, 1, 3, 2, 1, ACT_LEAKY, 1, 6, false)
+POCR_CONV3G(agg8_b3, 1, 3, 2, 1, ACT_LEAKY, 1, 8, false)
+POCR_CONV3G(gemm128_b3, 1, 8, 4, 2, ACT_NONE, 2, 1, false)
+POCR_CONV3G(gemm128_relu_b3, 1, 8, 4, 2, ACT_RELU, 2, 1, false)
+// (weights straight from L2 - BDIR - was measured slower for these: agg 1.04 vs 0.85 ms, c4 encoder 5.28 vs 5.11 ms)
 const int kConvNT3[9] = {64, 64, 128, 128, 128, 128, 128, 128, 128};
 // pixel-tile shape (TH, 16*MW) of conv1..conv9 and of the aggregation conv - the same numbers as in the tables above
 // (kConvTH3: the bf16x3 configurations, which tile conv5 / conv6 differently)
