@@ -16,7 +16,11 @@ def main(paths):
         cur = sqlite3.connect(path).cursor()
         q = ("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) "
              "from counters_collection group by kernel_name, counter_name")
-        for kern, ctr, total, ndisp in cur.execute(q):
+        rows = list(cur.execute(q))
+        lds_pass = any(ctr == "SQ_LDS_IDX_ACTIVE" for _k, ctr, _t, _n in rows)
+        for kern, ctr, total, ndisp in rows:
+            if lds_pass and ctr == "GRBM_GUI_ACTIVE":
+                ctr = "GRBM_GUI_ACTIVE_LDS"          # (the MFMA pass has its own GRBM_GUI_ACTIVE)
             out.setdefault(kern, {})[ctr] = total / max(1, ndisp)
             out[kern]["dispatches_" + ctr] = ndisp
     for kern, c in out.items():
@@ -27,6 +31,12 @@ def main(paths):
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs on the chip
             c["mfma_util"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+        if "SQ_LDS_IDX_ACTIVE" in c and "SQ_LDS_BANK_CONFLICT" in c:
+            # share of the LDS's busy cycles lost to bank conflicts, and (with GRBM_GUI_ACTIVE of the same pass) how busy the
+            # 256 LDS units were over the kernel
+            c["lds_bank_conflict_share"] = c["SQ_LDS_BANK_CONFLICT"] / max(1.0, c["SQ_LDS_IDX_ACTIVE"])
+            if "GRBM_GUI_ACTIVE_LDS" in c:
+                c["lds_util"] = c["SQ_LDS_IDX_ACTIVE"] / (256.0 * c["GRBM_GUI_ACTIVE_LDS"] / 8.0)
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
 
 
