@@ -60,6 +60,8 @@ struct DevBuf {
         size_t want = bytes + bytes / 8;
         HIP_TRY(hipMalloc(&p, want));
         cap = want;
+        static const bool poison = getenv("POCR_POISON") != nullptr;       // debugging aid: no kernel may depend on what fresh memory holds
+        if (poison) { HIP_TRY(hipMemset(p, 0xFF, want)); HIP_TRY(hipDeviceSynchronize()); }
         return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -139,9 +141,11 @@ const int kConvNT[9] = {64, 64, 128, 128, 128, 128, 128, 256, 256};
     }
 // measured per layer in profiles/r02_conv_bf16x3_bench.txt; BDIR = weights straight from L2 into registers (no LDS tile):
 // wins wherever each wave owns its channels (WM 1) and the accumulators leave room for three weight sets
-POCR_CONV3(conv2_b3,  4, 4, 4, 4, 2, 2, ACT_RELU, false, 2, false)   // 64->64 + pool 2x2: 4x64 px, NT 64, waves split M
-POCR_CONV3(conv3_b3,  4, 2, 2, 1, 1, 1, ACT_RELU, false, 1, true)    // 64->128: 4x32 px, NT 128
-POCR_CONV3(conv4_b3,  4, 2, 2, 1, 2, 2, ACT_RELU, false, 1, true)    // 128->128 + pool 2x2
+// the low-K layers (2-4 chunks of K) want SMALL tiles: two or three workgroups per CU cover each other's prologue / epilogue
+// (MFMA busy 44-52 % with one 4x64 / 4x32 workgroup per CU; -10 ... -16 % with these)
+POCR_CONV3(conv2_b3,  4, 2, 2, 2, 2, 2, ACT_RELU, false, 2, false)   // 64->64 + pool 2x2: 4x32 px, NT 64, waves 2 (pixels) x 2 (channels)
+POCR_CONV3(conv3_b3,  5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)    // 64->128: 5x16 px, NT 128
+POCR_CONV3(conv4_b3,  4, 1, 2, 1, 2, 2, ACT_RELU, false, 2, true)    // 128->128 + pool 2x2: 4x16 px
 POCR_CONV3(conv56_b3, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)    // ->256: 5x16 px, NT 128, two workgroups per CU
 POCR_CONV3(conv7_b3,  2, 2, 2, 1, 2, 1, ACT_RELU, false, 2, true)    // 256->256 + pool 2x1: 2x32 px (the pool needs an even tile height)
 POCR_CONV3(conv8_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true)   // 256->512: 5x16 px, NT 128, two workgroups per CU
@@ -172,9 +176,9 @@ const int kConvNT3[9] = {64, 64, 128, 128, 128, 128, 128, 128, 128};
 // pixel-tile shape (TH, 16*MW) of conv1..conv9 and of the aggregation conv - the same numbers as in the tables above
 // (kConvTH3: the bf16x3 configurations, which tile conv5 / conv6 differently)
 const int kConvTH[10] = {4, 4, 4, 4, 10, 10, 10, 5, 5, 1};
-const int kConvTH3[10] = {4, 4, 4, 4, 5, 5, 2, 5, 5, 1};
+const int kConvTH3[10] = {4, 4, 5, 4, 5, 5, 2, 5, 5, 1};
 const int kConvTW[10] = {32, 64, 32, 32, 16, 16, 16, 16, 16, 48};
-const int kConvTW3[10] = {32, 64, 32, 32, 16, 16, 32, 16, 16, 48};
+const int kConvTW3[10] = {32, 32, 16, 16, 16, 16, 32, 16, 16, 48};
 // input width level of each conv (0: W_pad, 1: W_pad/2, 2: (W_pad/2)/2) and of its output
 const int kConvLvlIn[10] = {0, 0, 1, 1, 2, 2, 2, 2, 2, 2};
 const int kConvLvlOut[10] = {0, 1, 1, 2, 2, 2, 2, 2, 2, 2};
@@ -581,6 +585,7 @@ int run_network(pocr_engine *e, Slot &s) {
     const int Hh = c.lstm_hidden, npad = round_up(n, 16);
     {   // (re)allocation of any buffer whose address is baked into the cached graphs flushes them
         const void *before[4] = {s.xproj.p, s.hbuf.p, s.cbuf.p, nullptr};
+        const size_t stride_before = s.h_stride;
         if (s.xproj.reserve((size_t)rows * 8 * Hh * sizeof(float))) return 1;
         if (2 * (size_t)2 * npad * Hh > 2 * s.h_stride || !s.hbuf.p) {
             const size_t cap_pad = (size_t)round_up(npad, 64);
@@ -588,7 +593,9 @@ int run_network(pocr_engine *e, Slot &s) {
             if (s.cbuf.reserve((size_t)2 * cap_pad * Hh * sizeof(float))) return 1;
             s.h_stride = (size_t)2 * cap_pad * Hh;
         }
-        bool moved = before[0] != s.xproj.p || before[1] != s.hbuf.p || before[2] != s.cbuf.p;
+        // (h_stride is baked into the captured launches too - as the ping-pong offset and the memset size - and can change
+        // while the over-allocated buffer stays where it is)
+        bool moved = before[0] != s.xproj.p || before[1] != s.hbuf.p || before[2] != s.cbuf.p || stride_before != s.h_stride;
         for (int l = 0; l < c.lstm_layers; ++l) {
             const void *yb = s.lstm_y[l].p;
             if (s.lstm_y[l].reserve((size_t)rows * 2 * Hh * sizeof(float))) return 1;

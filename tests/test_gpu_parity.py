@@ -559,7 +559,7 @@ def test_lstm_wide_step_kernel_matches_the_fixture(golden, tmp_path, monkeypatch
     dict(height=40, conv_out=48, lstm_hidden=48, lstm_layers=2),       # widths that are not multiples of 32: fp32-MFMA projections
     dict(height=40, conv_out=128, sa_heads=4, sa_ff=272, sa_layers=1, arch=netspec.ARCH_SA),   # encoder, feed-forward width not a multiple of 32
 ])
-def test_other_geometries_against_oracle(kw, tmp_path):
+def test_other_heights_and_widths_against_oracle(kw, tmp_path):
     """Line heights 32 / 48 / 64 (the other aggregation kernels), other widths of the recurrent and encoder layers (which decide
     whether a linear layer runs on the bf16x3 kernel in GEMM mode or on the fp32-MFMA one): engine vs the reference-pinned oracle."""
     from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR

@@ -50,6 +50,15 @@ VBF(b7_b, 10, 2, 2, 2, 2, 1, ACT_RELU, false, 1)     // 10x32 px, NT64?? (WN 2 x
 VBF(b7_c, 6, 1, 2, 1, 2, 1, ACT_RELU, false, 2)      // 6x16 px: 2 tiles cover 10 rows (+20 % rows)
 VBD(d7_c, 6, 1, 2, 1, 2, 1, ACT_RELU, false, 2)
 VBD(d7_d, 2, 2, 2, 1, 2, 1, ACT_RELU, false, 2)      // 2x32 px, NT128: MS 4
+VBF(b2_f, 4, 2, 2, 2, 2, 2, ACT_RELU, false, 2)      // 4x32 px, NT64, 2 x 2, MS 4: 2+ WG/CU
+VBD(d2_f, 4, 2, 2, 2, 2, 2, ACT_RELU, false, 2)
+VBF(b2_g, 4, 2, 2, 2, 2, 2, ACT_RELU, false, 3)
+VBD(d3_c, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2)      // conv3 on 5x16 tiles (the conv5/6 configuration)
+VBD(d3_d, 4, 1, 2, 1, 1, 1, ACT_RELU, false, 2)
+VBD(d3_e, 4, 1, 2, 1, 1, 1, ACT_RELU, false, 3)
+VBD(d4_c, 4, 1, 2, 1, 2, 2, ACT_RELU, false, 2)      // conv4 (pool 2x2) on 4x16 tiles
+VBD(d4_d, 4, 1, 2, 1, 2, 2, ACT_RELU, false, 3)
+VBD(d4_e, 2, 2, 2, 1, 2, 2, ACT_RELU, false, 2)      // 2x32
 VBD(d2_a, 4, 4, 4, 4, 2, 2, ACT_RELU, false, 2)
 VBD(d2_b, 4, 4, 1, 1, 2, 2, ACT_RELU, false, 2)
 VF32(f9, 5, 1, 4, 1, 1, ACT_LEAKY, true, PIPE_DEEP)
@@ -105,7 +114,8 @@ int main(int argc, char **argv) {
                             {"direct-B 10x16 NT128", d6_a, 128, true}, {"direct-B 10x16 NT128 2WG", d6_b, 128, true},
                             {"direct-B 5x16 NT128 2WG", d6_c, 128, true}, {"direct-B 5x16 NT256", d6_d, 256, true}};
     else if (layer == 3) vars = {{"fp32 MFMA (shipped conv3)", f3, 128, false}, {"bf16x3 4x32 NT128", b3_a, 128, true}, {"bf16x3 4x32 NT128 2WG", b3_b, 128, true}, {"bf16x3 4x64 NT128 2x2", b3_c, 128, true},
-                            {"direct-B 4x32 NT128", d3_a, 128, true}, {"direct-B 4x32 NT128 2WG", d3_b, 128, true}};
+                            {"direct-B 4x32 NT128", d3_a, 128, true}, {"direct-B 4x32 NT128 2WG", d3_b, 128, true},
+                            {"direct-B 5x16 NT128 2WG", d3_c, 128, true}, {"direct-B 4x16 NT128 2WG", d3_d, 128, true}, {"direct-B 4x16 NT128 3WG", d3_e, 128, true}};
     else if (layer == 5) vars = {{"fp32 MFMA (shipped conv5)", f5, 128, false}, {"bf16x3 10x16 NT128", b6_a, 128, true}, {"direct-B 10x16 NT128", d6_a, 128, true},
                             {"direct-B 10x16 NT128 2WG", d6_b, 128, true}, {"direct-B 5x16 NT128 2WG", d6_c, 128, true}};
     else if (layer == 7) vars = {{"fp32 MFMA (shipped conv7)", f7, 128, false}, {"bf16x3 10x16 NT128 pool 2x1", b7_a, 128, true},
@@ -116,12 +126,14 @@ int main(int argc, char **argv) {
                             {"direct-B 5x16 NT128 2WG", d8_a, 128, true}, {"direct-B 5x16 NT128 3WG", d8_b, 128, true}};
     else if (layer == 4) vars = {{"fp32 MFMA (shipped conv4)", f4, 128, false}, {"bf16x3 4x32 NT128 pool", b4_a, 128, true},
                             {"bf16x3 4x64 NT128 2x2 pool", b4_b, 128, true}, {"bf16x3 4x64 NT64 2x2 2WG", b4_c, 64, true},
-                            {"direct-B 4x32 NT128", d4_a, 128, true}, {"direct-B 4x32 NT128 2WG", d4_b, 128, true}};
+                            {"direct-B 4x32 NT128", d4_a, 128, true}, {"direct-B 4x32 NT128 2WG", d4_b, 128, true},
+                            {"direct-B 4x16 NT128 2WG", d4_c, 128, true}, {"direct-B 4x16 NT128 3WG", d4_d, 128, true}, {"direct-B 2x32 NT128 2WG", d4_e, 128, true}};
     else if (layer == 2) vars = {{"fp32 MFMA (shipped conv2)", f2, 64, false}, {"bf16x3 4x64 NT64 N-split", b2_a, 64, true},
                             {"bf16x3 4x64 NT64 M-split 2WG", b2_b, 64, true}, {"bf16x3 8x64 NT64 M-split", b2_c, 64, true},
                             {"direct-B 4x64 NT64 M-split 2WG", d2_a, 64, true}, {"direct-B 4x64 NT64 N-split 2WG", d2_b, 64, true},
                             {"bf16x3 8x32 NT64 2x2", b2_d, 64, true}, {"bf16x3 4x64 NT64 2x2", b2_e, 64, true},
-                            {"direct-B 8x32 NT64 2x2", d2_c, 64, true}, {"direct-B 4x64 NT64 2x2", d2_d, 64, true}};
+                            {"direct-B 8x32 NT64 2x2", d2_c, 64, true}, {"direct-B 4x64 NT64 2x2", d2_d, 64, true},
+                            {"bf16x3 4x32 NT64 2x2 2WG", b2_f, 64, true}, {"direct-B 4x32 NT64 2x2 2WG", d2_f, 64, true}, {"bf16x3 4x32 NT64 2x2 3WG", b2_g, 64, true}};
     else { printf("layer %d not covered\n", layer); return 1; }
     const size_t xin = (size_t)n * s.H * s.W * s.cin;
     const int Hout = s.H / s.ph, Wout = s.W / s.pw;
