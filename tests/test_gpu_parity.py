@@ -581,6 +581,25 @@ def test_other_heights_and_widths_against_oracle(kw, tmp_path):
     assert worst < LOGIT_TOL, worst
 
 
+def test_recurrence_graphs_follow_the_hidden_state_stride(golden, tmp_path):
+    """Regression: the cached hipGraphs of the recurrence bake the ping-pong offset of the hidden-state buffer.  576 lines, then
+    640 lines in ONE launch each (same graph key: same T, same power-of-two bucket of slices) grow that offset inside the
+    over-allocated buffer - the pointer stays, the stride does not.  The second launch must equal a fresh engine's."""
+    from pero_ocr_amd.ocr_engine import line_ocr_engine
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    g = golden("c1")
+    path = g.write_engine_json(tmp_path)
+    crops = synth.make_crops(91, [64] * 640, g.meta["height"])
+    eng = PytorchEngineLineOCR(path, Dev(), batch_size=8)
+    for n in (576, 640):
+        chunks = line_ocr_engine.plan_chunks([64] * n, eng.max_input_horizontal_pixels)
+        assert len(line_ocr_engine.plan_launches(chunks, line_ocr_engine.launch_target(eng))) == 1
+    eng.process_lines(crops[:576], no_logits=True)
+    got, _, _ = eng.process_lines(crops, no_logits=True)
+    fresh, _, _ = PytorchEngineLineOCR(path, Dev(), batch_size=8).process_lines(crops, no_logits=True)
+    assert got == fresh and len(set(got)) > 50
+
+
 def test_slot_reset_recovers_an_abandoned_launch(small):
     """A launch that is never collected (exception between launch and collect) must not wedge the engine."""
     spec, weights, eng, net = small
