@@ -60,8 +60,13 @@ struct DevBuf {
         size_t want = bytes + bytes / 8;
         HIP_TRY(hipMalloc(&p, want));
         cap = want;
-        static const bool poison = getenv("POCR_POISON") != nullptr;       // debugging aid: no kernel may depend on what fresh memory holds
-        if (poison) { HIP_TRY(hipMemset(p, 0xFF, want)); HIP_TRY(hipDeviceSynchronize()); }
+        // debugging aid: no kernel may depend on what fresh memory holds.  POCR_POISON=1, or "lo:hi" = only allocations of lo..hi bytes
+        static const char *poison = getenv("POCR_POISON");
+        if (poison) {
+            size_t lo = 0, hi = ~(size_t)0;
+            if (strchr(poison, ':')) { lo = strtoull(poison, nullptr, 10); hi = strtoull(strchr(poison, ':') + 1, nullptr, 10); }
+            if (bytes >= lo && bytes <= hi) { HIP_TRY(hipMemset(p, 0xFF, want)); HIP_TRY(hipDeviceSynchronize()); }
+        }
         return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
