@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2y; mkdir -p $O
+O=$R/gpurun_out/r2fin; mkdir -p $O
 timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; echo "rc $?" >> $O/pytest_gpu.txt
 timeout 500 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 timeout 600 python bench.py --workload c3 > $O/bench_c3.json 2> $O/bench_c3.err
