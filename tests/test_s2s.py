@@ -310,3 +310,27 @@ def test_gpu_s2s_other_geometries_against_oracle(kw, tmp_path):
     assert got_t == want_t and got_c == want_c
     worst = max([float(np.max(np.abs(a - b))) for a, b in zip(got_l, want_l) if a.size] or [0.0])
     assert worst < LOGIT_TOL, worst
+
+
+@pytest.mark.gpu
+def test_gpu_s2s_bench_configuration_against_oracle(tmp_path):
+    """The configuration tools/s2s_bench.py measures (E 512, 8 heads, 2 encoder / 3 decoder layers, 233 classes) at a boundary bias
+    where random weights run most lines into the 272-step limit: strings and logits of the HIP engine against the oracle over
+    the whole decoding loop."""
+    import torch
+    from pero_ocr_amd import synth
+    chars = synth.make_charset(231)
+    net = {"dim_model": 512, "dim_ff": 2048, "heads": 8, "encoder_layers": 2, "decoder_layers": 3, "conv_subsampling": [8, 4]}
+    path = os.path.join(str(tmp_path), "ocr.json")
+    with open(path, "w", encoding="utf8") as f:
+        json.dump({"line_px_height": 40, "line_vertical_scale": 1.0, "checkpoint": "absent", "characters": chars, "net_name": net,
+                   "max_line_width": 1024, "net": {"weight_seed": 20261002, "boundary_bias": 18.0}}, f)
+    eng = tengine.TransformerEngineLineOCR(path, torch.device("cuda:0"), batch_size=4)
+    crops = synth.make_crops(602, [512] * 4, 40)
+    got_t, got_l, _ = eng.process_lines(crops, sparse_logits=False)
+    spec = eng.net_spec
+    model = s2s_oracle.OracleS2S(spec, netspec.generate_weights(spec, 20261002, boundary_bias=18.0))
+    want_t, want_l, _c, _ = s2s_oracle.process_lines(model, crops, eng.characters, 40, 480 * 4, 1024)
+    assert got_t == want_t and max(len(t) for t in got_t) >= 272
+    worst = max(float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) for a, b in zip(got_l, want_l))
+    assert worst < LOGIT_TOL, worst
