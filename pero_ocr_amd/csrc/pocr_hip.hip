@@ -413,6 +413,10 @@ __global__ __launch_bounds__(256) void style_embed_kernel(float *feat, const flo
 }
 #pragma clang fp contract(fast)
 
+__global__ __launch_bounds__(256) void zero_fill_kernel(f32x4 *p, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
 int run_network(pocr_engine *e, Slot &s) {
     const pocr_config &c = e->cfg;
     hipStream_t st = s.stream;          // switches to s.seq_stream after the backbone
@@ -720,8 +724,9 @@ int run_network(pocr_engine *e, Slot &s) {
             hipGraphExec_t exec = nullptr;
             bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
-                (void)hipMemsetAsync(s.hbuf.p, 0, 2 * s.h_stride * sizeof(float), st);
-                (void)hipMemsetAsync(s.cbuf.p, 0, s.h_stride * sizeof(float), st);
+                // (kernel nodes, not memset nodes: the initial state must be zeroed by every replay on every HIP runtime)
+                hipLaunchKernelGGL(zero_fill_kernel, dim3(256), dim3(256), 0, st, s.hbuf.as<f32x4>(), 2 * s.h_stride / 4);
+                hipLaunchKernelGGL(zero_fill_kernel, dim3(256), dim3(256), 0, st, s.cbuf.as<f32x4>(), s.h_stride / 4);
                 for (int step = 0; step < T; ++step) launch_step(l, step, bucket, s.lstm_dims.as<int32_t>());
                 ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph != nullptr;
             }
