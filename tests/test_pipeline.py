@@ -57,3 +57,51 @@ def test_page_to_text(tmp_path, golden):
     assert [ln.transcription for ln in lines] == direct
     assert all(ln.logits.shape[1] == len(g.characters) and ln.logit_coords[0] == 8 for ln in lines)
     assert all(0 < ln.transcription_confidence <= 1 for ln in lines)
+
+
+def test_page_stream_with_layout_network_front(tmp_path, golden):
+    """PageStream end to end on the GPU: layout network (its maps are computed, the baselines come from the generator - the
+    post-processing is out of scope) + resident cropper on the helper thread, the recogniser on the lines of two pages per call.
+    Every page must carry what `process_lines` returns for the batch it was part of (= the oracle engine on those lines), in order."""
+    from oracle import engine_oracle, model_oracle
+    from pero_ocr_amd import parsenet_spec
+    from pero_ocr_amd.document_ocr.page_ocr import LineCropper, PageOCR
+    from pero_ocr_amd.document_ocr.page_stream import PageStream
+    from pero_ocr_amd.layout_engines import torch_parsenet
+    g = golden("c1")
+    pn_path = os.path.join(str(tmp_path), "pn.pocrp")
+    torch_parsenet.save_blob(pn_path, parsenet_spec.generate_weights(5))
+    parsenet = torch_parsenet.TorchParseNet(pn_path, Dev(), downsample=2, adaptive_downsample=False)
+    cropper = LineCropper({"LINE_HEIGHT": str(g.height), "INTERP": "0", "LINE_SCALE": "1.0"})
+    ocr = PageOCR({"OCR_JSON": g.write_engine_json(tmp_path)}, Dev())
+    rng = np.random.RandomState(18)
+    pages, boxes = [], {}
+    for k in range(5):
+        page = np.full((640, 1024, 3), 230, np.uint8)
+        widths = [int(w) for w in rng.randint(150, 800, size=5)]
+        rows = []
+        for i, (w, img) in enumerate(zip(widths, synth.make_crops(200 + k, widths))):
+            y0, x0 = 30 + i * 110, int(rng.randint(10, 1010 - w))
+            page[y0:y0 + 40, x0:x0 + w] = img
+            rows.append((x0, y0, w))
+        pages.append(page)
+        boxes[id(page)] = rows
+    seen_maps = []
+
+    def front(img):
+        maps, ds = parsenet.get_maps_with_optimal_resolution(img)
+        seen_maps.append(maps.shape)
+        return Layout([Line(i, [[x0, y0 + 30], [x0 + w // 3, y0 + 31], [x0 + 2 * w // 3, y0 + 29], [x0 + w, y0 + 30]], [30, 10])
+                       for i, (x0, y0, w) in enumerate(boxes[id(img)])])
+    out = list(PageStream(front, cropper, ocr, pages_per_batch=2).process(iter(pages)))
+    assert [id(img) for img, _ in out] == [id(p) for p in pages] and seen_maps == [(320, 512, 5)] * 5
+    net = model_oracle.OracleNet(g.spec(), g.weights())
+    for first in (0, 2, 4):                                      # batches of two pages (the last one alone)
+        layouts = [lay for _img, lay in out[first:first + 2]]
+        crops = [ln.crop for lay in layouts for ln in lay.lines]
+        want, _l, _c, _ = engine_oracle.process_lines(lambda b: model_oracle.forward_logits(net, b), crops, ocr.ocr_engine.characters,
+                                                      g.height, 480 * 8, sparse_logits=False)
+        assert [ln.transcription for lay in layouts for ln in lay.lines] == want
+    for img, lay in out:
+        for ln in lay.lines:
+            assert np.array_equal(ln.crop, crop_oracle.crop(img, ln.baseline, ln.heights, g.height, 1.0, 0))
