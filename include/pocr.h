@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define POCR_ABI_VERSION 9
-#define POCR_NUM_SLOTS 2
+#define POCR_NUM_SLOTS 4
 
 typedef struct pocr_engine pocr_engine;
 

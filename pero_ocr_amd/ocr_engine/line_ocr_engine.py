@@ -92,6 +92,16 @@ def launch_target(engine=None) -> int:
     return max(1, int(t))
 
 
+def pipeline_depth(engine=None) -> int:
+    """Launches in flight: the engine's `pipeline_depth` attribute, else POCR_PIPELINE_DEPTH, else 2; at most the slots the
+    native engine has."""
+    d = getattr(engine, "pipeline_depth", None)
+    if d is None:
+        d = int(os.environ.get("POCR_PIPELINE_DEPTH", 2))
+    slots = getattr(getattr(engine, "model", None), "num_slots", 2)
+    return max(1, min(int(d), int(slots)))
+
+
 def plan_launches(chunks: Sequence[Chunk], target: int = LAUNCH_WORK_TARGET) -> List[Launch]:
     """Greedy merge of consecutive chunks (plan order = descending width) up to `target` work."""
     out: List[Launch] = []
@@ -214,11 +224,15 @@ class BaseEngineLineOCR:
                 scatter(chunk.line_ids, *self._recognise_chunk(lines, chunk, want_logits=not no_logits))
             return transcriptions, logits_out, coords_out
 
-        # One-deep software pipeline over LAUNCHES (merged chunks): launch k+1 is enqueued on the other
-        # engine slot before launch k is collected, so its GPU work overlaps launch k's read-back and the
-        # host-side assembly.  (The reference runs chunk after chunk, line_ocr_engine.py:80-129; lines are
-        # independent given their padded width, so the results are the same.)
-        pending = None
+        # Software pipeline over LAUNCHES (merged chunks): launch k+1 is enqueued on another engine slot before launch k is
+        # collected, so its GPU work overlaps launch k's read-back and the host-side assembly.  (The reference runs chunk
+        # after chunk, line_ocr_engine.py:80-129; lines are independent given their padded width, so the results are the same.)
+        # `depth` launches in flight (one engine slot each): with long lines the recurrent layers of a launch are a chain of
+        # ~2 T dependent 12-us steps that leaves the GPU mostly idle - several chains side by side fill it (pages of 3-4 k px
+        # lines: 2 -> 4 launches in flight is +30 %); with short lines one chain already hides behind the next launch's convs.
+        from collections import deque
+        pending = deque()
+        depth = pipeline_depth(self)
         max_sparse_frames = getattr(self, "device_sparsify_max_frames", 0)
         try:
             for k, launch in enumerate(plan_launches(chunks, launch_target(self))):
@@ -232,12 +246,14 @@ class BaseEngineLineOCR:
                     if tight_crop_logits:
                         ws = [lines[i].shape[1] for i in launch.line_ids]
                         rows = ([min(pad // sub, f) for f in frames], [min((pad + w) // sub, f) for w, f in zip(ws, frames)])
-                handle = self._submit_launch(lines, launch, not no_logits, k % 2, rows)
-                if pending is not None:
-                    scatter(pending[0].line_ids, *self._collect_launch(pending[1]), on_device=pending[2])
-                pending = (launch, handle, launch_sparse)
-            if pending is not None:
-                scatter(pending[0].line_ids, *self._collect_launch(pending[1]), on_device=pending[2])
+                while len(pending) >= depth:             # slot k % depth is free again once launch k - depth has been collected
+                    old = pending.popleft()
+                    scatter(old[0].line_ids, *self._collect_launch(old[1]), on_device=old[2])
+                handle = self._submit_launch(lines, launch, not no_logits, k % depth, rows)
+                pending.append((launch, handle, launch_sparse))
+            while pending:
+                old = pending.popleft()
+                scatter(old[0].line_ids, *self._collect_launch(old[1]), on_device=old[2])
         except BaseException:
             reset = getattr(getattr(self, "model", None), "reset", None)
             if reset is not None:
