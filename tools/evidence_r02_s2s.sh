@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2w; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_s2s; mkdir -p $O
 timeout 600 python tools/s2s_bench.py 2048 512 4 3 20 > $O/s2s_bench.json 2> $O/s2s_bench.err
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_s2s -o s2s -- python $R/tools/s2s_bench.py 2048 512 4 3 20 > $O/s2s_under_rocprof.json 2> $O/prof_s2s.err
