@@ -67,6 +67,34 @@ def greedy_decode_ctc(scores_probs, chars, device_id: int = 0) -> List[str]:
     return labels_to_strings(labels, lens, chars)
 
 
+class _HostTensor:
+    """numpy array behind the three calls callers chain on a parameter: `.cpu().detach().numpy()`."""
+
+    def __init__(self, array):
+        self._a = np.array(array, dtype=np.float32)
+        self.shape = self._a.shape
+
+    def cpu(self):
+        return self
+
+    def detach(self):
+        return self
+
+    def numpy(self):
+        return self._a
+
+
+class _EmbeddingView:
+    """Stand-in for the TorchScript `Embedding` sub-module of an embed_id model: `original_name`, `weight`, `parameters()`."""
+    original_name = "Embedding"
+
+    def __init__(self, weight):
+        self.weight = _HostTensor(weight)
+
+    def parameters(self):
+        return iter([self.weight])
+
+
 class PytorchEngineLineOCR(BaseEngineLineOCR):
     def __init__(self, json_def, device, batch_size=8):
         super().__init__(json_def, device, batch_size=batch_size)
@@ -77,10 +105,23 @@ class PytorchEngineLineOCR(BaseEngineLineOCR):
         if self.embed_id == "mean":
             self.embed_id = self.get_mean_embed_id()
         if self.embed_id is not None:
-            self.model.set_embed_id(self.embed_id)          # every run_ocr call passes [embed_id] * N (:64-66)
+            self.embed_id = self.embed_id                   # (the setter hands the row to the device now that the model exists)
         elif self.net_spec.embed_num:
             raise ValueError("the model has an embeddings layer but the engine JSON carries no embed_id "
                              "(the reference's model call fails without the ids argument)")
+
+    # `embed_id` stays live-writable like in the reference, where run_ocr reads it on every call (:64-66) and
+    # user_scripts/select_embed_id.py:80 assigns it between process_lines calls
+    @property
+    def embed_id(self):
+        return self._embed_id
+
+    @embed_id.setter
+    def embed_id(self, value):
+        self._embed_id = value
+        model = getattr(self, "model", None)
+        if model is not None and value is not None and value != "mean":
+            model.set_embed_id(int(value))
 
     def get_mean_embed_id(self):
         if not self.net_spec.embed_num:
@@ -112,6 +153,12 @@ class PytorchEngineLineOCR(BaseEngineLineOCR):
             raise ValueError(f"model height {spec.height} != line_px_height {self.line_px_height}")
         self.net_spec = spec
         self.model = _native.NativeEngine(spec, netspec.pack_weights(spec, weights), _device_index(self.device))
+        # the one thing callers ask the model object itself: the embeddings table (user_scripts/select_embed_id.py:114-120
+        # walks `model.named_modules()` for the module called "embeddings_layer" and clusters its parameters)
+        modules = [("", self.model)]
+        if spec.embed_num:
+            modules.append(("embeddings_layer", _EmbeddingView(weights["embeddings_layer.weight"])))
+        self.model.named_modules = lambda: iter(modules)
 
     def run_ocr(self, batch_data) -> Tuple[List[str], np.ndarray]:
         """uint8 [n, H, W_pad, 3] -> (decoded strings, float32 logits [n, T, C])."""

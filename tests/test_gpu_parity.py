@@ -149,12 +149,14 @@ def test_embed_id_selects_the_style_row(golden, tmp_path):
     crops = g.crops()
     t_mean, l_mean, _ = eng.process_lines(crops, sparse_logits=False)
     assert t_mean == g.transcriptions
-    eng.model.set_embed_id(1)
+    found = [child for name, child in eng.model.named_modules() if name == "embeddings_layer" and child.original_name == "Embedding"]
+    assert len(found) == 1 and next(found[0].parameters()).cpu().detach().numpy().shape == (g.meta["embed_num"] + 1, 2 * eng.net_spec.conv_out)
+    eng.embed_id = 1                                           # live-writable, as user_scripts/select_embed_id.py:80 uses it
     t_one, l_one, _ = eng.process_lines(crops, sparse_logits=False)
     assert t_one == golden("embed").transcriptions            # same weights and crops, the fixture recorded with embed_id 1
     assert max(float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) for a, b in zip(l_mean, l_one)) > 0.5
     with pytest.raises(RuntimeError, match="outside the embeddings table"):
-        eng.model.set_embed_id(g.meta["embed_num"] + 1)
+        eng.embed_id = g.meta["embed_num"] + 1
     cfg = json.load(open(path, encoding="utf8"))
     del cfg["embed_id"]
     json.dump(cfg, open(path, "w", encoding="utf8"))

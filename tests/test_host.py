@@ -143,3 +143,13 @@ def test_export_weights_roundtrip_from_torch_state_dict(tmp_path):
     spec2, w2 = mod.state_to_weights(net.state_dict(), height=40)
     assert spec2 == spec
     assert all(np.array_equal(w[k], w2[k]) for k in w), [k for k in w if not np.array_equal(w[k], w2[k])]
+
+
+def test_embeddings_layer_is_reachable_like_in_the_reference():
+    """user_scripts/select_embed_id.py:114-120: `for name, child in engine.model.named_modules()` -> the module named
+    "embeddings_layer" with original_name "Embedding", `next(child.parameters()).cpu().detach().numpy()` = the table."""
+    from pero_ocr_amd.ocr_engine import pytorch_ocr_engine as pe
+    w = np.arange(24, dtype=np.float32).reshape(4, 6)
+    view = pe._EmbeddingView(w)
+    assert view.original_name == "Embedding" and view.weight.shape[0] - 1 == 3          # get_mean_embed_id's expression
+    assert np.array_equal(next(view.parameters()).cpu().detach().numpy(), w)
