@@ -587,7 +587,10 @@ def main():
             result["stage_ms"] = {k: round(v, 4) for k, v in ms.items()}
         result.update(extra)
         if world == 1 and not args.no_cpu_baseline and args.workload in ("c2", "c4"):
-            result["cpu_baseline"] = cpu_baseline(spec, weights, crops, wl["width"], wl["batch_size"])
+            try:
+                result["cpu_baseline"] = cpu_baseline(spec, weights, crops, wl["width"], wl["batch_size"])
+            except Exception as exc:          # noqa: BLE001 - the GPU line must not be lost to a host-side problem
+                result["cpu_baseline"] = {"value": None, "unit": "lines/s", "cores": 0, "kind": "port", "sample": f"failed: {type(exc).__name__}: {exc}"}
         print(json.dumps(result), flush=True)
     if transport is not None:
         transport.barrier()
