@@ -36,9 +36,9 @@ int cropper_join(pocr_cropper *c) {
 
 int pin_reserve(void **p, size_t *cap, size_t bytes) {
     if (bytes <= *cap) return 0;
-    if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
+    if (*p) { (void)locked_host_free(*p); *p = nullptr; *cap = 0; }
     const size_t want = bytes + bytes / 8;
-    HIP_TRY(hipHostMalloc(p, want, hipHostMallocDefault));
+    HIP_TRY(locked_host_malloc(p, want, hipHostMallocDefault));
     *cap = want;
     return 0;
 }
@@ -70,9 +70,9 @@ void pocr_cropper_destroy(pocr_cropper *c) {
     if (!c) return;
     if (c->uploader.joinable()) c->uploader.join();
     (void)hipSetDevice(c->device);
-    (void)hipDeviceSynchronize();
+    (void)locked_device_sync();
     for (DevBuf *b : {&c->page, &c->specs, &c->knots, &c->coefs, &c->state, &c->curves, &c->out, &c->grid}) b->release();
-    for (void *p : {c->pin_page, c->pin_out, c->pin_small}) if (p) (void)hipHostFree(p);
+    for (void *p : {c->pin_page, c->pin_out, c->pin_small}) if (p) (void)locked_host_free(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -206,7 +206,7 @@ int pocr_cropper_read_curves(pocr_cropper *c, double *out, int64_t cap) {
     for (int i = 0; i < c->n; ++i) if (!c->hstate[i].status || c->hstate[i].curve_off + 4 * (int64_t)c->hstate[i].width > total)
         total = std::max<int64_t>(total, c->hstate[i].curve_off + 4 * (int64_t)c->hstate[i].width);
     if (total > cap) return fail("curve buffer holds %lld doubles, caller offers %lld", (long long)total, (long long)cap);
-    if (total > 0) HIP_TRY(hipMemcpy(out, c->curves.p, (size_t)total * 8, hipMemcpyDeviceToHost));
+    if (total > 0) HIP_TRY(locked_memcpy(out, c->curves.p, (size_t)total * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

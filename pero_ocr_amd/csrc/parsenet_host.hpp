@@ -54,15 +54,15 @@ size_t pocr_parsenet_num_weight_floats(void) { return pn_num_floats(); }
 void pocr_parsenet_destroy(pocr_parsenet *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    (void)hipDeviceSynchronize();
+    (void)locked_device_sync();
     for (auto &l : p->enc) { l.w.release(); l.b.release(); }
     for (auto &l : p->dec) { l.w.release(); l.b.release(); }
     for (DevBuf *b : {&p->head_w, &p->head_b, &p->lut, &p->lines, &p->tiles, &p->wline, &p->ooff, &p->page, &p->small, &p->out}) b->release();
     for (auto &b : p->x) b.release();
     for (auto &b : p->p) b.release();
     for (auto &b : p->y) b.release();
-    if (p->pin_in) (void)hipHostFree(p->pin_in);
-    if (p->pin_out) (void)hipHostFree(p->pin_out);
+    if (p->pin_in) (void)locked_host_free(p->pin_in);
+    if (p->pin_out) (void)locked_host_free(p->pin_out);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -161,9 +161,9 @@ int pocr_parsenet_get_maps(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, 
     // ---- upload (+ area down-sampling on the device)
     const size_t in_bytes = (size_t)H * W * 3;
     if (in_bytes > p->pin_in_cap) {
-        if (p->pin_in) (void)hipHostFree(p->pin_in);
+        if (p->pin_in) (void)locked_host_free(p->pin_in);
         p->pin_in = nullptr; p->pin_in_cap = 0;
-        HIP_TRY(hipHostMalloc(&p->pin_in, in_bytes, hipHostMallocDefault));
+        HIP_TRY(locked_host_malloc(&p->pin_in, in_bytes, hipHostMallocDefault));
         p->pin_in_cap = in_bytes;
     }
     memcpy(p->pin_in, img_hwc, in_bytes);
@@ -251,9 +251,9 @@ int pocr_parsenet_get_maps(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(p->ev1, st));
     if (out_bytes > p->pin_out_cap) {
-        if (p->pin_out) (void)hipHostFree(p->pin_out);
+        if (p->pin_out) (void)locked_host_free(p->pin_out);
         p->pin_out = nullptr; p->pin_out_cap = 0;
-        HIP_TRY(hipHostMalloc(&p->pin_out, out_bytes, hipHostMallocDefault));
+        HIP_TRY(locked_host_malloc(&p->pin_out, out_bytes, hipHostMallocDefault));
         p->pin_out_cap = out_bytes;
     }
     HIP_TRY(hipMemcpyAsync(p->pin_out, p->out.p, out_bytes, hipMemcpyDeviceToHost, st));

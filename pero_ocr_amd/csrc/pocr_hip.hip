@@ -8,6 +8,7 @@
 #include <cstring>
 #include <algorithm>
 #include <functional>
+#include <mutex>
 #include <unordered_set>
 #include <map>
 #include <tuple>
@@ -51,11 +52,24 @@ int fail(const char *fmt, ...) {
             return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+// Calls that are "unsafe" while another thread of the process captures a stream into a hipGraph (allocation, free, the
+// synchronising copies and device-wide synchronisation) and the capture itself exclude each other: a page stream runs the
+// layout network and the cropper on a helper thread while the recogniser's thread may be capturing its recurrence
+// (hipStreamCaptureModeThreadLocal permits that on paper; a rarely failing multi-threaded test said otherwise).
+std::recursive_mutex g_unsafe_mu;
+struct UnsafeLock { std::lock_guard<std::recursive_mutex> g{g_unsafe_mu}; };
+inline hipError_t locked_host_malloc(void **p, size_t n, unsigned flags) { UnsafeLock l; return hipHostMalloc(p, n, flags); }
+inline hipError_t locked_host_free(void *p) { UnsafeLock l; return hipHostFree(p); }
+inline hipError_t locked_device_sync() { UnsafeLock l; return hipDeviceSynchronize(); }
+inline hipError_t locked_memcpy(void *d, const void *s_, size_t n, hipMemcpyKind k) { UnsafeLock l; return hipMemcpy(d, s_, n, k); }
+inline hipError_t locked_memcpy2d(void *d, size_t dp, const void *s_, size_t sp, size_t w, size_t h, hipMemcpyKind k) { UnsafeLock l; return hipMemcpy2D(d, dp, s_, sp, w, h, k); }
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap) return 0;
+        UnsafeLock lock;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8;
         HIP_TRY(hipMalloc(&p, want));
@@ -65,11 +79,11 @@ struct DevBuf {
         if (poison) {
             size_t lo = 0, hi = ~(size_t)0;
             if (strchr(poison, ':')) { lo = strtoull(poison, nullptr, 10); hi = strtoull(strchr(poison, ':') + 1, nullptr, 10); }
-            if (bytes >= lo && bytes <= hi) { HIP_TRY(hipMemset(p, 0xFF, want)); HIP_TRY(hipDeviceSynchronize()); }
+            if (bytes >= lo && bytes <= hi) { HIP_TRY(hipMemset(p, 0xFF, want)); HIP_TRY(locked_device_sync()); }
         }
         return 0;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { UnsafeLock lock; if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -542,7 +556,7 @@ int run_network(pocr_engine *e, Slot &s) {
                 if (k + 1 < E) pe[(size_t)t * E + k + 1] = cosf((float)t * div);
             }
         }
-        HIP_TRY(hipDeviceSynchronize());     // another slot may still be reading the old table
+        HIP_TRY(locked_device_sync());     // another slot may still be reading the old table
         if (upload(e->pe, pe, st)) return 1;
         e->pe_rows = rows_pe;
     }
@@ -617,7 +631,7 @@ int run_network(pocr_engine *e, Slot &s) {
         }
         if (!s.lstm_dims.p) {
             if (s.lstm_dims.reserve(16)) return 1;
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.lstm_dims_host), 16, hipHostMallocDefault));
+            HIP_TRY(locked_host_malloc(reinterpret_cast<void **>(&s.lstm_dims_host), 16, hipHostMallocDefault));
         }
     }
     auto launch_step = [&](int l, int step, int slices, const int32_t *dims) {
@@ -708,7 +722,7 @@ int run_network(pocr_engine *e, Slot &s) {
             if (pa.dbg) {       // POCR_LSTM_DBG=1: phase cycle counts of workgroup (0, 0, 0), wave 0 (blocks the stream)
                 unsigned long long h[16 + 128];
                 HIP_TRY(hipStreamSynchronize(st));
-                HIP_TRY(hipMemcpy(h, pa.dbg, sizeof(h), hipMemcpyDeviceToHost));
+                HIP_TRY(locked_memcpy(h, pa.dbg, sizeof(h), hipMemcpyDeviceToHost));
                 fprintf(stderr, "[lstm dbg] layer %d z %d: items %llu blocking %llu | cycles/item: wait %.0f barrier %.0f mfma %.0f cell %.0f publish %.0f store %.0f fetch %.0f | total %.0f | first miss: step %llu slice %llu flag %llu\n",
                         l, zs, h[0], h[1], (double)h[2] / h[0], (double)h[4] / h[0], (double)h[5] / h[0], (double)h[6] / h[0], (double)h[3] / h[0], (double)h[8] / h[0], (double)h[9] / h[0], (double)h[7] / h[0], h[4] >> 48, (h[4] >> 32) & 0xffff, h[4] & 0xffffffffull);
             }
@@ -722,6 +736,7 @@ int run_network(pocr_engine *e, Slot &s) {
         if (it == s.lstm_graphs.end() && e->use_graphs) {
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
+            UnsafeLock capture_lock;                     // (released at the end of this block, after instantiation)
             bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 // (kernel nodes, not memset nodes: the initial state must be zeroed by every replay on every HIP runtime)
@@ -792,14 +807,14 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
     const size_t lg_bytes = s.want_logits ? (size_t)rows * C * sizeof(float) : 0;
     const size_t need = 2 * nt_bytes + (size_t)round_up(n, 4) * sizeof(int32_t) + lg_bytes;
     if (need > s.pinned_cap) {
-        if (s.pinned) (void)hipHostFree(s.pinned);
+        if (s.pinned) (void)locked_host_free(s.pinned);
         s.pinned = nullptr; s.pinned_cap = 0;
-        HIP_TRY(hipHostMalloc(&s.pinned, need + need / 4, hipHostMallocDefault));
+        HIP_TRY(locked_host_malloc(&s.pinned, need + need / 4, hipHostMallocDefault));
         s.pinned_cap = need + need / 4;
     }
     char *pin = static_cast<char *>(s.pinned);
     if (s.lstm_err_off >= 0) {
-        if (!s.lstm_err_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.lstm_err_host), 16, hipHostMallocDefault));
+        if (!s.lstm_err_host) HIP_TRY(locked_host_malloc(reinterpret_cast<void **>(&s.lstm_err_host), 16, hipHostMallocDefault));
         HIP_TRY(hipMemcpyAsync(s.lstm_err_host, s.lstm_flags.as<uint32_t>() + s.lstm_err_off, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipMemcpyAsync(pin, s.labels.p, nt_bytes, hipMemcpyDeviceToHost, st));
@@ -839,9 +854,9 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
         const size_t trip_base = (conf_off + (size_t)n * sizeof(float) + 15) / 16 * 16;
         const size_t need_sp = trip_base + spec * 8;
         if (need_sp > s.sp_pinned_cap) {
-            if (s.sp_pinned) (void)hipHostFree(s.sp_pinned);
+            if (s.sp_pinned) (void)locked_host_free(s.sp_pinned);
             s.sp_pinned = nullptr; s.sp_pinned_cap = 0;
-            HIP_TRY(hipHostMalloc(&s.sp_pinned, need_sp + need_sp / 4, hipHostMallocDefault));
+            HIP_TRY(locked_host_malloc(&s.sp_pinned, need_sp + need_sp / 4, hipHostMallocDefault));
             s.sp_pinned_cap = need_sp + need_sp / 4;
         }
         char *sp = static_cast<char *>(s.sp_pinned);
@@ -930,7 +945,7 @@ int pocr_set_embed_id(pocr_engine *e, int32_t embed_id) {
     if (num <= 0) return fail("this model has no embeddings layer (embed_num 0) but an embed_id was given");
     if (embed_id < 0 || embed_id > num) return fail("embed_id %d outside the embeddings table (0..%d)", embed_id, num);
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());                       // launches in flight read the previous row
+    HIP_TRY(locked_device_sync());                       // launches in flight read the previous row
     std::vector<float> ss(2 * (size_t)E);
     const float *row = e->embed_table.data() + (size_t)embed_id * 2 * E;
     for (int k = 0; k < E; ++k) { ss[k] = 1.0f + row[k]; ss[E + k] = row[E + k]; }      // torch: (1.0 + emb[:, :E]) in float32
@@ -998,7 +1013,7 @@ static int compute_pad_constants(pocr_engine *e) {
     for (int l = 0; l < 9; ++l) {
         const int W = wl[kConvLvlOut[l]], C = kConvPlan[l].cout, Hl = s.act_h[l];
         if (e->cconst[l].reserve((size_t)Hl * C * sizeof(float))) return 1;
-        HIP_TRY(hipMemcpy2D(e->cconst[l].p, (size_t)C * sizeof(float), s.act[l].as<float>() + (size_t)(W / 2) * C,
+        HIP_TRY(locked_memcpy2d(e->cconst[l].p, (size_t)C * sizeof(float), s.act[l].as<float>() + (size_t)(W / 2) * C,
                             (size_t)W * C * sizeof(float), (size_t)C * sizeof(float), (size_t)Hl, hipMemcpyDeviceToDevice));
     }
     s.staged = false;
@@ -1089,7 +1104,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
             std::vector<float> bias(cout16 * 16, 0.f);
             for (int k = 0; k < L.cout; ++k) bias[k] = b[k];
             if (e->conv_w[i].reserve(wsp.size() * 2)) return bail(1);
-            if (hipMemcpy(e->conv_w[i].p, wsp.data(), wsp.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return bail(fail("weight upload failed"));
+            if (locked_memcpy(e->conv_w[i].p, wsp.data(), wsp.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return bail(fail("weight upload failed"));
             if (upload(e->conv_b[i], bias, st)) return bail(1);
             continue;
         }
@@ -1264,7 +1279,7 @@ static void comm_release(pocr_engine *e);
 void pocr_destroy(pocr_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    (void)hipDeviceSynchronize();
+    (void)locked_device_sync();
     if (e->comm.active()) comm_release(e);
     for (auto &b : e->conv_w) b.release();
     for (auto &b : e->cconst) b.release();
@@ -1285,23 +1300,23 @@ void pocr_destroy(pocr_engine *e) {
             for (auto &b : *v) b.release();
         for (DevBuf *b : {&s.s2s_x, &s.s2s_x1, &s.s2s_x2, &s.s2s_t, &s.s2s_ctx, &s.s2s_q, &s.s2s_ff, &s.s2s_logits, &s.s2s_tokens,
                           &s.s2s_state, &s.s2s_tables}) b->release();
-        if (s.s2s_pinned) (void)hipHostFree(s.s2s_pinned);
-        if (s.s2s_flags) (void)hipHostFree(s.s2s_flags);
+        if (s.s2s_pinned) (void)locked_host_free(s.s2s_pinned);
+        if (s.s2s_flags) (void)locked_host_free(s.s2s_flags);
         for (auto &ev : s.s2s_ev)
             if (ev) (void)hipEventDestroy(ev);
         for (DevBuf *b : {&s.crops, &s.lines, &s.feat, &s.xproj, &s.hbuf, &s.cbuf, &s.logits, &s.best, &s.labels, &s.lens,
                           &s.sa_x, &s.sa_x1, &s.sa_qkv, &s.sa_att, &s.sa_tmp, &s.sa_ff, &s.sp_rowstat, &s.sp_colcount,
                           &s.sp_line_nnz, &s.sp_line_off, &s.sp_indptr, &s.sp_data, &s.sp_indices, &s.sp_rows, &s.sp_conf, &s.geom, &s.seqgeom})
             b->release();
-        if (s.pinned) (void)hipHostFree(s.pinned);
-        if (s.sp_pinned) (void)hipHostFree(s.sp_pinned);
+        if (s.pinned) (void)locked_host_free(s.pinned);
+        if (s.sp_pinned) (void)locked_host_free(s.sp_pinned);
         for (auto &kv : s.lstm_graphs) (void)hipGraphExecDestroy(kv.second);
         s.lstm_graphs.clear();
         s.lstm_dims.release();
         s.lstm_flags.release();
-        if (s.lstm_dims_host) (void)hipHostFree(s.lstm_dims_host);
-        if (s.lstm_err_host) (void)hipHostFree(s.lstm_err_host);
-        if (s.host_in) (void)hipHostFree(s.host_in);
+        if (s.lstm_dims_host) (void)locked_host_free(s.lstm_dims_host);
+        if (s.lstm_err_host) (void)locked_host_free(s.lstm_err_host);
+        if (s.host_in) (void)locked_host_free(s.host_in);
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);
         if (s.conv_done) (void)hipEventDestroy(s.conv_done);
@@ -1491,9 +1506,9 @@ static int stage_ragged_impl(pocr_engine *e, int32_t slot, const uint8_t *crops,
     const size_t desc_bytes = (size_t)round_up(n, 4) * sizeof(LineDesc);
     const size_t need = desc_bytes + total;
     if (need > s.host_in_cap) {
-        if (s.host_in) (void)hipHostFree(s.host_in);
+        if (s.host_in) (void)locked_host_free(s.host_in);
         s.host_in = nullptr; s.host_in_cap = 0;
-        HIP_TRY(hipHostMalloc(&s.host_in, need + need / 4, hipHostMallocDefault));
+        HIP_TRY(locked_host_malloc(&s.host_in, need + need / 4, hipHostMallocDefault));
         s.host_in_cap = need + need / 4;
     }
     LineDesc *desc = static_cast<LineDesc *>(s.host_in);
@@ -1697,8 +1712,8 @@ static void comm_release(pocr_engine *e) {
     if (c.comm) (void)rccl().CommDestroy(c.comm);
     if (c.d_send) (void)hipFree(c.d_send);
     if (c.d_recv) (void)hipFree(c.d_recv);
-    if (c.h_send) (void)hipHostFree(c.h_send);
-    if (c.h_recv) (void)hipHostFree(c.h_recv);
+    if (c.h_send) (void)locked_host_free(c.h_send);
+    if (c.h_recv) (void)locked_host_free(c.h_recv);
     if (c.stream) (void)hipStreamDestroy(c.stream);
     c = Comm{};
 }
@@ -1717,20 +1732,20 @@ static int comm_reserve(pocr_engine *e, size_t send_bytes) {
     const size_t recv_bytes = send_bytes * (size_t)c.world;
     if (send_bytes > c.send_cap) {
         if (c.d_send) (void)hipFree(c.d_send);
-        if (c.h_send) (void)hipHostFree(c.h_send);
+        if (c.h_send) (void)locked_host_free(c.h_send);
         c.d_send = c.h_send = nullptr; c.send_cap = 0;
         const size_t want = send_bytes + send_bytes / 4 + 256;
         HIP_TRY(hipMalloc(&c.d_send, want));
-        HIP_TRY(hipHostMalloc(&c.h_send, want, hipHostMallocDefault));
+        HIP_TRY(locked_host_malloc(&c.h_send, want, hipHostMallocDefault));
         c.send_cap = want;
     }
     if (recv_bytes > c.recv_cap) {
         if (c.d_recv) (void)hipFree(c.d_recv);
-        if (c.h_recv) (void)hipHostFree(c.h_recv);
+        if (c.h_recv) (void)locked_host_free(c.h_recv);
         c.d_recv = c.h_recv = nullptr; c.recv_cap = 0;
         const size_t want = recv_bytes + recv_bytes / 4 + 256;
         HIP_TRY(hipMalloc(&c.d_recv, want));
-        HIP_TRY(hipHostMalloc(&c.h_recv, want, hipHostMallocDefault));
+        HIP_TRY(locked_host_malloc(&c.h_recv, want, hipHostMallocDefault));
         c.recv_cap = want;
     }
     return 0;
@@ -1773,7 +1788,7 @@ int pocr_comm_allreduce_max(pocr_engine *e, double *value) {
 int pocr_device_synchronize(pocr_engine *e) {
     if (!e) return fail("engine is NULL");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(locked_device_sync());
     return 0;
 }
 
@@ -1857,9 +1872,9 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
     constexpr int BLK = 8, MAXBLK = (DEC_MAX_KEYS + BLK) / BLK + 2;
     const size_t flags_need = ((size_t)MAXBLK + nb) * sizeof(int32_t);
     if (flags_need > s.s2s_flags_cap) {
-        if (s.s2s_flags) (void)hipHostFree(s.s2s_flags);
+        if (s.s2s_flags) (void)locked_host_free(s.s2s_flags);
         s.s2s_flags = nullptr; s.s2s_flags_cap = 0;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.s2s_flags), 2 * flags_need, hipHostMallocDefault));
+        HIP_TRY(locked_host_malloc(reinterpret_cast<void **>(&s.s2s_flags), 2 * flags_need, hipHostMallocDefault));
         s.s2s_flags_cap = 2 * flags_need;
     }
     HIP_TRY(hipMemsetAsync(s.s2s_tokens.p, 0xFF, (size_t)n * S_cap * sizeof(int32_t), st));
@@ -1972,10 +1987,10 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
     const size_t tok_bytes = (size_t)n * S_cap * sizeof(int32_t);
     const size_t lg_bytes = want_logits ? (size_t)n * smax * C * sizeof(float) : 0;
     if (tok_bytes + lg_bytes > s.s2s_pinned_cap) {
-        if (s.s2s_pinned) (void)hipHostFree(s.s2s_pinned);
+        if (s.s2s_pinned) (void)locked_host_free(s.s2s_pinned);
         s.s2s_pinned = nullptr; s.s2s_pinned_cap = 0;
         const size_t want = (tok_bytes + lg_bytes) * 5 / 4;
-        HIP_TRY(hipHostMalloc(&s.s2s_pinned, want, hipHostMallocDefault));
+        HIP_TRY(locked_host_malloc(&s.s2s_pinned, want, hipHostMallocDefault));
         s.s2s_pinned_cap = want;
     }
     char *pin = static_cast<char *>(s.s2s_pinned);
@@ -2027,9 +2042,9 @@ int pocr_s2s_sparse(pocr_engine *e, int32_t slot, const int32_t *row_end, float 
     const size_t off_bytes = (size_t)(n + 1) * sizeof(int64_t), ip_bytes = (size_t)n * (C + 1) * sizeof(int32_t);
     const size_t need_sp = off_bytes + ip_bytes + (size_t)n * sizeof(int32_t) + cap * 8;
     if (need_sp > s.sp_pinned_cap) {
-        if (s.sp_pinned) (void)hipHostFree(s.sp_pinned);
+        if (s.sp_pinned) (void)locked_host_free(s.sp_pinned);
         s.sp_pinned = nullptr; s.sp_pinned_cap = 0;
-        HIP_TRY(hipHostMalloc(&s.sp_pinned, need_sp + need_sp / 4, hipHostMallocDefault));
+        HIP_TRY(locked_host_malloc(&s.sp_pinned, need_sp + need_sp / 4, hipHostMallocDefault));
         s.sp_pinned_cap = need_sp + need_sp / 4;
     }
     char *sp = static_cast<char *>(s.sp_pinned);
@@ -2119,13 +2134,13 @@ int pocr_ctc_greedy(int device_id, const float *logits_ntc, int32_t n, int32_t T
              len.reserve((size_t)n * sizeof(int32_t));
     auto done = [&](int r) { lg.release(); best.release(); lab.release(); len.release(); return r; };
     if (rc) return done(1);
-    if (hipMemcpy(lg.p, logits_ntc, nt * C * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
+    if (locked_memcpy(lg.p, logits_ntc, nt * C * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
     hipLaunchKernelGGL(frame_argmax_kernel, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, 0, lg.as<float>(), best.as<int32_t>(), (int)nt, C);
     hipLaunchKernelGGL(ctc_collapse_kernel, dim3(n), dim3(64), 0, 0, best.as<int32_t>(), lab.as<int32_t>(), len.as<int32_t>(), T, C - 1, nullptr, nullptr, T);
-    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return done(fail("CTC kernels failed"));
-    if (frame_argmax_nt && hipMemcpy(frame_argmax_nt, best.p, nt * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
-    if (hipMemcpy(labels_nt, lab.p, nt * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
-    if (hipMemcpy(label_len_n, len.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    if (hipGetLastError() != hipSuccess || locked_device_sync() != hipSuccess) return done(fail("CTC kernels failed"));
+    if (frame_argmax_nt && locked_memcpy(frame_argmax_nt, best.p, nt * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    if (locked_memcpy(labels_nt, lab.p, nt * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    if (locked_memcpy(label_len_n, len.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
     return done(0);
 }
 
@@ -2146,21 +2161,21 @@ int pocr_sparsify(int device_id, const float *logits_ntc, int32_t n, int32_t T, 
              ip.reserve((size_t)n * (C + 1) * sizeof(int32_t)) || dd.reserve(cap * sizeof(float)) || di.reserve(cap * sizeof(int32_t));
     auto done = [&](int r) { for (DevBuf *b : {&lg, &rowstat, &colcount, &nnz, &off, &ip, &dd, &di}) b->release(); return r; };
     if (rc) return done(1);
-    if (hipMemcpy(lg.p, logits_ntc, cap * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
+    if (locked_memcpy(lg.p, logits_ntc, cap * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
     hipLaunchKernelGGL(sparse_count_kernel, dim3(n), dim3(256), 0, 0, lg.as<float>(), (const int32_t *)nullptr, (const int32_t *)nullptr,
                        rowstat.as<float>(), colcount.as<int32_t>(), nnz.as<int32_t>(), T, C, threshold, (const int32_t *)nullptr, (const int32_t *)nullptr);
     hipLaunchKernelGGL(sparse_scan_kernel, dim3(1), dim3(64), 0, 0, nnz.as<int32_t>(), off.as<int64_t>(), n);
     hipLaunchKernelGGL(sparse_fill_kernel, dim3(n), dim3(256), 0, 0, lg.as<float>(), (const int32_t *)nullptr, (const int32_t *)nullptr,
                        rowstat.as<float>(), colcount.as<int32_t>(), off.as<int64_t>(), ip.as<int32_t>(), dd.as<float>(), di.as<int32_t>(), T, C,
                        threshold, (int64_t)cap, (const int32_t *)nullptr, (const int32_t *)nullptr);
-    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return done(fail("sparsify kernels failed"));
-    if (hipMemcpy(line_off, off.p, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
-    if (hipMemcpy(indptr, ip.p, (size_t)n * (C + 1) * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    if (hipGetLastError() != hipSuccess || locked_device_sync() != hipSuccess) return done(fail("sparsify kernels failed"));
+    if (locked_memcpy(line_off, off.p, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    if (locked_memcpy(indptr, ip.p, (size_t)n * (C + 1) * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
     const int64_t total = line_off[n];
     if (total > capacity) return done(fail("%lld entries kept, caller's buffers hold %lld", (long long)total, (long long)capacity));
     if (total > 0) {
-        if (hipMemcpy(data, dd.p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
-        if (hipMemcpy(indices, di.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+        if (locked_memcpy(data, dd.p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+        if (locked_memcpy(indices, di.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
     }
     return done(0);
 }
@@ -2221,13 +2236,13 @@ int pocr_crop_lines(int device_id, const uint8_t *page_hwc, int32_t H, int32_t W
              dout.reserve((size_t)n_out);
     auto done = [&](int r) { dpage.release(); dcoord.release(); dtab.release(); dout.release(); return r; };
     if (rc) return done(1);
-    if (hipMemcpy(dpage.p, page_hwc, page_bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(dcoord.p, coords, (size_t)n_coord * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(dtab.p, tab.data(), (size_t)n * sizeof(CropLine), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
+    if (locked_memcpy(dpage.p, page_hwc, page_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        locked_memcpy(dcoord.p, coords, (size_t)n_coord * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        locked_memcpy(dtab.p, tab.data(), (size_t)n * sizeof(CropLine), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
     hipLaunchKernelGGL(remap_u8_kernel, dim3((line_height * w_max + 255) / 256, n), dim3(256), 0, 0, dpage.as<uint8_t>(), H, W, C,
                        dcoord.as<float>(), dtab.as<CropLine>(), line_height, dout.as<uint8_t>());
-    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return done(fail("remap kernel failed"));
-    if (hipMemcpy(crops, dout.p, (size_t)n_out, hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    if (hipGetLastError() != hipSuccess || locked_device_sync() != hipSuccess) return done(fail("remap kernel failed"));
+    if (locked_memcpy(crops, dout.p, (size_t)n_out, hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
     return done(0);
 }
 
@@ -2259,17 +2274,17 @@ int pocr_crop_curves(int device_id, const uint8_t *page_hwc, int32_t H, int32_t 
              (grid_out ? dgrid.reserve((size_t)n_grid * sizeof(float)) : 0);
     auto done = [&](int r) { for (DevBuf *b : {&dpage, &dcurve, &drows, &drot, &dtab, &dout, &dgrid}) b->release(); return r; };
     if (rc) return done(1);
-    if (hipMemcpy(dpage.p, page_hwc, page_bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(dcurve.p, curves, (size_t)n_curve * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(drows.p, rows, (size_t)n * line_height * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(drot.p, rot, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(dtab.p, tab.data(), (size_t)n * sizeof(CurveLine), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
+    if (locked_memcpy(dpage.p, page_hwc, page_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        locked_memcpy(dcurve.p, curves, (size_t)n_curve * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        locked_memcpy(drows.p, rows, (size_t)n * line_height * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        locked_memcpy(drot.p, rot, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        locked_memcpy(dtab.p, tab.data(), (size_t)n * sizeof(CurveLine), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
     hipLaunchKernelGGL(remap_curves_u8_kernel, dim3((line_height * w_max + 255) / 256, n), dim3(256), 0, 0, dpage.as<uint8_t>(), H, W, C,
                        dcurve.as<double>(), drows.as<double>(), drot.as<double>(), dtab.as<CurveLine>(), line_height, dout.as<uint8_t>(),
                        grid_out ? dgrid.as<float>() : (float *)nullptr);
-    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return done(fail("remap kernel failed"));
-    if (hipMemcpy(crops, dout.p, (size_t)n_out, hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
-    if (grid_out && hipMemcpy(grid_out, dgrid.p, (size_t)n_grid * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    if (hipGetLastError() != hipSuccess || locked_device_sync() != hipSuccess) return done(fail("remap kernel failed"));
+    if (locked_memcpy(crops, dout.p, (size_t)n_out, hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
+    if (grid_out && locked_memcpy(grid_out, dgrid.p, (size_t)n_grid * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
     return done(0);
 }
 

@@ -103,13 +103,18 @@ def pipeline_depth(engine=None) -> int:
 
 
 def plan_launches(chunks: Sequence[Chunk], target: int = LAUNCH_WORK_TARGET) -> List[Launch]:
-    """Greedy merge of consecutive chunks (plan order = descending width) up to `target` work."""
+    """Greedy merge of consecutive chunks (plan order = descending width) into ceil(total / target) launches of about equal
+    work: a job a little larger than `target` (one page of long lines) becomes two balanced launches whose recurrent and
+    convolutional phases overlap, not a full one and a remainder."""
+    works = [len(ch.line_ids) * ch.w_pad for ch in chunks]
+    total = sum(works)
+    n_launches = max(1, -(-total // max(1, target)))
+    budget = -(-total // n_launches)
     out: List[Launch] = []
     cur: List[Chunk] = []
     acc = 0
-    for ch in chunks:
-        w = len(ch.line_ids) * ch.w_pad
-        if cur and acc + w > target:
+    for ch, w in zip(chunks, works):
+        if cur and acc + w > budget and len(out) < n_launches - 1:
             out.append(Launch(cur))
             cur, acc = [], 0
         cur.append(ch)
