@@ -98,10 +98,22 @@ def test_page_stream_with_layout_network_front(tmp_path, golden):
     net = model_oracle.OracleNet(g.spec(), g.weights())
     for first in (0, 2, 4):                                      # batches of two pages (the last one alone)
         layouts = [lay for _img, lay in out[first:first + 2]]
-        crops = [ln.crop for lay in layouts for ln in lay.lines]
-        want, _l, _c, _ = engine_oracle.process_lines(lambda b: model_oracle.forward_logits(net, b), crops, ocr.ocr_engine.characters,
-                                                      g.height, 480 * 8, sparse_logits=False)
-        assert [ln.transcription for lay in layouts for ln in lay.lines] == want
+        lines = [ln for lay in layouts for ln in lay.lines]
+        crops = [ln.crop for ln in lines]
+        # exactly what the engine returns for that batch on its own (the GPU path is deterministic) ...
+        direct_t, direct_l, _ = ocr.ocr_engine.process_lines(crops, sparse_logits=False)
+        assert [ln.transcription for ln in lines] == direct_t
+        # ... and the oracle on those lines: logits within the tolerance, arg-max equal wherever the oracle's own top-2 margin
+        # is not a near tie (these crops are not margin-selected like the fixtures', and the CPU oracle's last bits depend on
+        # how oneDNN splits its work over the threads it gets)
+        _t, want_l, _c, _ = engine_oracle.process_lines(lambda b: model_oracle.forward_logits(net, b), crops, ocr.ocr_engine.characters,
+                                                        g.height, 480 * 8, sparse_logits=False)
+        for got, want in zip(direct_l, want_l):
+            got, want = np.asarray(got), np.asarray(want)
+            assert float(np.max(np.abs(got - want))) < 1e-3
+            srt = np.sort(want, axis=1)
+            clear = (srt[:, -1] - srt[:, -2]) > 2e-3
+            assert np.array_equal(np.argmax(got, axis=1)[clear], np.argmax(want, axis=1)[clear])
     for img, lay in out:
         for ln in lay.lines:
             assert np.array_equal(ln.crop, crop_oracle.crop(img, ln.baseline, ln.heights, g.height, 1.0, 0))
