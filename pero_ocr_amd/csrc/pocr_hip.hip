@@ -55,7 +55,8 @@ int fail(const char *fmt, ...) {
 // Calls that are "unsafe" while another thread of the process captures a stream into a hipGraph (allocation, free, the
 // synchronising copies and device-wide synchronisation) and the capture itself exclude each other: a page stream runs the
 // layout network and the cropper on a helper thread while the recogniser's thread may be capturing its recurrence
-// (hipStreamCaptureModeThreadLocal permits that on paper; a rarely failing multi-threaded test said otherwise).
+// (hipStreamCaptureModeThreadLocal permits that on paper; the lock is cheap insurance - it costs nothing in the steady state,
+// where no buffer grows and every graph is cached).
 std::recursive_mutex g_unsafe_mu;
 struct UnsafeLock { std::lock_guard<std::recursive_mutex> g{g_unsafe_mu}; };
 inline hipError_t locked_host_malloc(void **p, size_t n, unsigned flags) { UnsafeLock l; return hipHostMalloc(p, n, flags); }
