@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define POCR_ABI_VERSION 9
+#define POCR_ABI_VERSION 10
 #define POCR_NUM_SLOTS 4
 
 typedef struct pocr_engine pocr_engine;
@@ -75,6 +75,11 @@ void pocr_destroy(pocr_engine *e);
 
 const char *pocr_last_error(void);
 int pocr_abi_version(void);
+/* Arithmetic of the convolution / GEMM kernels of this process (diagnostic; `bench.py` prices its roofline by it).  The
+ * reference computes them in float32 (`aten::conv2d` behind `model(x)`, pytorch_ocr_engine.py:66,69).  2 = fp32 operands
+ * as two f16 planes, three f16 MFMAs per 32-deep block (default); 3 = three bf16 planes, six MFMAs (POCR_CONV_SPLIT=3);
+ * 0 = fp32 MFMA (POCR_CONV_FP32=1).  All three accumulate in fp32 and stay within the fp32 reference's own rounding noise. */
+int pocr_conv_split(void);
 /* Number of visible HIP devices (0 when none / no driver). */
 int pocr_device_count(void);
 
@@ -166,6 +171,8 @@ int pocr_slot_reset(pocr_engine *e, int32_t slot);
  *                         count - all ranks derive it from the same chunk plan, so no size exchange is needed);
  *                         recv = int32 [world * count], rank r's block at r * count.  Blocking.
  *   pocr_comm_allreduce_max: in-place max over ranks of one double (also a barrier; bench.py's max-over-ranks time).
+ *   pocr_comm_info      : what the communicator itself reports - *count = ncclCommCount, *rank = ncclCommUserRank (both 0
+ *                         when the engine has no communicator).  A run that claims N ranks over RCCL prints this number.
  *   pocr_comm_destroy   : optional, pocr_destroy() does it too. */
 #define POCR_UNIQUE_ID_BYTES 128
 int pocr_comm_unique_id(uint8_t *id128);
@@ -173,6 +180,7 @@ int pocr_comm_init(pocr_engine *e, const uint8_t *id128, int32_t rank, int32_t w
 int pocr_comm_destroy(pocr_engine *e);
 int pocr_allgather_labels(pocr_engine *e, const int32_t *send, int64_t count, int32_t *recv);
 int pocr_comm_allreduce_max(pocr_engine *e, double *value);
+int pocr_comm_info(pocr_engine *e, int32_t *count, int32_t *rank);
 /* hipDeviceSynchronize() on the engine's device (fences of the measurement harness). */
 int pocr_device_synchronize(pocr_engine *e);
 

@@ -194,7 +194,13 @@ CONFIGS = {
     # and the per-line logit statistics are stored; no dense logits.
     "c3": dict(n_symbols=231, weight_seed=20260929, crop_seed=306, widths="make_widths(33, 2048)", batch_size=8,
                store_dense=False, calibrate=True, calib_width=512, weight_kwargs=dict(blank_bias=4.0), select_margin=2e-3,
-               modes=("dense",), sample_rows=2),
+               modes=("dense",), sample_rows=8, dense_stats=True),
+    # one UNFILTERED fixture (consecutive crop indices, no margin selection) next to the selected ones, so that
+    # arg-max behaviour near ties stays tested against the reference: compared with the margin-gated rule (a frame may
+    # differ only where the reference's own top-2 margin is below the logit noise; the count of such frames is bounded).
+    "c2u": dict(n_symbols=231, weight_seed=20260929, crop_seed=307, widths=[512] * 64, batch_size=274,
+                store_dense=False, calibrate=True, calib_width=512, weight_kwargs=dict(blank_bias=4.0),
+                modes=("dense",)),
     # style-embedding models (pytorch_ocr_engine.py:46-50, 64-66): the engine JSON carries embed_num / embed_id and the
     # reference calls model(batch, ids); one fixture with a numeric id, one with "mean" (= the last row of the table)
     "embed": dict(n_symbols=99, weight_seed=20260932, crop_seed=602, widths=[300, 120, 517, 64, 300, 800, 33, 256, 411, 96],

@@ -4,10 +4,12 @@ The reference computes in float32; on long lines its own rounding noise reaches 
 1530 of c3, class 63: reference vs float64 arithmetic 1.1e-3).  A 1e-3 logit bar against the reference alone would then
 test the reference's noise, not this build.  This script runs the restated network (oracle/model_oracle.py, pinned
 bit-exactly against the reference run by gen_golden.py) in FLOAT64 over the fixture's page stream, chunk by chunk as the
-reference batches it, and stores the sampled rows as `rows64_all` (float32-rounded).  Tests then require
+reference batches it, and stores the sampled rows as `rows64_delta16` = float16(reference row - float64 row): the
+difference is < 2e-3, so float16 keeps it to < 1e-6 and the fixture stays small (conftest.Golden.rows64 rebuilds the
+truth rows).  Tests then require
     |hip - truth| < 1e-3                      (this build against exact arithmetic)
     |hip - reference| < 1e-3 + |reference - truth|   (the reference's own deviation is not charged to the build)
-Usage: python oracle/gen_truth_rows.py [fixture]
+Usage: python oracle/gen_truth_rows.py [fixture ...]      (c2 c2u c3 c4)
 """
 import os
 import sys
@@ -34,7 +36,7 @@ def main(name):
             x = (torch.from_numpy(np.ascontiguousarray(batch)).double() / 255.0).permute(0, 3, 1, 2)
             nct = net(x).numpy()
         for j, i in enumerate(ids):
-            out[i] = nct[j].T[g.sample_rows[i]].astype(np.float32)
+            out[i] = nct[j].T[g.sample_rows[i]]
         if k % 20 == 0:
             print(f"chunk {k}/{len(g.plan)}", flush=True)
     rows64 = np.concatenate(out)
@@ -43,9 +45,11 @@ def main(name):
           (np.abs(ref - rows64).max(), int((np.abs(ref - rows64).max(axis=1) > 5e-4).sum()), ref.shape[0]))
     path = os.path.join(GOLDEN_DIR, f"{name}.npz")
     arrays = dict(np.load(path))
-    arrays["rows64_all"] = rows64
+    arrays.pop("rows64_all", None)
+    arrays["rows64_delta16"] = (ref.astype(np.float64) - rows64.astype(np.float64)).astype(np.float16)
     np.savez_compressed(path, **arrays)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "c3")
+    for nm in (sys.argv[1:] or ["c3"]):
+        main(nm)

@@ -91,6 +91,8 @@ class OracleNet(nn.Module):
         import math
         import torch.nn.functional as F
         sp, w = self.spec, self.sa
+        if f.dtype != torch.float32:                                  # oracle/gen_truth_rows.py runs the restatement in float64
+            w = {k: v.to(f.dtype) for k, v in w.items()}
         e, h = sp.conv_out, sp.sa_heads
         d = e // h
         x = f.permute(0, 2, 1)                                        # [N,T,E]; lines are independent
@@ -100,6 +102,7 @@ class OracleNet(nn.Module):
         pe = torch.zeros(t, e)
         pe[:, 0::2] = torch.sin(position * div_term)
         pe[:, 1::2] = torch.cos(position * div_term)
+        pe = pe.to(f.dtype)                                           # the table itself is a float32 constant of the model
         x = F.layer_norm(x, (e,), w["sa.norm.weight"], w["sa.norm.bias"], LN_EPS) + pe
         outs = [x]
         for l in range(sp.sa_layers):

@@ -14,7 +14,7 @@ import numpy as np
 from .netspec import NetSpec
 
 LIB_NAME = "libpocr_hip.so"
-ABI_VERSION = 9
+ABI_VERSION = 10
 UNIQUE_ID_BYTES = 128
 STAGE_NAMES = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv8", "conv9",
                "agg", "lstm", "head", "ctc", "total")
@@ -58,6 +58,7 @@ SYMBOLS = {
     "pocr_destroy": (None, [C.c_void_p]),
     "pocr_last_error": (C.c_char_p, []),
     "pocr_abi_version": (C.c_int, []),
+    "pocr_conv_split": (C.c_int, []),
     "pocr_set_embed_id": (C.c_int, [C.c_void_p, C.c_int32]),
     "pocr_device_count": (C.c_int, []),
     "pocr_run_batch": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, _f32p, _i32p, _i32p, _i32p]),
@@ -101,6 +102,7 @@ SYMBOLS = {
     "pocr_comm_destroy": (C.c_int, [C.c_void_p]),
     "pocr_allgather_labels": (C.c_int, [C.c_void_p, _i32p, C.c_int64, _i32p]),
     "pocr_comm_allreduce_max": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "pocr_comm_info": (C.c_int, [C.c_void_p, _i32p, _i32p]),
     "pocr_device_synchronize": (C.c_int, [C.c_void_p]),
     "pocr_parsenet_num_weight_floats": (C.c_size_t, []),
     "pocr_parsenet_create": (C.c_int, [_f32p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
@@ -397,6 +399,13 @@ class NativeEngine:
         if self._lib.pocr_comm_allreduce_max(self._h, C.byref(v)):
             raise RuntimeError("pocr_comm_allreduce_max: " + self._err())
         return float(v.value)
+
+    def comm_info(self):
+        """(ranks, this rank) as the RCCL communicator itself reports them (ncclCommCount / ncclCommUserRank); (0, 0) without one."""
+        cnt, rk = C.c_int32(0), C.c_int32(0)
+        if self._lib.pocr_comm_info(self._h, C.byref(cnt), C.byref(rk)):
+            raise RuntimeError("pocr_comm_info: " + self._err())
+        return int(cnt.value), int(rk.value)
 
     def device_synchronize(self):
         if self._lib.pocr_device_synchronize(self._h):
@@ -697,3 +706,8 @@ def comm_unique_id() -> bytes:
 
 def device_count() -> int:
     return int(load().pocr_device_count())
+
+
+def conv_split() -> int:
+    """Arithmetic of the conv / GEMM kernels of this process: 2 = f16x2 (default), 3 = bf16x3, 0 = fp32 MFMA."""
+    return int(load().pocr_conv_split())

@@ -28,6 +28,8 @@ struct RcclApi {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     std::string err;
 
     // 0 on success.  POCR_RCCL_LIB overrides the library name.  The ROCm installation this library was built against comes
@@ -52,6 +54,8 @@ struct RcclApi {
         AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
         GetVersion = reinterpret_cast<decltype(GetVersion)>(sym("ncclGetVersion"));
+        CommCount = reinterpret_cast<decltype(CommCount)>(sym("ncclCommCount"));
+        CommUserRank = reinterpret_cast<decltype(CommUserRank)>(sym("ncclCommUserRank"));
         if (!ok) { dlclose(lib); lib = nullptr; return 1; }
         return 0;
     }

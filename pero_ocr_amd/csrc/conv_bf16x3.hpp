@@ -75,10 +75,47 @@ __device__ __forceinline__ void split3_quad(const f32x4 p, u32x2 &hi, u32x2 &mid
     lo = (u32x2){(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
 }
 
+// ---- f16x2: the same idea on the f16 matrix pipe with TWO planes and THREE MFMAs per product block.
+// x = h + l * 2^-11 with h = f16(x) (round to nearest, 11 significant bits) and l = f16((x - h) * 2^11): the residual is
+// scaled into f16's normal range, so l carries another 11 bits whatever the magnitude of x (x is represented to 2^-22
+// relative, as against 2^-24 for fp32 itself).  a * b = ah * bh + 2^-11 (ah * bl + al * bh) + 2^-22 al * bl: the last term
+// is dropped (<= 2^-22 |a b|), the two middle terms run in their own accumulator which is scaled by 2^-11 once in the
+// epilogue.  Products of two f16 values are exact in fp32 (11 + 11 bits).  Per product the error is ~2^-22 |a b| with
+// random sign, which over K terms adds up like sqrt(K) - far below the K / 32 accumulator roundings both schemes share
+// (and the K roundings of an fp32 fma chain): measured against float64 the two splits are equally close, 3-5x closer
+// than fp32 MFMA (tools/conv_bench_bf16.hip, profiles/r03_conv_f16x2_bench.txt).  Range: |x| must stay below 65504 (f16's
+// largest finite value) - activations and weights of a recogniser are O(1); POCR_CONV_SPLIT=3 selects bf16x3 (fp32's range).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define POCR_MFMA_F16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
+constexpr float kF16x2Scale = 2048.0f;
+
+__device__ __forceinline__ void split2_quad(const f32x4 p, u32x2 &hi, u32x2 &lo) {
+    const f32x2 a = {p[0], p[1]}, b = {p[2], p[3]};
+    const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);       // round to nearest even
+    const f32x2 ra = (a - __builtin_convertvector(ha, f32x2)) * kF16x2Scale, rb = (b - __builtin_convertvector(hb, f32x2)) * kF16x2Scale;
+    const f16x2 la = __builtin_convertvector(ra, f16x2), lb = __builtin_convertvector(rb, f16x2);
+    hi = (u32x2){__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+    lo = (u32x2){__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+}
+
 // Issue-order template for the scheduler (LDS-weights loop): the G operand reads of a step spread evenly between its TOT MFMAs.
 template <int G, int TOT, int... I>
 __device__ __forceinline__ void sched_template_lds(std::integer_sequence<int, I...>) {
     ((__builtin_amdgcn_sched_group_barrier(0x008, ((I + 1) * TOT) / G - (I * TOT) / G, 0), __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)), ...);
+}
+
+// The same for the direct-weights loop: G operand reads, TOT MFMAs, NV weight loads (mask 0x020 VMEM read) spread over the step.
+template <int G, int TOT, int NV, int I>
+__device__ __forceinline__ void sched_group_dir() {
+    __builtin_amdgcn_sched_group_barrier(0x008, ((I + 1) * TOT) / G - (I * TOT) / G, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    if constexpr ((I * NV) / G != ((I + 1) * NV) / G) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+}
+template <int G, int TOT, int NV, int... I>
+__device__ __forceinline__ void sched_template_dir(std::integer_sequence<int, I...>) {
+    (sched_group_dir<G, TOT, NV, I>(), ...);
 }
 
 // WM waves split the pixel tile (column strips), 4 / WM waves split the output channels; the B tile (weights of one
@@ -94,16 +131,18 @@ __device__ __forceinline__ void sched_template_lds(std::integer_sequence<int, I.
 // UPCAT: the input is the virtual tensor cat([nearest-upsample-x2(x), x2], channels) of the layout network's decoder
 // (conv_igemm.hpp STAGE_UPCAT): 32-channel chunks below cin_up come from x at half resolution, the rest from the skip tensor.
 template <int TH, int MW, int NS, int WM, int POOLH, int POOLW, int ACT, bool BN, int MINW = 1, bool BDIR = false,
-          int KH = 3, int KW = 3, int PADH = 1, int PADW = 1, bool UPCAT = false>
+          int KH = 3, int KW = 3, int PADH = 1, int PADW = 1, bool UPCAT = false, int SPL = 3>
 __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
-    constexpr int NWAVE = 4, WN = NWAVE / WM, KC = 32, NTAP = KH * KW;
+    // SPL = planes per operand: 3 = bf16x3 (six MFMAs per 32-deep product block), 2 = f16x2 (three)
+    static_assert(SPL == 2 || SPL == 3, "operand split: 3 bf16 planes or 2 f16 planes");
+    constexpr int NWAVE = 4, WN = NWAVE / WM, KC = 32, NTAP = KH * KW, WU = SPL * 64, NMF = SPL == 3 ? 6 : 3;
     static_assert(MW % WM == 0, "column strips must divide among the M waves");
     constexpr int TW = 16 * MW, MWW = MW / WM, MS = TH * MWW, NT = NS * WN * 16, NTHR = 256;
     constexpr int HH = TH + KH - 1, HW = TW + KW - 1, NP = HH * HW, NPPAD = (NP + 15) / 16 * 16;
     constexpr int CQ = KC / 4;
     constexpr int PS = 4 * NPPAD;                       // 16-byte units per bf16 plane of the A tile ([octet][pixel])
-    constexpr int A_U = 3 * PS;                         // A tile (single-buffered, refilled once per chunk; BDIR: two of them)
-    constexpr int B_F4 = BDIR ? 0 : (NT / 16) * 3 * 64; // 16-byte units per B buffer (one (chunk, tap) step)
+    constexpr int A_U = SPL * PS;                       // A tile (single-buffered, refilled once per chunk; BDIR: two of them)
+    constexpr int B_F4 = BDIR ? 0 : (NT / 16) * WU;     // 16-byte units per B buffer (one (chunk, tap) step)
     constexpr int A_LD = (CQ * NP + NTHR - 1) / NTHR;
     constexpr int B_LD = BDIR ? 1 : (B_F4 + NTHR - 1) / NTHR;
     static_assert(POOLH == 1 || TH % 2 == 0, "H-pool needs an even tile height");
@@ -178,8 +217,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     const float *ximg = UPCAT ? a.x + (size_t)img * (a.H >> 1) * (Win >> 1) * a.cin_up : a.x + img_base;
     const float *ximg2 = UPCAT ? a.x2 + (size_t)img * a.H * Win * (a.cin - a.cin_up) : nullptr;
     const int nch_up = UPCAT ? a.cin_up / KC : 0;
-    const f32x4 *wt4 = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * (NT / 16) * 192;     // 192 x 16 B per cout tile
-    const size_t chunk_stride = (size_t)a.cout16 * 192, tap_stride = (size_t)nchunks * chunk_stride;
+    const f32x4 *wt4 = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * (NT / 16) * WU;      // WU x 16 B per cout tile
+    const size_t chunk_stride = (size_t)a.cout16 * WU, tap_stride = (size_t)nchunks * chunk_stride;
     f32x4 ra[A_LD], rb[B_LD];
     auto ldA = [&](int chunk) {
 #pragma unroll
@@ -194,11 +233,18 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < A_LD; ++r)
             if (a_lds[r] >= 0) {
-                u32x2 hi, mid, lo;
-                split3_quad(ra[r], hi, mid, lo);
-                base[a_lds[r]] = hi;
-                base[a_lds[r] + 2 * PS] = mid;
-                base[a_lds[r] + 4 * PS] = lo;
+                if constexpr (SPL == 3) {
+                    u32x2 hi, mid, lo;
+                    split3_quad(ra[r], hi, mid, lo);
+                    base[a_lds[r]] = hi;
+                    base[a_lds[r] + 2 * PS] = mid;
+                    base[a_lds[r] + 4 * PS] = lo;
+                } else {
+                    u32x2 hi, lo;
+                    split2_quad(ra[r], hi, lo);
+                    base[a_lds[r]] = hi;
+                    base[a_lds[r] + 2 * PS] = lo;
+                }
             }
     };
     auto ldB = [&](const f32x4 *tile) {
@@ -216,16 +262,16 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         }
     };
     if constexpr (BDIR) {
-    const u32x4 *wq = reinterpret_cast<const u32x4 *>(wt4) + (wn * NS) * 192 + lane;
+    const u32x4 *wq = reinterpret_cast<const u32x4 *>(wt4) + (wn * NS) * WU + lane;
     // three register sets of weight fragments, rotated with the step (statically: 9 taps = 3 x 3; other tap counts unroll
     // three chunks): the set of step s + 2 is requested while step s computes - two steps (~2000 cycles) cover an L2
     // miss, one does not
-    u32x4 bw[3][NS][3];
-    auto ldW = [&](u32x4 (&dst)[NS][3], const u32x4 *tile) {
+    u32x4 bw[3][NS][SPL];
+    auto ldW = [&](u32x4 (&dst)[NS][SPL], const u32x4 *tile) {
 #pragma unroll
         for (int n = 0; n < NS; ++n)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) dst[n][p] = tile[n * 192 + p * 64];
+            for (int p = 0; p < SPL; ++p) dst[n][p] = tile[n * WU + p * 64];
     };
     // step s = chunk * NTAP + tap uses set s % 3; the chunk loop is unrolled U-fold so that s % 3 is static
     constexpr int U = NTAP % 3 == 0 ? 1 : 3;
@@ -263,12 +309,26 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #else
                 const u32x4 *Ab = ldsA + abuf * A_U + dy * HW + dx + li + kq * NPPAD + wm * MWW * 16;
 #endif
-                u32x4 (&bc)[NS][3] = bw[sl % 3];
+                u32x4 (&bc)[NS][SPL] = bw[sl % 3];
 #pragma unroll
                 for (int m = 0; m < MS; ++m) {
                     const int o = (m / MWW) * HW + (m % MWW) * 16;
+                    if constexpr (SPL == 2) {
 #if POCR_BF16X3_DBG & 1
-                    const u32x4 ah = bc[0][0] ^ (unsigned)m, am = bc[0][1] ^ (unsigned)m, al = bc[0][2] ^ (unsigned)m;     // no LDS reads
+                        const u32x4 ah = bc[0][0] ^ (unsigned)m, al = bc[0][1] ^ (unsigned)m;
+                        (void)o; (void)Ab;
+#else
+                        const u32x4 ah = Ab[o], al = Ab[o + PS];
+#endif
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(al, bc[n][0], acc2[m][n]);
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_F16(ah, bc[n][0], acc[m][n]);
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(ah, bc[n][1], acc2[m][n]);
+                    } else {
+#if POCR_BF16X3_DBG & 1
+                    const u32x4 ah = bc[0][0] ^ (unsigned)m, am = bc[0][1] ^ (unsigned)m, al = bc[0][SPL - 1] ^ (unsigned)m;     // no LDS reads
                     (void)o; (void)Ab;
 #else
                     const u32x4 ah = Ab[o], am = Ab[o + PS], al = Ab[o + 2 * PS];
@@ -280,24 +340,18 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
                     for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bc[n][1], acc2[m][n]);
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bc[n][2], acc2[m][n]);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bc[n][SPL - 1], acc2[m][n]);
 #pragma unroll
                     for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bc[n][0], acc2[m][n]);
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bc[n][1], acc2[m][n]);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bc[n][SPL - 2], acc2[m][n]);
+                    }
                 }
 #if POCR_BF16X3_SCHED
                 // issue order of one step, as a template for the scheduler: the A reads and the weight loads of the step after
                 // next spread between the MFMAs instead of bunched where the source puts them (mask 8 MFMA, 0x100 DS read, 0x20 VMEM read)
-                {
-                    constexpr int G = MS * 3, MPG = NS * 2, NV = NS * 3;      // one A read per group of NS * 2 MFMAs; NV weight loads spread over the G groups
-#pragma unroll
-                    for (int gq = 0; gq < G; ++gq) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        if ((gq * NV) / G != ((gq + 1) * NV) / G) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    }
-                }
+                // one A read per group of TOT / G MFMAs; NV weight loads spread over the G groups
+                sched_template_dir<MS * SPL, MS * NS * NMF, NS * SPL>(std::make_integer_sequence<int, MS * SPL>{});
 #endif
 #if !(POCR_BF16X3_DBG & 4)
                 if (tap == NTAP / 2) stA(abuf ^ 1);       // the other A buffer: its last readers passed the barrier of the previous chunk
@@ -325,14 +379,24 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             if (tap == 0 && next_chunk) ldA(chunk + 1);
             const int dy = tap / KW, dx = tap % KW;
             const u32x4 *Ab = ldsA + dy * HW + dx + li + kq * NPPAD + wm * MWW * 16;
-            const u32x4 *Bb = ldsB + bcur * B_F4 + (wn * NS) * 192 + lane;
+            const u32x4 *Bb = ldsB + bcur * B_F4 + (wn * NS) * WU + lane;
             u32x4 bh[NS], bm[NS], bl[NS];
 #pragma unroll
-            for (int n = 0; n < NS; ++n) { bh[n] = Bb[n * 192]; bm[n] = Bb[n * 192 + 64]; bl[n] = Bb[n * 192 + 128]; }
+            for (int n = 0; n < NS; ++n) { bh[n] = Bb[n * WU]; bm[n] = Bb[n * WU + 64]; bl[n] = Bb[n * WU + (SPL - 1) * 64]; }
 #pragma unroll
             for (int m = 0; m < MS; ++m) {
                 const int o = (m / MWW) * HW + (m % MWW) * 16;
-                const u32x4 ah = Ab[o], am = Ab[o + PS], al = Ab[o + 2 * PS];
+                if constexpr (SPL == 2) {           // bm = the scaled low plane of the weights
+                    const u32x4 ah = Ab[o], al = Ab[o + PS];
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(al, bh[n], acc2[m][n]);
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_F16(ah, bh[n], acc[m][n]);
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(ah, bm[n], acc2[m][n]);
+                    continue;
+                }
+                const u32x4 ah = Ab[o], am = Ab[o + PS], al = Ab[o + (SPL - 1) * PS];
                 // The main term (hi x hi) and the five small terms run in SEPARATE accumulators, added once in the epilogue:
                 // the running sum of the main term sees one rounding per 32-deep block (the fp32-MFMA chain: 32), and the
                 // small terms round at their own magnitude, 2^-8 of the main one.  Measured against float64: 3x closer than
@@ -351,7 +415,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                 for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bm[n], acc2[m][n]);
             }
 #if POCR_BF16X3_SCHED
-            sched_template_lds<(MS + NS) * 3, MS * NS * 6>(std::make_integer_sequence<int, (MS + NS) * 3>{});
+            sched_template_lds<(MS + NS) * SPL, MS * NS * NMF>(std::make_integer_sequence<int, (MS + NS) * SPL>{});
 #endif
             if (more) stB(bcur ^ 1);
             if (last && next_chunk) {
@@ -366,7 +430,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int m = 0; m < MS; ++m)
 #pragma unroll
-        for (int n = 0; n < NS; ++n) acc[m][n] += acc2[m][n];
+        for (int n = 0; n < NS; ++n) {
+            if constexpr (SPL == 2) acc[m][n] += acc2[m][n] * (1.0f / kF16x2Scale);
+            else acc[m][n] += acc2[m][n];
+        }
     // ---- epilogue (identical to conv_igemm_kernel: same D layout)
     const int Wo = Win, Wout = Wo / POOLW;
 #pragma unroll

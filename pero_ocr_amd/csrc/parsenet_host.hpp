@@ -94,7 +94,7 @@ int pocr_parsenet_create(const float *weights, size_t n_floats, int device_id, p
         L.cin = kPnEnc[i][0]; L.cout = kPnEnc[i][1]; L.nt = enc_nt[i];
         const float *w = cur.take((size_t)L.cout * L.cin * 9), *b = cur.take(L.cout);
         L.cout16 = round_up(L.cout, L.nt) / 16;
-        L.b3 = i > 0 && getenv("POCR_CONV_FP32") == nullptr;          // e0 (3 input channels, fused uint8 staging) stays on the fp32 kernel
+        L.b3 = i > 0 && conv_split() != 0;          // e0 (3 input channels, fused uint8 staging) stays on the fp32 kernel
         if (L.b3) {
             auto wsp = build_wsplit(9, L.cin, L.cout16, [&](int co, int ci, int tap) { return w[((size_t)co * L.cin + ci) * 9 + tap]; }, L.cout);
             std::vector<float> bias(L.cout16 * 16, 0.f);
@@ -115,7 +115,7 @@ int pocr_parsenet_create(const float *weights, size_t n_floats, int device_id, p
         L.cin = kPnDec[i][0] + kPnDec[i][1]; L.cout = kPnDec[i][2]; L.nt = dec_nt[i];
         const float *w = cur.take((size_t)L.cout * L.cin * 9), *b = cur.take(L.cout);
         L.cout16 = round_up(L.cout, L.nt) / 16;
-        L.b3 = getenv("POCR_CONV_FP32") == nullptr;
+        L.b3 = conv_split() != 0;
         std::vector<float> bias(L.cout16 * 16, 0.f);
         for (int k = 0; k < L.cout; ++k) bias[k] = b[k];
         if (L.b3) {

@@ -154,8 +154,23 @@ POCR_CONV(gemm128_relu_k, 1, 1, 0, 0, 1, 8, 2, 4, 16, 1, 1, ACT_RELU, false, STA
 const int kConvNT[9] = {64, 64, 128, 128, 128, 128, 128, 256, 256};
 // The same layers on the bf16 matrix pipe with fp32-level accuracy (conv_bf16x3.hpp: three-way exact operand split, six
 // bf16 MFMAs per product block); tile configurations from tools/conv_bench_bf16.hip.  (TH, MW, NS, WM, POOLH, POOLW, ACT, BN)
-#define POCR_CONV3(name, TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW, BDIR)                                        \
+// Operand split of the split-precision kernels, process-wide (weights are laid out for it at creation): 2 = f16x2 (two f16
+// planes, THREE MFMAs per 32-deep product block: ceiling 2500 / 3 = 833 TFLOP/s of algorithmic fp32 FLOPs; the default),
+// 3 = bf16x3 (three bf16 planes, six MFMAs: 416.7; POCR_CONV_SPLIT=3), 0 = fp32 MFMA kernels (POCR_CONV_FP32=1: 157.3).
+int conv_split() {
+    static const int mode = [] {
+        if (const char *env = getenv("POCR_CONV_FP32")) if (atoi(env) != 0) return 0;
+        if (const char *env = getenv("POCR_CONV_SPLIT")) return atoi(env) == 3 ? 3 : 2;
+        return 2;
+    }();
+    return mode;
+}
+// MINW2: workgroups per CU the f16x2 instantiation is budgeted for (launch bounds)
+#define POCR_CONV3(name, TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW, BDIR, MINW2)                                 \
     int name(ConvArgs a, hipStream_t st) {                                                                         \
+        if (conv_split() == 2)                                                                                     \
+            return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW2, BDIR, 3, 3, 1, 1, false, 2>, \
+                               TH, 16 * MW, NS * (4 / WM) * 16, 256, a, st);                                       \
         return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW, BDIR>, TH, 16 * MW,   \
                            NS * (4 / WM) * 16, 256, a, st);                                                        \
     }
@@ -163,23 +178,29 @@ const int kConvNT[9] = {64, 64, 128, 128, 128, 128, 128, 256, 256};
 // wins wherever each wave owns its channels (WM 1) and the accumulators leave room for three weight sets
 // the low-K layers (2-4 chunks of K) want SMALL tiles: two or three workgroups per CU cover each other's prologue / epilogue
 // (MFMA busy 44-52 % with one 4x64 / 4x32 workgroup per CU; -10 ... -16 % with these)
-POCR_CONV3(conv2_b3,  4, 2, 2, 2, 2, 2, ACT_RELU, false, 2, false)   // 64->64 + pool 2x2: 4x32 px, NT 64, waves 2 (pixels) x 2 (channels)
-POCR_CONV3(conv3_b3,  5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)    // 64->128: 5x16 px, NT 128
-POCR_CONV3(conv4_b3,  4, 1, 2, 1, 2, 2, ACT_RELU, false, 2, true)    // 128->128 + pool 2x2: 4x16 px
-POCR_CONV3(conv56_b3, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)    // ->256: 5x16 px, NT 128, two workgroups per CU
-POCR_CONV3(conv7_b3,  2, 2, 2, 1, 2, 1, ACT_RELU, false, 2, true)    // 256->256 + pool 2x1: 2x32 px (the pool needs an even tile height)
-POCR_CONV3(conv8_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true)   // 256->512: 5x16 px, NT 128, two workgroups per CU
-POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true)    // 512->512 + BN
+POCR_CONV3(conv2_b3,  4, 2, 2, 2, 2, 2, ACT_RELU, false, 2, false, 3)   // 64->64 + pool 2x2: 4x32 px, NT 64, waves 2 (pixels) x 2 (channels)
+POCR_CONV3(conv3_b3,  5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true, 2)    // 64->128: 5x16 px, NT 128
+POCR_CONV3(conv4_b3,  4, 1, 2, 1, 2, 2, ACT_RELU, false, 2, true, 2)    // 128->128 + pool 2x2: 4x16 px
+POCR_CONV3(conv56_b3, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true, 2)    // ->256: 5x16 px, NT 128, two workgroups per CU
+POCR_CONV3(conv7_b3,  2, 2, 2, 1, 2, 1, ACT_RELU, false, 2, true, 2)    // 256->256 + pool 2x1: 2x32 px (the pool needs an even tile height)
+POCR_CONV3(conv8_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true, 2)   // 256->512: 5x16 px, NT 128, two workgroups per CU
+POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true, 2)    // 512->512 + BN
 // the aggregation conv (AH x 1, no padding) and the GEMM-mode layers (1 x 1: LSTM input projections, encoder linears) on the
 // same kernel: weights through LDS, 48 pixels x 256 channels / 128 rows x 128 columns per workgroup
 #define POCR_CONV3G(name, TH, MW, NS, WM, ACT, MINW, KH, BDIR)                                                      \
     int name(ConvArgs a, hipStream_t st) {                                                                         \
+        if (conv_split() == 2)                                                                                     \
+            return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT, false, MINW, BDIR, KH, 1, 0, 0, false, 2>, TH, \
+                               16 * MW, NS * (4 / WM) * 16, 256, a, st);                                           \
         return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT, false, MINW, BDIR, KH, 1, 0, 0>, TH,    \
                            16 * MW, NS * (4 / WM) * 16, 256, a, st);                                               \
     }
 // decoder convs of the layout network: virtual cat(up2(x), skip) input
 #define POCR_CONV3U(name, TH, MW, NS, WM, MINW, BDIR)                                                               \
     int name(ConvArgs a, hipStream_t st) {                                                                         \
+        if (conv_split() == 2)                                                                                     \
+            return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT_RELU, false, MINW, BDIR, 3, 3, 1, 1, true, 2>, \
+                               TH, 16 * MW, NS * (4 / WM) * 16, 256, a, st);                                       \
         return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT_RELU, false, MINW, BDIR, 3, 3, 1, 1, true>, \
                            TH, 16 * MW, NS * (4 / WM) * 16, 256, a, st);                                           \
     }
@@ -206,10 +227,26 @@ const int kAggNT = 256, kProjNT = 128, kHeadNT = 64, kSkinnyNT = 64;
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// wsplit[tap][cin/32][cout16][plane][lane][8 bf16] = plane of W(co = 16 s + (lane & 15), ci = 32 g + 8 (lane >> 4) + j, tap):
-// hi / mid / lo of the exact truncation split (conv_bf16x3.hpp), zero outside cout_valid
+// wsplit[tap][cin/32][cout16][plane][lane][8 x 16 bit] = plane of W(co = 16 s + (lane & 15), ci = 32 g + 8 (lane >> 4) + j, tap),
+// zero outside cout_valid.  conv_split() == 3: hi / mid / lo of the exact bf16 truncation split; == 2: h = f16(w) and
+// l = f16((w - h) * 2^11), both rounded to nearest (conv_bf16x3.hpp)
+inline void split_weight(float wv, int split, uint16_t *planes) {
+    if (split == 2) {
+        const _Float16 h = (_Float16)wv;
+        const _Float16 l = (_Float16)((wv - (float)h) * 2048.0f);
+        memcpy(&planes[0], &h, 2); memcpy(&planes[1], &l, 2);
+        return;
+    }
+    uint32_t wb; memcpy(&wb, &wv, 4);
+    const uint32_t hb = wb & 0xffff0000u; float hf; memcpy(&hf, &hb, 4);
+    const float r1 = wv - hf; uint32_t r1b; memcpy(&r1b, &r1, 4);
+    const uint32_t mb = r1b & 0xffff0000u; float mf; memcpy(&mf, &mb, 4);
+    const float r2 = r1 - mf; uint32_t r2b; memcpy(&r2b, &r2, 4);
+    planes[0] = (uint16_t)(hb >> 16); planes[1] = (uint16_t)(mb >> 16); planes[2] = (uint16_t)(r2b >> 16);
+}
 std::vector<uint16_t> build_wsplit(int ntaps, int cin, int cout16, const std::function<float(int, int, int)> &W, int cout_valid) {
-    std::vector<uint16_t> wsp((size_t)ntaps * (cin / 32) * cout16 * 3 * 64 * 8);
+    const int split = conv_split();
+    std::vector<uint16_t> wsp((size_t)ntaps * (cin / 32) * cout16 * split * 64 * 8);
     size_t o = 0;
     for (int tap = 0; tap < ntaps; ++tap)
         for (int g = 0; g < cin / 32; ++g)
@@ -218,16 +255,12 @@ std::vector<uint16_t> build_wsplit(int ntaps, int cin, int cout16, const std::fu
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const int co = 16 * sg + (lane & 15), ci = 32 * g + 8 * (lane >> 4) + j;
-                        const float wv = co < cout_valid ? W(co, ci, tap) : 0.f;
-                        uint32_t wb; memcpy(&wb, &wv, 4);
-                        const uint32_t hb = wb & 0xffff0000u; float hf; memcpy(&hf, &hb, 4);
-                        const float r1 = wv - hf; uint32_t r1b; memcpy(&r1b, &r1, 4);
-                        const uint32_t mb = r1b & 0xffff0000u; float mf; memcpy(&mf, &mb, 4);
-                        const float r2 = r1 - mf; uint32_t r2b; memcpy(&r2b, &r2, 4);
-                        part[0][lane][j] = (uint16_t)(hb >> 16); part[1][lane][j] = (uint16_t)(mb >> 16); part[2][lane][j] = (uint16_t)(r2b >> 16);
+                        uint16_t pl[3] = {0, 0, 0};
+                        split_weight(co < cout_valid ? W(co, ci, tap) : 0.f, split, pl);
+                        part[0][lane][j] = pl[0]; part[1][lane][j] = pl[1]; part[2][lane][j] = pl[2];
                     }
-                memcpy(&wsp[o], part, sizeof(part));
-                o += 3 * 64 * 8;
+                memcpy(&wsp[o], part, (size_t)split * 64 * 8 * sizeof(uint16_t));
+                o += (size_t)split * 64 * 8;
             }
     return wsp;
 }
@@ -939,6 +972,7 @@ extern "C" {
 
 const char *pocr_last_error(void) { return g_err.c_str(); }
 int pocr_abi_version(void) { return POCR_ABI_VERSION; }
+int pocr_conv_split(void) { return conv_split(); }
 
 int pocr_set_embed_id(pocr_engine *e, int32_t embed_id) {
     if (!e) return fail("engine is NULL");
@@ -1044,7 +1078,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     e->cfg = *cfg;
     if (const char *env = getenv("POCR_NO_GRAPHS")) e->use_graphs = atoi(env) == 0;
     if (const char *env = getenv("POCR_LSTM_PERSIST")) e->lstm_persist = atoi(env) != 0;
-    if (const char *env = getenv("POCR_CONV_FP32")) e->bf16x3 = atoi(env) == 0;
+    e->bf16x3 = conv_split() != 0;
     if (const char *env = getenv("POCR_LSTM_WIDE")) e->lstm_wide = atoi(env) != 0;
     if (const char *env = getenv("POCR_LSTM_MULTI")) e->lstm_multi = atoi(env);
     e->device = device_id;
@@ -1082,26 +1116,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         const int cout16 = round_up(L.cout, b3 ? kConvNT3[i] : kConvNT[i]) / 16;
         e->conv_cout16[i] = cout16;
         if (b3) {
-            // wsplit[tap][cin/32][cout16][plane][lane][8 bf16] = plane of W[co = 16 s + (lane & 15)][ci = 32 g + 8 (lane >> 4) + j][tap];
-            // hi / mid / lo = the exact truncation split of conv_bf16x3.hpp
-            std::vector<uint16_t> wsp((size_t)9 * (L.cin / 32) * cout16 * 3 * 64 * 8);
-            size_t o = 0;
-            for (int tap = 0; tap < 9; ++tap)
-                for (int g = 0; g < L.cin / 32; ++g)
-                    for (int sg = 0; sg < cout16; ++sg)
-                        for (int pl = 0; pl < 3; ++pl)
-                            for (int lane = 0; lane < 64; ++lane)
-                                for (int j = 0; j < 8; ++j, ++o) {
-                                    const int co = 16 * sg + (lane & 15), ci = 32 * g + 8 * (lane >> 4) + j;
-                                    const float wv = co < L.cout ? w[((size_t)co * L.cin + ci) * 9 + tap] : 0.f;
-                                    uint32_t wb; memcpy(&wb, &wv, 4);
-                                    const uint32_t hb = wb & 0xffff0000u; float hf; memcpy(&hf, &hb, 4);
-                                    const float r1 = wv - hf; uint32_t r1b; memcpy(&r1b, &r1, 4);
-                                    const uint32_t mb = r1b & 0xffff0000u; float mf; memcpy(&mf, &mb, 4);
-                                    const float r2 = r1 - mf; uint32_t r2b; memcpy(&r2b, &r2, 4);
-                                    const uint32_t parts[3] = {hb, mb, r2b & 0xffff0000u};
-                                    wsp[o] = (uint16_t)(parts[pl] >> 16);
-                                }
+            auto wsp = build_wsplit(9, L.cin, cout16, [&](int co, int ci, int tap) { return w[((size_t)co * L.cin + ci) * 9 + tap]; }, L.cout);
             std::vector<float> bias(cout16 * 16, 0.f);
             for (int k = 0; k < L.cout; ++k) bias[k] = b[k];
             if (e->conv_w[i].reserve(wsp.size() * 2)) return bail(1);
@@ -1708,11 +1723,24 @@ int pocr_comm_init(pocr_engine *e, const uint8_t *id128, int32_t rank, int32_t w
     return 0;
 }
 
+// What the communicator itself says (ncclCommCount / ncclCommUserRank), not what the caller passed to pocr_comm_init: a
+// bench line that claims N RCCL ranks carries these numbers.  No communicator: *count = *rank = 0, returns 0.
+int pocr_comm_info(pocr_engine *e, int32_t *count, int32_t *rank) {
+    if (!e) return fail("engine is NULL");
+    if (!count || !rank) return fail("count / rank is NULL");
+    *count = 0; *rank = 0;
+    if (!e->comm.active()) return 0;
+    int c = 0, r = 0;
+    NCCL_TRY(rccl().CommCount(e->comm.comm, &c));
+    NCCL_TRY(rccl().CommUserRank(e->comm.comm, &r));
+    *count = c; *rank = r;
+    return 0;
+}
+
 static void comm_release(pocr_engine *e) {
     Comm &c = e->comm;
     if (c.comm) (void)rccl().CommDestroy(c.comm);
-    if (c.d_send) (void)hipFree(c.d_send);
-    if (c.d_recv) (void)hipFree(c.d_recv);
+    { UnsafeLock l; if (c.d_send) (void)hipFree(c.d_send); if (c.d_recv) (void)hipFree(c.d_recv); }
     if (c.h_send) (void)locked_host_free(c.h_send);
     if (c.h_recv) (void)locked_host_free(c.h_recv);
     if (c.stream) (void)hipStreamDestroy(c.stream);
@@ -1732,20 +1760,20 @@ static int comm_reserve(pocr_engine *e, size_t send_bytes) {
     Comm &c = e->comm;
     const size_t recv_bytes = send_bytes * (size_t)c.world;
     if (send_bytes > c.send_cap) {
-        if (c.d_send) (void)hipFree(c.d_send);
+        if (c.d_send) { UnsafeLock l; (void)hipFree(c.d_send); }
         if (c.h_send) (void)locked_host_free(c.h_send);
         c.d_send = c.h_send = nullptr; c.send_cap = 0;
         const size_t want = send_bytes + send_bytes / 4 + 256;
-        HIP_TRY(hipMalloc(&c.d_send, want));
+        { UnsafeLock l; HIP_TRY(hipMalloc(&c.d_send, want)); }
         HIP_TRY(locked_host_malloc(&c.h_send, want, hipHostMallocDefault));
         c.send_cap = want;
     }
     if (recv_bytes > c.recv_cap) {
-        if (c.d_recv) (void)hipFree(c.d_recv);
+        if (c.d_recv) { UnsafeLock l; (void)hipFree(c.d_recv); }
         if (c.h_recv) (void)locked_host_free(c.h_recv);
         c.d_recv = c.h_recv = nullptr; c.recv_cap = 0;
         const size_t want = recv_bytes + recv_bytes / 4 + 256;
-        HIP_TRY(hipMalloc(&c.d_recv, want));
+        { UnsafeLock l; HIP_TRY(hipMalloc(&c.d_recv, want)); }
         HIP_TRY(locked_host_malloc(&c.h_recv, want, hipHostMallocDefault));
         c.recv_cap = want;
     }

@@ -46,26 +46,36 @@ def load_blob(path: str) -> np.ndarray:
     return flat
 
 
+def _area_weights(n_in: int, n_out: int):
+    """Sparse [n_out, n_in] matrix of INTER_AREA weights: output o covers the source interval [o * scale, (o + 1) * scale),
+    at most ceil(scale) + 1 taps, each weighted by the covered length, rows normalised."""
+    from scipy import sparse
+    scale = n_in / n_out
+    taps = int(np.ceil(scale)) + 1
+    o = np.arange(n_out, dtype=np.float64)
+    a, b = o * scale, np.minimum((o + 1.0) * scale, float(n_in))
+    idx = np.floor(a).astype(np.int64)[:, None] + np.arange(taps, dtype=np.int64)[None, :]
+    wgt = np.minimum(b[:, None], idx + 1.0) - np.maximum(a[:, None], idx.astype(np.float64))
+    wgt = np.where((idx < n_in) & (wgt > 0), wgt, 0.0)
+    wgt /= wgt.sum(axis=1, keepdims=True)
+    rows = np.repeat(np.arange(n_out, dtype=np.int64), taps)
+    return sparse.csr_matrix((wgt.reshape(-1), (rows, np.minimum(idx, n_in - 1).reshape(-1))), shape=(n_out, n_in))
+
+
 def resize_area(img: np.ndarray, downsample: float) -> np.ndarray:
     """Host INTER_AREA for a fractional factor (the device handles integers): output pixel = area-weighted mean of the
-    source rectangle it covers, rounded to nearest; output size cvRound(size / downsample) like cv2.resize(fx=1/ds)."""
+    source rectangle it covers, rounded to nearest; output size cvRound(size / downsample) like cv2.resize(fx=1/ds).
+    Separable and sparse (two CSR products, <= ceil(ds) + 1 taps per output pixel): ~0.3 s for a 4k x 3k page - this is
+    the path every page after the first takes once get_maps_with_optimal_resolution remembers a fractional factor."""
     h, w = img.shape[:2]
+    c = img.shape[2] if img.ndim == 3 else 1
     oh, ow = int(np.rint(h / downsample)), int(np.rint(w / downsample))
-
-    def weights(n_in, n_out):
-        scale = n_in / n_out
-        m = np.zeros((n_out, n_in), dtype=np.float64)
-        for o in range(n_out):
-            a, b = o * scale, min((o + 1) * scale, n_in)
-            i0, i1 = int(np.floor(a)), int(np.ceil(b))
-            for i in range(i0, min(i1, n_in)):
-                m[o, i] = min(b, i + 1) - max(a, i)
-            m[o] /= m[o].sum()
-        return m
-    wy, wx = weights(h, oh), weights(w, ow)
-    out = np.einsum("oh,hwc->owc", wy, img.astype(np.float64))
-    out = np.einsum("pw,owc->opc", wx, out)
-    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    wy, wx = _area_weights(h, oh), _area_weights(w, ow)
+    rows = wy @ img.reshape(h, w * c).astype(np.float64)                                   # [oh, w * c]
+    cols = wx @ np.ascontiguousarray(rows.reshape(oh, w, c).transpose(1, 0, 2)).reshape(w, oh * c)   # [ow, oh * c]
+    out = cols.reshape(ow, oh, c).transpose(1, 0, 2)
+    out = np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    return out if img.ndim == 3 else out[:, :, 0]
 
 
 class Net(object):

@@ -103,22 +103,25 @@ def pipeline_depth(engine=None) -> int:
 
 
 def plan_launches(chunks: Sequence[Chunk], target: int = LAUNCH_WORK_TARGET) -> List[Launch]:
-    """Greedy merge of consecutive chunks (plan order = descending width) into ceil(total / target) launches of about equal
-    work: a job a little larger than `target` (one page of long lines) becomes two balanced launches whose recurrent and
-    convolutional phases overlap, not a full one and a remainder."""
+    """Merge consecutive chunks (plan order = descending width) into ceil(total / target) launches of about equal work: a job
+    a little larger than `target` (one page of long lines) becomes two balanced launches whose recurrent and convolutional
+    phases overlap, not a full one and a remainder.  Cuts follow the CUMULATIVE work: launch j ends at the chunk boundary
+    nearest to (j + 1) * total / n_launches, so no shortfall piles up in the last launch (every launch stays within one
+    chunk's work of the mean; the largest launch sets a slot's activation high-water mark and the pipeline's tail)."""
     works = [len(ch.line_ids) * ch.w_pad for ch in chunks]
     total = sum(works)
     n_launches = max(1, -(-total // max(1, target)))
-    budget = -(-total // n_launches)
     out: List[Launch] = []
     cur: List[Chunk] = []
-    acc = 0
+    done = 0                                   # work of the chunks already placed (closed launches + cur)
     for ch, w in zip(chunks, works):
-        if cur and acc + w > budget and len(out) < n_launches - 1:
+        boundary = (len(out) + 1) * total / n_launches
+        # cut BEFORE this chunk if that leaves the running total closer to the boundary than cutting after it would
+        if cur and len(out) < n_launches - 1 and abs(done - boundary) <= abs(done + w - boundary):
             out.append(Launch(cur))
-            cur, acc = [], 0
+            cur = []
         cur.append(ch)
-        acc += w
+        done += w
     if cur:
         out.append(Launch(cur))
     return out

@@ -159,6 +159,19 @@ def init_rccl_from_env(engine, rank: Optional[int] = None, world: Optional[int] 
     return RcclTransport(engine)
 
 
+ROW_FAILED = -2          # length field of a payload row whose rank could not produce it
+
+
+def _raise_together(got: np.ndarray, failure, transport, m_of: Sequence[int]) -> None:
+    """After the all-gather: if any rank flagged its rows, EVERY rank raises (the failing one its own exception)."""
+    if failure is not None:
+        raise failure
+    if got.size and bool(np.any(got[:, 1] == ROW_FAILED)):
+        bounds = np.concatenate([[0], np.cumsum(m_of)])
+        bad = [r for r in range(transport.world) if np.any(got[bounds[r]:bounds[r + 1], 1] == ROW_FAILED)]
+        raise RuntimeError(f"rank(s) {bad} failed in their share of the page stream; no rank returns a partial result")
+
+
 def allgather_rows(transport, rows: np.ndarray, m_max: int, m_of: Sequence[int]) -> np.ndarray:
     """ONE fixed-stride all-gather.  rows: int32 [m_r, stride] of this rank; every rank knows m_of (rows per rank) and
     therefore m_max from the shared plan, so no sizes are exchanged.  Returns the ranks' rows back to back."""
@@ -194,18 +207,26 @@ class ShardedLineOCR:
         m_of = [sum(len(chunks[i].line_ids) for i in p) for p in parts]
         t_max = max([c.frames for c in chunks], default=0)
         rows = np.full((m_of[tr.rank], t_max + 2), -1, dtype=np.int32)       # [line id, length, labels...]
-        many = getattr(self.recognise, "many", None)
-        results = many(lines, [chunks[ci] for ci in mine]) if many else None     # merged, pipelined launches
-        k0 = 0
-        for k, ci in enumerate(mine):
-            ch = chunks[ci]
-            lab, ln = results[k] if results is not None else self.recognise(lines, ch)
-            m = len(ch.line_ids)
-            rows[k0:k0 + m, 0] = ch.line_ids
-            rows[k0:k0 + m, 1] = ln
-            rows[k0:k0 + m, 2:2 + lab.shape[1]] = lab
-            k0 += m
+        # A rank that fails must not leave the others blocked in the collective: it still takes part, with its rows
+        # flagged (length = ROW_FAILED), and every rank raises after the exchange.
+        failure = None
+        try:
+            many = getattr(self.recognise, "many", None)
+            results = many(lines, [chunks[ci] for ci in mine]) if many else None     # merged, pipelined launches
+            k0 = 0
+            for k, ci in enumerate(mine):
+                ch = chunks[ci]
+                lab, ln = results[k] if results is not None else self.recognise(lines, ch)
+                m = len(ch.line_ids)
+                rows[k0:k0 + m, 0] = ch.line_ids
+                rows[k0:k0 + m, 1] = ln
+                rows[k0:k0 + m, 2:2 + lab.shape[1]] = lab
+                k0 += m
+        except Exception as exc:              # noqa: BLE001 - re-raised below, after the collective
+            failure = exc
+            rows[:, 1] = ROW_FAILED
         got = allgather_rows(tr, rows, max(m_of, default=0), m_of)
+        _raise_together(got, failure, tr, m_of)
         texts: List[Optional[str]] = [None] * len(lines)
         for row in got:
             texts[int(row[0])] = "".join(self.characters[c] for c in row[2:2 + row[1]])
@@ -237,8 +258,10 @@ def engine_recogniser(engine) -> Callable:
 
         pending = None
         try:
-            for j, launch in enumerate(plan_launches(chunks, launch_target(None))):
-                handle = engine._submit_launch(lines, launch, False, j % 2)
+            from .ocr_engine.line_ocr_engine import pipeline_depth
+            depth = pipeline_depth(engine)
+            for j, launch in enumerate(plan_launches(chunks, launch_target(engine))):
+                handle = engine._submit_launch(lines, launch, False, j % min(2, depth))
                 if pending is not None:
                     finish(*pending)
                 pending = (launch, handle)
@@ -285,17 +308,25 @@ class ShardedSeq2SeqOCR:
             for i, _first, _end in b.parts:
                 bound[i] = bound.get(i, 0) + b.w_pad // 4 + 1
         stride = max(bound.values(), default=0) + 2
-        texts = self.recognise(lines, [batches[i] for i in mine]) if mine else {}
-        ids = sorted(texts)
-        rows = np.full((len(ids), stride), -1, dtype=np.int32)
-        for k, i in enumerate(ids):
-            cps = [ord(ch) for ch in texts[i]][:stride - 2]
-            rows[k, 0], rows[k, 1] = i, len(cps)
-            rows[k, 2:2 + len(cps)] = cps
         m_of = [len(x) for x in ids_of]
-        if m_of[tr.rank] != len(ids):
-            raise RuntimeError("the recogniser did not return every line of this rank's batches")
+        rows = np.full((m_of[tr.rank], stride), -1, dtype=np.int32)
+        failure = None
+        try:                                   # (a failing rank still takes part in the collective, see ShardedLineOCR)
+            texts = self.recognise(lines, [batches[i] for i in mine]) if mine else {}
+            ids = sorted(texts)
+            if m_of[tr.rank] != len(ids):
+                raise RuntimeError("the recogniser did not return every line of this rank's batches")
+            for k, i in enumerate(ids):
+                cps = [ord(ch) for ch in texts[i]]
+                if len(cps) > stride - 2:
+                    raise RuntimeError(f"line {i}: transcription of {len(cps)} symbols exceeds the plan's bound {stride - 2}")
+                rows[k, 0], rows[k, 1] = i, len(cps)
+                rows[k, 2:2 + len(cps)] = cps
+        except Exception as exc:              # noqa: BLE001 - re-raised below, after the collective
+            failure = exc
+            rows[:, 1] = ROW_FAILED
         got = allgather_rows(tr, rows, max(m_of, default=0), m_of)
+        _raise_together(got, failure, tr, m_of)
         out: List[Optional[str]] = [None] * len(lines)
         for row in got:
             out[int(row[0])] = "".join(chr(int(c)) for c in row[2:2 + row[1]])

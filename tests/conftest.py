@@ -92,10 +92,15 @@ class Golden:
 
     def rows64(self, i):
         """The sampled rows computed in float64 by the restated network (oracle/gen_truth_rows.py), or None."""
+        if "rows_all" not in self.arrays.files:
+            return None
+        r = self.rows(i)                 # builds _srow_off
+        a, b = int(self._srow_off[i]), int(self._srow_off[i + 1])
+        if "rows64_delta16" in self.arrays.files:      # truth = reference row - float16(reference - truth), exact to < 1e-6
+            return (r.astype(np.float64) - self._whole("rows64_delta16")[a:b].astype(np.float64)).astype(np.float32)
         if "rows64_all" not in self.arrays.files:
             return None
-        self.rows(i)                     # builds _srow_off
-        return self._whole("rows64_all")[int(self._srow_off[i]):int(self._srow_off[i + 1])]
+        return self._whole("rows64_all")[a:b]
 
     def l2(self, i):
         if "l2_all" in self.arrays.files:

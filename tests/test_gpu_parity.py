@@ -186,6 +186,24 @@ def _check_full_tensor_stats(g, logits):
     return worst
 
 
+def _check_truth_rows(g, logits, name):
+    """Sampled rows against the float64 restatement (oracle/gen_truth_rows.py) and against the float32 reference.  Returns
+    (max |hip - f64|, max |ref - f64|, rows with |hip - ref| > 1e-3, rows with |ref - f64| > 5e-4, sampled rows)."""
+    hip_t = ref_t = 0.0
+    n_hip_ref = n_ref_t = n_rows = 0
+    for i in range(g.n):
+        got, ref, truth = np.asarray(logits[i])[g.sample_rows[i]], g.rows(i), g.rows64(i)
+        assert truth is not None, "the fixture has no float64 rows (oracle/gen_truth_rows.py)"
+        hip_t = max(hip_t, float(np.max(np.abs(got - truth))))
+        ref_t = max(ref_t, float(np.max(np.abs(ref - truth))))
+        n_hip_ref += int(np.sum(np.max(np.abs(got - ref), axis=1) > LOGIT_TOL))
+        n_ref_t += int(np.sum(np.max(np.abs(ref - truth), axis=1) > 0.5 * LOGIT_TOL))
+        n_rows += got.shape[0]
+    print(f"[{name}] sampled rows {n_rows}: max|hip-f64| {hip_t:.3e}, max|ref-f64| {ref_t:.3e}, rows with |hip-ref| > 1e-3: {n_hip_ref}, "
+          f"rows with |ref-f64| > 5e-4: {n_ref_t}")
+    return hip_t, ref_t, n_hip_ref, n_ref_t, n_rows
+
+
 def test_c2_full_batch_matches_reference_golden(golden, tmp_path):
     """BASELINE config 2: 256 lines @40x512 in ONE chunk (batch_size 274), W_pad 576, T 144.  Every line of the fixture
     was picked so that the reference's top-2 margin is >= 1e-3 on each of its 36 864 frames and the winners cover ~190 of
@@ -207,6 +225,27 @@ def test_c2_full_batch_matches_reference_golden(golden, tmp_path):
     assert not bad, f"argmax differs on lines {bad} (reference min top-2 margin {g.min_top2_margin:.2e})"
     assert worst < LOGIT_TOL, worst
     assert _check_full_tensor_stats(g, logits) < LOGIT_TOL
+    hip_t, _ref_t, n_hip_ref, _n, _rows = _check_truth_rows(g, logits, "c2")      # against exact arithmetic too
+    assert hip_t < LOGIT_TOL and n_hip_ref == 0
+
+
+def test_c2_unfiltered_lines_near_ties(golden, tmp_path):
+    """The UNFILTERED companion of c2 (64 consecutive crop indices, no margin selection: the reference's own top-2 margin goes
+    down to ~1e-6 on some frames).  The margin-gated rule: a frame's arg-max may differ from the reference only where the
+    reference's margin is below the logit noise (2e-4), and only on a handful of frames - a regression in the split
+    arithmetic's accuracy shows up here as a growing flip count instead of being filtered out by fixture selection."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    g = golden("c2u")
+    assert "crop_indices" not in g.meta and g.min_top2_margin < 2e-4
+    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=g.batch_size)
+    texts, logits, coords = eng.process_lines(g.crops(), sparse_logits=False)
+    flips = _check_against_golden(g, texts, logits, coords, exact_margin=2e-4)
+    near = int(np.sum(g.arrays["margin_all"] < 2e-4))
+    print(f"[c2u] frames {g.arrays['margin_all'].size}, reference margin < 2e-4 on {near}, arg-max differs on {flips}")
+    assert flips <= max(3, near // 4), flips
+    assert _check_full_tensor_stats(g, logits) < LOGIT_TOL
+    hip_t, ref_t, n_hip_ref, _n, _rows = _check_truth_rows(g, logits, "c2u")
+    assert hip_t < LOGIT_TOL and n_hip_ref == 0
 
 
 def test_run_ocr_padded_path_equals_ragged_path(golden, tmp_path):
@@ -361,6 +400,8 @@ def test_c4_full_batch_matches_reference_golden(golden, tmp_path):
     flips = _check_against_golden(g, texts, logits, coords, exact_margin=0.0)
     assert flips == 0 and texts == g.transcriptions
     assert _check_full_tensor_stats(g, logits) < LOGIT_TOL
+    hip_t, _ref_t, n_hip_ref, _n, _rows = _check_truth_rows(g, logits, "c4")
+    assert hip_t < LOGIT_TOL and n_hip_ref == 0
 
 
 def test_lstm_persistent_launch_matches_step_kernel(monkeypatch):
@@ -480,19 +521,22 @@ def test_c3_page_stream_over_rccl_matches_reference_golden(golden, tmp_path):
     texts, logits, coords = eng.process_lines(lines, sparse_logits=False)
     assert texts == g.transcriptions and coords == g.logit_coords
     # Logits.  On lines of 200+ frames the float32 REFERENCE is itself up to 1.1e-3 away from exact arithmetic on a few
-    # logits (oracle/gen_truth_rows.py; line 1530, class 63), so the fixture also holds the sampled rows computed in
-    # float64: this build must be within 1e-3 of THAT, and within 1e-3 of the reference plus the reference's own deviation.
-    worst_truth = worst_ref = 0.0
+    # logits (oracle/gen_truth_rows.py; line 1530, class 63), so the fixture also holds the sampled rows (8 per line: 16 384
+    # rows) computed in float64.  This build must be within 1e-3 of THAT, no further from it than the reference itself is,
+    # and the rows on which it is more than 1e-3 away from the reference are bounded by a COUNT: no more than the rows on
+    # which the reference is itself more than 5e-4 from exact arithmetic.  Every logit of the stream is covered by the
+    # full-tensor statistics (per class max / mean over the frames, per frame logsumexp, per line L2).
     for i in range(g.n):
-        li = np.asarray(logits[i])
-        assert np.array_equal(np.argmax(li, axis=1), g.argmax(i)), f"line {i}: per-frame argmax differs"
-        got, ref, truth = li[g.sample_rows[i]], g.rows(i), g.rows64(i)
-        worst_truth = max(worst_truth, float(np.max(np.abs(got - truth))))
-        worst_ref = max(worst_ref, float(np.max(np.abs(got - ref) - np.abs(ref - truth))))
-        l2 = float(np.sqrt(np.sum(li.astype(np.float64) ** 2)))
-        assert abs(l2 - g.l2(i)) < 1e-4 * max(1.0, l2)
-    assert worst_truth < LOGIT_TOL, worst_truth
-    assert worst_ref < LOGIT_TOL, worst_ref
+        assert np.array_equal(np.argmax(np.asarray(logits[i]), axis=1), g.argmax(i)), f"line {i}: per-frame argmax differs"
+    hip_t, ref_t, n_hip_ref, n_ref_t, _rows = _check_truth_rows(g, logits, "c3")
+    assert hip_t < LOGIT_TOL, hip_t
+    assert hip_t <= ref_t, (hip_t, ref_t)
+    assert n_hip_ref <= n_ref_t, (n_hip_ref, n_ref_t)
+    # the statistics are 1-Lipschitz in the max norm: the reference's own deviation from exact arithmetic (ref_t, measured
+    # above on the sampled rows) is the part of the difference that is not this build's
+    stats = _check_full_tensor_stats(g, logits)
+    print(f"[c3] full-tensor statistics: worst deviation from the reference {stats:.3e}")
+    assert stats < LOGIT_TOL + ref_t, stats
 
 
 def test_rccl_allgather_and_allreduce_world1():
@@ -504,7 +548,9 @@ def test_rccl_allgather_and_allreduce_world1():
     with pytest.raises(RuntimeError, match="no communicator"):
         eng.comm_world = 1
         eng.allgather_labels(np.arange(4, dtype=np.int32))
+    assert eng.comm_info() == (0, 0)                    # no communicator yet
     tr = sharding.init_rccl_from_env(eng, rank=0, world=1)
+    assert eng.comm_info() == (1, 0)                    # ncclCommCount / ncclCommUserRank of the communicator itself
     for count in (1, 7, 4096, 300000):
         send = (np.arange(count, dtype=np.int64) * 2654435761 % 100003).astype(np.int32)
         out = tr.allgather_i32(send)

@@ -153,3 +153,70 @@ def test_embeddings_layer_is_reachable_like_in_the_reference():
     view = pe._EmbeddingView(w)
     assert view.original_name == "Embedding" and view.weight.shape[0] - 1 == 3          # get_mean_embed_id's expression
     assert np.array_equal(next(view.parameters()).cpu().detach().numpy(), w)
+
+
+def test_plan_launches_are_balanced():
+    """every launch within one chunk's work of the mean - no shortfall piling up in the last launch (it sets the
+    activation high-water mark of a slot and the pipeline's tail)."""
+    from pero_ocr_amd import synth
+    for n in (47, 300, 2048, 8192):
+        widths = synth.make_widths(33, n)
+        chunks = line_ocr_engine.plan_chunks(widths, 480 * 8)
+        for target in (line_ocr_engine.LAUNCH_WORK_TARGET, 40000, 10 ** 9):
+            launches = line_ocr_engine.plan_launches(chunks, target)
+            assert [c for l in launches for c in l.chunks] == list(chunks)          # order kept, nothing lost
+            works = [l.work for l in launches]
+            total, biggest = sum(works), max(len(c.line_ids) * c.w_pad for c in chunks)
+            n_l = max(1, -(-total // target))
+            assert len(launches) <= n_l
+            assert max(works) <= total / n_l + biggest, (n, target, max(works), total / n_l, biggest)
+
+
+def test_bench_json_shape_for_rccl_and_gloo_fallback():
+    """a figure whose exchange ran over the gloo fallback must not be readable as the RCCL result."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    res = {"value": 123.0}
+    ok = bench.shape_rccl_fields(res, {"rccl_ranks": 8}, "rccl (pocr_allgather_labels, C ABI)")
+    assert ok == {"rccl_ranks": 8}
+    fb = bench.shape_rccl_fields(res, {"rccl_ranks": 0}, "gloo FALLBACK (RCCL communicator not available on every rank; this rank: x)")
+    assert fb["value"] is None and fb["value_gloo_fallback"] == 123.0 and fb["rccl_ranks"] == 0
+    single = bench.shape_rccl_fields(res, {"rccl_ranks": 0}, "none")
+    assert single == {"rccl_ranks": 0}
+    assert bench.conv_peak_tflops(2) == pytest.approx(2500.0 / 3) and bench.conv_peak_tflops(3) == pytest.approx(2500.0 / 6)
+    assert bench.conv_peak_tflops(0) == 157.3
+
+
+def test_resize_area_sparse_equals_dense_definition():
+    """The fractional INTER_AREA host resample (every page after the first takes it once the adaptive factor is remembered):
+    the separable sparse form equals the dense area-weight definition, and a 2000 x 1500 page takes well under a second."""
+    import time
+    from pero_ocr_amd.layout_engines.torch_parsenet import resize_area
+    rng = np.random.RandomState(3)
+
+    def dense(img, ds):
+        h, w = img.shape[:2]
+        oh, ow = int(np.rint(h / ds)), int(np.rint(w / ds))
+
+        def weights(n_in, n_out):
+            scale = n_in / n_out
+            m = np.zeros((n_out, n_in))
+            for o in range(n_out):
+                a, b = o * scale, min((o + 1) * scale, n_in)
+                for i in range(int(np.floor(a)), min(int(np.ceil(b)), n_in)):
+                    m[o, i] = min(b, i + 1) - max(a, i)
+                m[o] /= m[o].sum()
+            return m
+        out = np.einsum("oh,hwc->owc", weights(h, oh), img.astype(np.float64))
+        out = np.einsum("pw,owc->opc", weights(w, ow), out)
+        return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    for h, w, ds in ((120, 200, 3.3), (97, 131, 1.7), (64, 64, 1.01), (201, 77, 4.6)):
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        assert np.array_equal(resize_area(img, ds), dense(img, ds)), (h, w, ds)
+    page = rng.randint(0, 256, (1500, 2000, 3)).astype(np.uint8)
+    t0 = time.perf_counter()
+    out = resize_area(page, 3.3)
+    assert out.shape == (455, 606, 3)
+    assert time.perf_counter() - t0 < 3.0          # (was 4.9 s with dense [n_out, n_in] matrices; ~0.2 s now)

@@ -64,6 +64,20 @@ def _worker(rank, world, port, out_dir):
         few = sharding.ShardedLineOCR(_fake_recognise, chars, 480 * 64).process_lines(lines[:3])
         # sequence-to-sequence engine: whole reference batches per rank, transcriptions gathered as code points
         s2s = sharding.ShardedSeq2SeqOCR(_fake_s2s, 480 * 4, 1024).process_lines(lines)
+        # one rank fails inside its share: it must still take part in the collective and BOTH ranks must raise
+        def failing(lines_, chunk):
+            if rank == 1:
+                raise ValueError("device lost (simulated)")
+            return _fake_recognise(lines_, chunk)
+        try:
+            sharding.ShardedLineOCR(failing, chars, 480 * 8).process_lines(lines)
+            outcome = "returned"
+        except ValueError as exc:
+            outcome = f"own:{exc}"
+        except RuntimeError as exc:
+            outcome = f"peer:{exc}"
+        with open(os.path.join(out_dir, f"fail{rank}.txt"), "w") as f:
+            f.write(outcome)
         np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array(texts + few, dtype=object), allow_pickle=True)
         np.save(os.path.join(out_dir, f"s{rank}.npy"), np.array(s2s, dtype=object), allow_pickle=True)
     finally:
@@ -81,6 +95,9 @@ def test_gloo_world2_allgather_labels(tmp_path):
     r0 = np.load(tmp_path / "r0.npy", allow_pickle=True).tolist()
     r1 = np.load(tmp_path / "r1.npy", allow_pickle=True).tolist()
     assert r0 == r1 and all(t is not None for t in r0)
+    # the simulated failure on rank 1: neither rank hangs or returns a partial result
+    assert (tmp_path / "fail1.txt").read_text().startswith("own:device lost")
+    assert (tmp_path / "fail0.txt").read_text().startswith("peer:rank(s) [1] failed")
     # single-process expectation
     widths = [300, 17, 641, 640, 300, 1, 1290, 96, 33, 512, 300, 3900, 1000, 64, 257, 2000] * 3
     lines = synth.make_crops(4, widths)

@@ -18,13 +18,49 @@ static void launch(K kern, int TH, int TW, int NT, ConvArgs a, hipStream_t st) {
     a.tiles_w = (a.Wo + TW - 1) / TW; a.tiles_h = (a.Ho + TH - 1) / TH; a.tiles_n = (a.cout16 * 16) / NT;
     hipLaunchKernelGGL(kern, dim3((unsigned)conv_grid_blocks(a)), dim3(256), 0, st, a);
 }
-struct Variant { const char *name; void (*fn)(ConvArgs, hipStream_t); int nt; bool bf; };
+struct Variant { const char *name; void (*fn)(ConvArgs, hipStream_t); int nt; int bf; };     // bf: 0 fp32 MFMA, 1 / 3 bf16x3, 2 f16x2
 #define VF32(NAME, TH, MW, NS, PH, PW, ACT, BN, PIPE) static void NAME(ConvArgs a, hipStream_t st) { \
     launch(conv_igemm_kernel<3, 3, 1, 1, TH, MW, NS, 4, 16, PH, PW, ACT, BN, STAGE_F32_NHWC, PIPE>, TH, 16 * MW, NS * 64, a, st); }
 #define VBF(NAME, TH, MW, NS, WM, PH, PW, ACT, BN, MINW) static void NAME(ConvArgs a, hipStream_t st) { \
     launch(conv3x3_bf16x3_kernel<TH, MW, NS, WM, PH, PW, ACT, BN, MINW>, TH, 16 * MW, NS * (4 / WM) * 16, a, st); }
 #define VBD(NAME, TH, MW, NS, WM, PH, PW, ACT, BN, MINW) static void NAME(ConvArgs a, hipStream_t st) { \
     launch(conv3x3_bf16x3_kernel<TH, MW, NS, WM, PH, PW, ACT, BN, MINW, true>, TH, 16 * MW, NS * (4 / WM) * 16, a, st); }
+// f16x2 (two f16 planes, three MFMAs per product block): LDS weights / weights straight from L2
+#define VH(NAME, TH, MW, NS, WM, PH, PW, ACT, BN, MINW) static void NAME(ConvArgs a, hipStream_t st) { \
+    launch(conv3x3_bf16x3_kernel<TH, MW, NS, WM, PH, PW, ACT, BN, MINW, false, 3, 3, 1, 1, false, 2>, TH, 16 * MW, NS * (4 / WM) * 16, a, st); }
+#define VHD(NAME, TH, MW, NS, WM, PH, PW, ACT, BN, MINW) static void NAME(ConvArgs a, hipStream_t st) { \
+    launch(conv3x3_bf16x3_kernel<TH, MW, NS, WM, PH, PW, ACT, BN, MINW, true, 3, 3, 1, 1, false, 2>, TH, 16 * MW, NS * (4 / WM) * 16, a, st); }
+VHD(h9_a, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2)      // as shipped bf16x3 conv9: 5x16, NT128, 2 WG/CU
+VHD(h9_b, 5, 2, 2, 1, 1, 1, ACT_LEAKY, true, 2)      // 5x32: MS 10
+VHD(h9_c, 5, 2, 2, 1, 1, 1, ACT_LEAKY, true, 1)
+VHD(h9_d, 5, 1, 4, 1, 1, 1, ACT_LEAKY, true, 1)      // NT256, MS 5, NS 4
+VHD(h9_e, 5, 1, 4, 1, 1, 1, ACT_LEAKY, true, 2)
+VHD(h9_f, 5, 3, 1, 1, 1, 1, ACT_LEAKY, true, 2)      // 5x48 (144 = 3 x 48), NS 1, NT 64: MS 15
+VHD(h9_g, 5, 3, 2, 1, 1, 1, ACT_LEAKY, true, 1)      // 5x48, NS 2: MS 15 (240 accumulator registers)
+VH(h9_h, 5, 2, 4, 2, 1, 1, ACT_LEAKY, true, 2)       // LDS weights, 5x32, waves 2 x 2, NT 128
+VH(h9_i, 5, 4, 4, 4, 1, 1, ACT_LEAKY, true, 2)       // LDS weights, 5x64, waves split pixels, NT 64
+VH(h9_j, 5, 3, 4, 1, 1, 1, ACT_LEAKY, true, 1)       // LDS weights 5x48 NT256 N-split: MS 15, NS 4 ...
+VHD(h6_a, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2)
+VHD(h6_b, 10, 1, 2, 1, 1, 1, ACT_RELU, false, 2)     // MS 10
+VHD(h6_c, 5, 2, 2, 1, 1, 1, ACT_RELU, false, 2)
+VHD(h6_d, 10, 1, 4, 1, 1, 1, ACT_RELU, false, 1)
+VHD(h8_a, 5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2)
+VHD(h8_b, 5, 2, 2, 1, 1, 1, ACT_LEAKY, false, 2)
+VHD(h7_a, 2, 2, 2, 1, 2, 1, ACT_RELU, false, 2)
+VHD(h7_b, 10, 1, 2, 1, 2, 1, ACT_RELU, false, 2)
+VHD(h7_c, 2, 4, 2, 1, 2, 1, ACT_RELU, false, 2)
+VHD(h4_a, 4, 1, 2, 1, 2, 2, ACT_RELU, false, 2)
+VHD(h4_b, 4, 2, 2, 1, 2, 2, ACT_RELU, false, 2)
+VHD(h4_c, 4, 2, 2, 1, 2, 2, ACT_RELU, false, 3)
+VHD(h3_a, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2)
+VHD(h3_b, 4, 2, 2, 1, 1, 1, ACT_RELU, false, 2)
+VHD(h3_c, 4, 2, 2, 1, 1, 1, ACT_RELU, false, 3)
+VH(h2_a, 4, 2, 2, 2, 2, 2, ACT_RELU, false, 2)
+VH(h2_b, 4, 2, 2, 2, 2, 2, ACT_RELU, false, 3)
+VHD(h2_c, 4, 2, 2, 2, 2, 2, ACT_RELU, false, 2)
+VHD(h2_d, 4, 4, 2, 2, 2, 2, ACT_RELU, false, 2)
+VHD(h2_e, 8, 2, 2, 2, 2, 2, ACT_RELU, false, 2)
+VHD(h2_f, 4, 4, 4, 4, 2, 2, ACT_RELU, false, 2)      // 4x64 px, all four waves share the 64 channels: NS 4, MS 4
 VBD(d9_a, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2)      // direct weights, 5x16 px, NT128, 2 WG/CU
 VBD(d9_b, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 3)      // 3 WG/CU
 VBD(d9_c, 5, 1, 4, 1, 1, 1, ACT_LEAKY, true, 1)      // NT256
@@ -135,6 +171,25 @@ int main(int argc, char **argv) {
                             {"direct-B 8x32 NT64 2x2", d2_c, 64, true}, {"direct-B 4x64 NT64 2x2", d2_d, 64, true},
                             {"bf16x3 4x32 NT64 2x2 2WG", b2_f, 64, true}, {"direct-B 4x32 NT64 2x2 2WG", d2_f, 64, true}, {"bf16x3 4x32 NT64 2x2 3WG", b2_g, 64, true}};
     else { printf("layer %d not covered\n", layer); return 1; }
+    if (!getenv("ALLBF")) {            // default: the fp32 kernel, the shipped bf16x3 configuration, and the f16x2 candidates
+        std::vector<Variant> keep = {vars[0]};
+        const char *shipped[10] = {"", "", "bf16x3 4x32 NT64 2x2 2WG", "direct-B 5x16 NT128 2WG", "direct-B 4x16 NT128 2WG", "direct-B 5x16 NT128 2WG",
+                                   "direct-B 5x16 NT128 2WG", "direct-B 2x32 NT128 2WG", "direct-B 5x16 NT128 2WG", "direct-B 5x16 NT128 2WG"};
+        for (auto &v : vars) if (!strcmp(v.name, shipped[layer])) keep.push_back(v);
+        vars = keep;
+        if (layer == 9) { vars.insert(vars.end(), {{"f16x2 direct 5x16 NT128 2WG", h9_a, 128, 2}, {"f16x2 direct 5x32 NT128 2WG", h9_b, 128, 2}, {"f16x2 direct 5x32 NT128 1WG", h9_c, 128, 2},
+                                  {"f16x2 direct 5x16 NT256 1WG", h9_d, 256, 2}, {"f16x2 direct 5x16 NT256 2WG", h9_e, 256, 2}, {"f16x2 direct 5x48 NT64 2WG", h9_f, 64, 2},
+                                  {"f16x2 direct 5x48 NT128 1WG", h9_g, 128, 2}, {"f16x2 lds 5x32 NT128 2x2 2WG", h9_h, 128, 2}, {"f16x2 lds 5x64 NT64 M-split 2WG", h9_i, 64, 2},
+                                  {"f16x2 lds 5x48 NT256 1WG", h9_j, 256, 2}}); }
+        if (layer == 8) vars.insert(vars.end(), {{"f16x2 direct 5x16 NT128 2WG", h8_a, 128, 2}, {"f16x2 direct 5x32 NT128 2WG", h8_b, 128, 2}});
+        if (layer == 6 || layer == 5) vars.insert(vars.end(), {{"f16x2 direct 5x16 NT128 2WG", h6_a, 128, 2}, {"f16x2 direct 10x16 NT128 2WG", h6_b, 128, 2},
+                                  {"f16x2 direct 5x32 NT128 2WG", h6_c, 128, 2}, {"f16x2 direct 10x16 NT256 1WG", h6_d, 256, 2}});
+        if (layer == 7) vars.insert(vars.end(), {{"f16x2 direct 2x32 NT128 2WG", h7_a, 128, 2}, {"f16x2 direct 10x16 NT128 2WG", h7_b, 128, 2}, {"f16x2 direct 2x64 NT128 2WG", h7_c, 128, 2}});
+        if (layer == 4) vars.insert(vars.end(), {{"f16x2 direct 4x16 NT128 2WG", h4_a, 128, 2}, {"f16x2 direct 4x32 NT128 2WG", h4_b, 128, 2}, {"f16x2 direct 4x32 NT128 3WG", h4_c, 128, 2}});
+        if (layer == 3) vars.insert(vars.end(), {{"f16x2 direct 5x16 NT128 2WG", h3_a, 128, 2}, {"f16x2 direct 4x32 NT128 2WG", h3_b, 128, 2}, {"f16x2 direct 4x32 NT128 3WG", h3_c, 128, 2}});
+        if (layer == 2) vars.insert(vars.end(), {{"f16x2 lds 4x32 NT64 2x2 2WG", h2_a, 64, 2}, {"f16x2 lds 4x32 NT64 2x2 3WG", h2_b, 64, 2}, {"f16x2 direct 4x32 NT64 2x2", h2_c, 64, 2},
+                                  {"f16x2 direct 4x64 NT64 2x2", h2_d, 64, 2}, {"f16x2 direct 8x32 NT64 2x2", h2_e, 64, 2}, {"f16x2 direct 4x64 NT64 M-split NS4", h2_f, 64, 2}});
+    }
     const size_t xin = (size_t)n * s.H * s.W * s.cin;
     const int Hout = s.H / s.ph, Wout = s.W / s.pw;
     const size_t yout = (size_t)n * Hout * Wout * s.cout;
@@ -211,6 +266,19 @@ int main(int argc, char **argv) {
                     hw[o] = co < s.cout ? W(co, ci, tap) : 0.f;
                 }
             CK(hipMemcpy(dw, hw.data(), o * 4, hipMemcpyHostToDevice));
+        } else if (vars[vi].bf == 2) {
+            std::vector<uint16_t> hw((size_t)9 * (s.cin / 32) * cout16 * 2 * 64 * 8);
+            size_t o = 0;
+            for (int tap = 0; tap < 9; ++tap) for (int g = 0; g < s.cin / 32; ++g) for (int sg = 0; sg < cout16; ++sg)
+                for (int pl = 0; pl < 2; ++pl) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j, ++o) {
+                    const int co = 16 * sg + (lane & 15), ci = 32 * g + 8 * (lane >> 4) + j;
+                    const float w = co < s.cout ? W(co, ci, tap) : 0.f;
+                    const _Float16 h = (_Float16)w;
+                    const _Float16 l = (_Float16)((w - (float)h) * 2048.0f);
+                    const _Float16 v = pl ? l : h;
+                    memcpy(&hw[o], &v, 2);
+                }
+            CK(hipMemcpy(dw, hw.data(), o * 2, hipMemcpyHostToDevice));
         } else {
             std::vector<uint16_t> hw((size_t)9 * (s.cin / 32) * cout16 * 3 * 64 * 8);
             size_t o = 0;
