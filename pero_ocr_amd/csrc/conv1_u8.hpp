@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_igemm.hpp"
+#include "conv_bf16x3.hpp"
 
 namespace pocr {
 
@@ -28,6 +29,8 @@ struct Conv1Args {
     int32_t src_h;               // rows the crops really have (0: = H); rows [src_h, H) are zero padding (layout network pages)
 };
 
+// P2OUT: the output is written in the pre-split f16x2 layout conv2 stages by plain copies (conv_bf16x3.hpp, "P2").
+template <bool P2OUT = false>
 __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
     constexpr int TH = 4, TW = 32, HH = TH + 2, HW = TW + 2, NH = HH * HW * 3;
     __shared__ float halo[NH + 4];                    // [row][col][c]; halo[NH] = 0 backs the k >= 27 padding
@@ -89,6 +92,16 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
             for (int r = 0; r < 4; ++r) { const float t = acc[r] + bias; v[r] = t > 0.f ? t : 0.f; }
             quad_transpose(v, lane);                     // now: pixel 4*kq + (li & 3), channels 16*wave + 4*(li >> 2) + 0..3
             const int wc = w0 + mw * 16 + kq * 4 + (li & 3);
+            if constexpr (P2OUT) {
+                if (wc < Wp) {
+                    u32x2 hh, ll;
+                    split2_quad((f32x4){v[0], v[1], v[2], v[3]}, hh, ll);
+                    u32x2 *d = reinterpret_cast<u32x2 *>(reinterpret_cast<char *>(yimg + ((size_t)ho * Wp + wc) * 64) +
+                                                         p2_channel_bytes(wave * 16 + 4 * (li >> 2)));
+                    d[0] = hh; d[8] = ll;
+                }
+                continue;
+            }
             if (wc < Wp)
                 *reinterpret_cast<f32x4 *>(yimg + ((size_t)ho * Wp + wc) * 64 + wave * 16 + 4 * (li >> 2)) =
                     (f32x4){v[0], v[1], v[2], v[3]};

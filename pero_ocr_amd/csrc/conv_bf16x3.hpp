@@ -24,6 +24,9 @@
 #ifndef POCR_BF16X3_SCHED
 #define POCR_BF16X3_SCHED 1            // issue-order templates (sched_group_barrier) in the main loops: -2 ... -9 % per layer, same arithmetic
 #endif
+#ifndef POCR_STA_TAP
+#define POCR_STA_TAP (NTAP / 2)        // tap after which the next chunk's halo tile (requested at tap 0) is written to the other LDS buffer
+#endif
 #ifndef POCR_BF16X3_DBG
 #define POCR_BF16X3_DBG 0            // tools/conv_bench_bf16.hip: 1 no A reads, 2 no weight loads, 4 no A staging, 8 no barrier
 #endif
@@ -100,6 +103,20 @@ __device__ __forceinline__ void split2_quad(const f32x4 p, u32x2 &hi, u32x2 &lo)
     lo = (u32x2){__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
 }
 
+// ---- P2: activations kept in HBM already split ("pre-split", f16x2 only).  The two-plane f16 representation of a value
+// takes exactly the four bytes of the fp32 it replaces, so a producer's epilogue can split ONCE per output value and every
+// consumer's stager becomes a plain 16-byte copy HBM -> LDS: no split arithmetic and no fp32 staging registers in the main
+// loop (measured: the in-loop staging is 12 % of conv9), and each halo tile is no longer re-split by every channel-tile
+// workgroup that reads it.  Layout of a pixel with C channels (C % 32 == 0), 4 C bytes as before:
+//     for each 32-channel chunk g:  [h of channels 32 g .. 32 g + 31 : 32 x f16][l of the same channels : 32 x f16]
+// i.e. a chunk is 128 contiguous bytes = the eight 16-byte units (plane, channel octet) the MFMA A operands are made of.
+// Offsets and sizes of lines / pixels are those of the fp32 layout, so the geometry tables and pad_fill_kernel do not change.
+__device__ __forceinline__ void split2_scalar(float v, _Float16 &h, _Float16 &l) {
+    h = (_Float16)v;
+    l = (_Float16)((v - (float)h) * kF16x2Scale);
+}
+__device__ __forceinline__ size_t p2_channel_bytes(int c) { return (size_t)(c >> 5) * 128 + (size_t)(c & 31) * 2; }   // plane h; plane l at + 64
+
 // Issue-order template for the scheduler (LDS-weights loop): the G operand reads of a step spread evenly between its TOT MFMAs.
 template <int G, int TOT, int... I>
 __device__ __forceinline__ void sched_template_lds(std::integer_sequence<int, I...>) {
@@ -131,8 +148,11 @@ __device__ __forceinline__ void sched_template_dir(std::integer_sequence<int, I.
 // UPCAT: the input is the virtual tensor cat([nearest-upsample-x2(x), x2], channels) of the layout network's decoder
 // (conv_igemm.hpp STAGE_UPCAT): 32-channel chunks below cin_up come from x at half resolution, the rest from the skip tensor.
 template <int TH, int MW, int NS, int WM, int POOLH, int POOLW, int ACT, bool BN, int MINW = 1, bool BDIR = false,
-          int KH = 3, int KW = 3, int PADH = 1, int PADW = 1, bool UPCAT = false, int SPL = 3>
+          int KH = 3, int KW = 3, int PADH = 1, int PADW = 1, bool UPCAT = false, int SPL = 3, bool PRE_IN = false, bool PRE_OUT = false>
 __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
+    // PRE_IN: the input is in the P2 (pre-split) layout; PRE_OUT: the epilogue writes that layout (both f16x2 only)
+    static_assert(!(PRE_IN || PRE_OUT) || SPL == 2, "the pre-split activation layout is the f16x2 representation");
+    static_assert(!(PRE_IN && UPCAT), "the layout network keeps fp32 activations");
     // SPL = planes per operand: 3 = bf16x3 (six MFMAs per 32-deep product block), 2 = f16x2 (three)
     static_assert(SPL == 2 || SPL == 3, "operand split: 3 bf16 planes or 2 f16 planes");
     constexpr int NWAVE = 4, WN = NWAVE / WM, KC = 32, NTAP = KH * KW, WU = SPL * 64, NMF = SPL == 3 ? 6 : 3;
@@ -143,7 +163,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     constexpr int PS = 4 * NPPAD;                       // 16-byte units per bf16 plane of the A tile ([octet][pixel])
     constexpr int A_U = SPL * PS;                       // A tile (single-buffered, refilled once per chunk; BDIR: two of them)
     constexpr int B_F4 = BDIR ? 0 : (NT / 16) * WU;     // 16-byte units per B buffer (one (chunk, tap) step)
-    constexpr int A_LD = (CQ * NP + NTHR - 1) / NTHR;
+    constexpr int NP8 = (NP + 7) / 8 * 8;               // PRE_IN: 64 consecutive staging slots = 8 pixels x 8 sixteen-byte units
+    constexpr int A_LD = PRE_IN ? (8 * NP8 + NTHR - 1) / NTHR : (CQ * NP + NTHR - 1) / NTHR;
     constexpr int B_LD = BDIR ? 1 : (B_F4 + NTHR - 1) / NTHR;
     static_assert(POOLH == 1 || TH % 2 == 0, "H-pool needs an even tile height");
     __shared__ u32x4 lds[BDIR ? 2 * A_U : A_U + 2 * B_F4];      // one scalar type (unsigned) for every access: no type punning
@@ -202,6 +223,18 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < A_LD; ++r) {
         const int e = tid + r * NTHR;
+        if constexpr (PRE_IN) {
+            // Slot e: eight consecutive lanes take the same unit u = (plane, octet) of eight consecutive halo pixels (their
+            // ds_write_b128 fill 128 contiguous bytes of one LDS row: conflict-free), the eight lane groups of a wave the
+            // eight units of those pixels (each pixel's 128-byte chunk is read whole by one wave instruction).
+            const int l = e & 63, p = (e >> 6) * 8 + (l & 7), u = l >> 3;
+            const int hr = p / HW, wc = p % HW;
+            const int hi = h0 - PADH + hr, wi = w0 - PADW + wc;
+            a_ok[r] = p < NP && hi >= 0 && hi < a.H && wi >= 0 && wi < Win;
+            a_off[r] = a_ok[r] ? (unsigned)((hi * Win + wi) * (a.cin >> 2) + u) : 0u;          // 16-byte units; a chunk adds 8
+            a_lds[r] = p < NP ? (u >> 2) * PS + (u & 3) * NPPAD + p : -1;                       // 16-byte units
+            continue;
+        }
         const int cq = e % CQ, p = e / CQ;
         const int hr = p / HW, wc = p % HW;
         const int hi = h0 - PADH + hr, wi = w0 - PADW + wc;
@@ -223,6 +256,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     auto ldA = [&](int chunk) {
 #pragma unroll
         for (int r = 0; r < A_LD; ++r) {
+            if constexpr (PRE_IN) {
+                ra[r] = a_ok[r] ? reinterpret_cast<const f32x4 *>(ximg)[a_off[r] + chunk * 8] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
             const float *src = ximg + chunk * KC + a_off[r];
             if constexpr (UPCAT) { if (chunk >= nch_up) src = ximg2 + (chunk - nch_up) * KC + a_off2[r]; }
             ra[r] = a_ok[r] ? *reinterpret_cast<const f32x4 *>(src) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -233,6 +270,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < A_LD; ++r)
             if (a_lds[r] >= 0) {
+                if constexpr (PRE_IN) {                 // already split by the producer: a 16-byte copy
+                    ldsA[abuf * A_U + a_lds[r]] = __builtin_bit_cast(u32x4, ra[r]);
+                    continue;
+                }
                 if constexpr (SPL == 3) {
                     u32x2 hi, mid, lo;
                     split3_quad(ra[r], hi, mid, lo);
@@ -354,7 +395,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                 sched_template_dir<MS * SPL, MS * NS * NMF, NS * SPL>(std::make_integer_sequence<int, MS * SPL>{});
 #endif
 #if !(POCR_BF16X3_DBG & 4)
-                if (tap == NTAP / 2) stA(abuf ^ 1);       // the other A buffer: its last readers passed the barrier of the previous chunk
+                if (tap == POCR_STA_TAP) stA(abuf ^ 1);   // the other A buffer: its last readers passed the barrier of the previous chunk
 #endif
             }
 #if !(POCR_BF16X3_DBG & 8)
@@ -462,6 +503,32 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                 const int ho = (h0 + th) / POOLH;
                 const int wbase = w0 + (wm * MWW + mw) * 16 + kq * 4;
                 float *yrow = a.y + out_base + ((size_t)ho * Wout) * a.out_stride + co;
+                if constexpr (PRE_OUT) {                // P2 layout: every value split here, once (cout % 32 == 0, all valid)
+                    char *prow = reinterpret_cast<char *>(a.y + out_base + ((size_t)ho * Wout) * a.out_stride);
+                    const size_t pix_bytes = (size_t)a.out_stride * 4;
+                    if constexpr (POOLW == 2) {
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) {
+                            const int wc = wbase + 2 * rr;
+                            if (h0 + th < a.Ho && wc + 1 < Wo) {
+                                _Float16 hh, ll;
+                                split2_scalar(fmaxf(v[2 * rr], v[2 * rr + 1]), hh, ll);
+                                _Float16 *d = reinterpret_cast<_Float16 *>(prow + (size_t)(wc / 2) * pix_bytes + p2_channel_bytes(co));
+                                d[0] = hh; d[32] = ll;
+                            }
+                        }
+                    } else {
+                        quad_transpose(v, lane);
+                        const int wc = wbase + (li & 3), c4 = co - (li & 3);
+                        if (wc < Wo && h0 + th < a.Ho) {
+                            u32x2 hh, ll;
+                            split2_quad((f32x4){v[0], v[1], v[2], v[3]}, hh, ll);
+                            u32x2 *d = reinterpret_cast<u32x2 *>(prow + (size_t)wc * pix_bytes + p2_channel_bytes(c4));
+                            d[0] = hh; d[8] = ll;
+                        }
+                    }
+                    continue;
+                }
                 if constexpr (POOLW == 2) {
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr) {

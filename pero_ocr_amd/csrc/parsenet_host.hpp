@@ -210,7 +210,7 @@ int pocr_parsenet_get_maps(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, 
         c1.wfrag = p->enc[0].w.as<float>(); c1.bias = p->enc[0].b.as<float>(); c1.y = p->x[0].as<float>();
         c1.tiles = p->tiles.as<PixelTile>(); c1.line_w = p->wline.as<int32_t>(); c1.out_off = p->ooff.as<int64_t>();
         c1.H = Hp; c1.n_ptiles = (int)tiles.size(); c1.src_h = h;
-        hipLaunchKernelGGL(conv1_u8_kernel, dim3(c1.n_ptiles), dim3(256), 0, st, c1);
+        hipLaunchKernelGGL(conv1_u8_kernel<false>, dim3(c1.n_ptiles), dim3(256), 0, st, c1);
         HIP_TRY(hipGetLastError());
     }
     auto conv = [&](int (*fn)(ConvArgs, hipStream_t), const PnLayer &L, const float *x, const float *x2, int cin_up, float *y, int Hc, int Wc) {

@@ -195,6 +195,32 @@ POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true, 2)    // 512->
         return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT, false, MINW, BDIR, KH, 1, 0, 0>, TH,    \
                            16 * MW, NS * (4 / WM) * 16, 256, a, st);                                               \
     }
+// f16x2 with PRE-SPLIT activations (conv_bf16x3.hpp "P2"): the recogniser's conv stack in the default mode.  conv1 writes
+// the two-plane layout, conv2 .. conv9 read and write it (stager = 16-byte copies), the aggregation conv reads it and
+// writes fp32 features for the sequence model.
+#define POCR_CONVP(name, TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW, BDIR)                                        \
+    int name(ConvArgs a, hipStream_t st) {                                                                         \
+        return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW, BDIR, 3, 3, 1, 1, false, 2, true, true>, \
+                           TH, 16 * MW, NS * (4 / WM) * 16, 256, a, st);                                           \
+    }
+POCR_CONVP(conv2_p2,  4, 2, 2, 2, 2, 2, ACT_RELU, false, 3, false)
+POCR_CONVP(conv3_p2,  5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
+POCR_CONVP(conv4_p2,  4, 1, 2, 1, 2, 2, ACT_RELU, false, 2, true)
+POCR_CONVP(conv56_p2, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
+POCR_CONVP(conv7_p2,  2, 2, 2, 1, 2, 1, ACT_RELU, false, 2, true)
+POCR_CONVP(conv8_p2,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true)
+POCR_CONVP(conv9_p2,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true)
+#define POCR_CONVPG(name, TH, MW, NS, WM, ACT, MINW, KH, BDIR)                                                      \
+    int name(ConvArgs a, hipStream_t st) {                                                                         \
+        return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT, false, MINW, BDIR, KH, 1, 0, 0, false, 2, true, false>, TH, \
+                           16 * MW, NS * (4 / WM) * 16, 256, a, st);                                               \
+    }
+// 48 pixels x 128 channels, weights straight from L2, two workgroups per CU: 0.44 ms per c2 launch against 0.65 with the
+// 48 x 256 LDS-weights configuration of the bf16x3 build and 0.57 / 0.51 / 0.78 for NT 256 / three workgroups / 80-pixel tiles
+POCR_CONVPG(agg4_p2, 1, 3, 2, 1, ACT_LEAKY, 2, 4, true)
+POCR_CONVPG(agg5_p2, 1, 3, 2, 1, ACT_LEAKY, 2, 5, true)
+POCR_CONVPG(agg6_p2, 1, 3, 2, 1, ACT_LEAKY, 2, 6, true)
+POCR_CONVPG(agg8_p2, 1, 3, 2, 1, ACT_LEAKY, 2, 8, true)
 // decoder convs of the layout network: virtual cat(up2(x), skip) input
 #define POCR_CONV3U(name, TH, MW, NS, WM, MINW, BDIR)                                                               \
     int name(ConvArgs a, hipStream_t st) {                                                                         \
@@ -316,6 +342,7 @@ struct Slot {
     size_t sp_pinned_cap = 0;
     // profiling
     hipEvent_t ev[POCR_NUM_STAGES + 1]{};
+    hipEvent_t ev_conv_end = nullptr;         // end of the aggregation conv on the conv stream (the sequence stage may start later: deferred)
     float stage_ms[POCR_NUM_STAGES]{};
     bool have_ms = false;
     // BiLSTM recurrence as replayable hipGraphs: key (layer, T, slice bucket) -> 2 memsets + T step launches.
@@ -340,6 +367,7 @@ struct Slot {
     // latency-bound sequence tail of the previous chunk shares the chip with them
     hipEvent_t conv_done = nullptr;
     bool conv_done_valid = false;
+
     // sequence-to-sequence decoding (POCR_ARCH_S2S, decoder.hpp)
     std::vector<DevBuf> s2s_kv, s2s_cache;   // per decoder layer: projected encoder output [rows][2E]; self cache [S_cap][n][3E]
     DevBuf s2s_x, s2s_x1, s2s_x2, s2s_t, s2s_ctx, s2s_q, s2s_ff, s2s_logits, s2s_tokens, s2s_state, s2s_tables;
@@ -385,6 +413,7 @@ struct pocr_engine {
     bool lstm_wide = false;          // POCR_LSTM_WIDE=1: recurrence step with four 16-line slices per workgroup (lstm_step_wide_kernel);
                                      // measured: a quarter of the workgroups and less disturbance of the first convs, but 18 us
                                      // instead of 12 us per step and 64 KB of LDS that conv2's workgroups leave no room for - slower in all
+    bool p2 = false;                 // f16x2 with pre-split activations between conv1 and the aggregation conv (conv_bf16x3.hpp "P2"; POCR_NO_P2=1: split in every consumer)
     bool bf16x3 = true;              // conv2..conv9 on the bf16 matrix pipe with the exact 3-way operand split (POCR_CONV_FP32=1: fp32 MFMA)
     DevBuf cconst[9];                // per conv layer: the output column [H_out][cout] far inside zero padding
     bool pad_skip = false;           // skip + fill constant padding tiles (POCR_NO_PAD_SKIP=1 turns it off)
@@ -471,6 +500,7 @@ int run_network(pocr_engine *e, Slot &s) {
     const int n = s.n, H = c.height;
     const bool prof = e->profiling;
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(s.ev[i], st); };
+    const int T = s.t_max, E = c.conv_out, AH = H / 8, rows = s.rows;
 
     // ---- conv stack (after the previous launch's backbone, if that ran on another slot)
     {
@@ -512,12 +542,25 @@ int run_network(pocr_engine *e, Slot &s) {
             c1.wfrag = e->conv_w[0].as<float>(); c1.bias = e->conv_b[0].as<float>(); c1.y = s.act[0].as<float>();
             c1.tiles = s.g_tiles[0]; c1.line_w = s.g_lvl_w[0]; c1.out_off = s.g_act_off[0];
             c1.H = h; c1.n_ptiles = s.g_ntiles[0];
-            if (c1.n_ptiles > 0) hipLaunchKernelGGL(conv1_u8_kernel, dim3(c1.n_ptiles), dim3(256), 0, st, c1);
+            if (c1.n_ptiles > 0) {
+                if (e->p2) hipLaunchKernelGGL(conv1_u8_kernel<true>, dim3(c1.n_ptiles), dim3(256), 0, st, c1);
+                else hipLaunchKernelGGL(conv1_u8_kernel<false>, dim3(c1.n_ptiles), dim3(256), 0, st, c1);
+            }
             HIP_TRY(hipGetLastError());
         } else {
             a.x = s.act[i - 1].as<float>(); a.cin = L.cin;
             if (i == 8) { a.bn_scale = e->bn_scale.as<float>(); a.bn_shift = e->bn_shift.as<float>(); }
-            if (e->bf16x3) {
+            if (e->p2) {
+                switch (i) {
+                    case 1: rc = conv2_p2(a, st); break;
+                    case 2: rc = conv3_p2(a, st); break;
+                    case 3: rc = conv4_p2(a, st); break;
+                    case 4: case 5: rc = conv56_p2(a, st); break;
+                    case 6: rc = conv7_p2(a, st); break;
+                    case 7: rc = conv8_p2(a, st); break;
+                    default: rc = conv9_p2(a, st); break;
+                }
+            } else if (e->bf16x3) {
                 switch (i) {
                     case 1: rc = conv2_b3(a, st); break;
                     case 2: rc = conv3_b3(a, st); break;
@@ -544,7 +587,6 @@ int run_network(pocr_engine *e, Slot &s) {
         s.act_h[i] = h; s.act_c[i] = L.cout;
     }
     // ---- aggregation conv: line i [H/8][T_i][512] -> rows row_off[i] .. of feat [rows][E]
-    const int T = s.t_max, E = c.conv_out, AH = h, rows = s.rows;
     {
         if (s.feat.reserve((size_t)rows * E * sizeof(float))) return 1;
         ConvArgs a{};
@@ -555,7 +597,8 @@ int run_network(pocr_engine *e, Slot &s) {
         a.wfrag = e->agg_w.as<float>(); a.bias = e->agg_b.as<float>(); a.y = s.feat.as<float>();
         mark(POCR_STAGE_AGG);
         int rc;
-        if (e->b3_weights.count(e->agg_w.p)) rc = AH == 4 ? agg4_b3(a, st) : AH == 5 ? agg5_b3(a, st) : AH == 6 ? agg6_b3(a, st) : agg8_b3(a, st);
+        if (e->p2) rc = AH == 4 ? agg4_p2(a, st) : AH == 5 ? agg5_p2(a, st) : AH == 6 ? agg6_p2(a, st) : agg8_p2(a, st);
+        else if (e->b3_weights.count(e->agg_w.p)) rc = AH == 4 ? agg4_b3(a, st) : AH == 5 ? agg5_b3(a, st) : AH == 6 ? agg6_b3(a, st) : agg8_b3(a, st);
         else rc = AH == 4 ? agg4_k(a, st) : AH == 5 ? agg5_k(a, st) : AH == 6 ? agg6_k(a, st) : agg8_k(a, st);
         if (rc) return rc;
         if (c.embed_num > 0) {      // f * (1 + scale) + shift, the chosen style row for every line (pytorch_ocr_engine.py:64-66)
@@ -569,6 +612,7 @@ int run_network(pocr_engine *e, Slot &s) {
     HIP_TRY(hipEventRecord(s.conv_done, st));
     s.conv_done_valid = true;
     HIP_TRY(hipStreamWaitEvent(s.seq_stream, s.conv_done, 0));
+    if (prof) (void)hipEventRecord(s.ev_conv_end, st);
     st = s.seq_stream;
     const float *layer_in = s.feat.as<float>();
     int din = E;
@@ -922,7 +966,7 @@ int collect_outputs(pocr_engine *e, Slot &s, float *logits_ntc, int32_t *frame_a
         for (int i = 0; i < POCR_NUM_STAGES; ++i) s.stage_ms[i] = 0.f;
         const int order[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, POCR_STAGE_AGG, POCR_STAGE_LSTM, POCR_STAGE_HEAD, POCR_STAGE_CTC, POCR_NUM_STAGES};
         for (int k = 0; k + 1 < (int)(sizeof(order) / sizeof(int)); ++k)
-            HIP_TRY(hipEventElapsedTime(&s.stage_ms[order[k]], s.ev[order[k]], s.ev[order[k + 1]]));
+            HIP_TRY(hipEventElapsedTime(&s.stage_ms[order[k]], s.ev[order[k]], order[k] == POCR_STAGE_AGG ? s.ev_conv_end : s.ev[order[k + 1]]));
         HIP_TRY(hipEventElapsedTime(&s.stage_ms[POCR_STAGE_TOTAL], s.ev[0], s.ev[POCR_NUM_STAGES]));
         s.have_ms = true;
     }
@@ -1079,6 +1123,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     if (const char *env = getenv("POCR_NO_GRAPHS")) e->use_graphs = atoi(env) == 0;
     if (const char *env = getenv("POCR_LSTM_PERSIST")) e->lstm_persist = atoi(env) != 0;
     e->bf16x3 = conv_split() != 0;
+    e->p2 = conv_split() == 2 && !(getenv("POCR_NO_P2") && atoi(getenv("POCR_NO_P2")) != 0);
     if (const char *env = getenv("POCR_LSTM_WIDE")) e->lstm_wide = atoi(env) != 0;
     if (const char *env = getenv("POCR_LSTM_MULTI")) e->lstm_multi = atoi(env);
     e->device = device_id;
@@ -1095,6 +1140,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         for (auto &ev : sl.ev)
             if (hipEventCreate(&ev) != hipSuccess) return bail(fail("hipEventCreate failed"));
         if (hipEventCreateWithFlags(&sl.conv_done, hipEventDisableTiming) != hipSuccess) return bail(fail("hipEventCreate failed"));
+        if (hipEventCreate(&sl.ev_conv_end) != hipSuccess) return bail(fail("hipEventCreate failed"));
         sl.lstm_y.resize(cfg->arch == POCR_ARCH_BLSTM ? cfg->lstm_layers : 0);
         sl.sa_y.resize(cfg->arch == POCR_ARCH_SA || cfg->arch == POCR_ARCH_S2S ? cfg->sa_layers : 0);
         if (cfg->arch == POCR_ARCH_S2S) {
@@ -1336,6 +1382,7 @@ void pocr_destroy(pocr_engine *e) {
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);
         if (s.conv_done) (void)hipEventDestroy(s.conv_done);
+        if (s.ev_conv_end) (void)hipEventDestroy(s.ev_conv_end);
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.seq_stream) (void)hipStreamDestroy(s.seq_stream);
     }
@@ -2362,6 +2409,20 @@ int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t
         HIP_TRY(hipStreamSynchronize(s.seq_stream));
         HIP_TRY(hipMemcpyAsync(out, src, k * sizeof(float), hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(hipStreamSynchronize(s.stream));
+        if (e->p2 && what >= 0 && what < 9) {
+            // conv activations are kept pre-split (conv_bf16x3.hpp "P2": per pixel and 32-channel chunk 32 x f16 h, 32 x f16 l);
+            // the caller gets the values they stand for, x = h + l / 2048, in NHWC order
+            const int C = s.act_c[what];
+            std::vector<float> px(C);
+            for (size_t p0 = 0; p0 + C <= k; p0 += C) {
+                const _Float16 *raw = reinterpret_cast<const _Float16 *>(out + p0);
+                for (int c = 0; c < C; ++c) {
+                    const _Float16 h = raw[(c >> 5) * 64 + (c & 31)], l = raw[(c >> 5) * 64 + 32 + (c & 31)];
+                    px[c] = (float)h + (float)l * (1.0f / 2048.0f);
+                }
+                memcpy(out + p0, px.data(), (size_t)C * sizeof(float));
+            }
+        }
     }
     return 0;
 }

@@ -1025,3 +1025,45 @@ def test_padding_column_skip_is_bit_identical(monkeypatch):
     for ca, cb in zip(a, b):
         for k, (x, y) in enumerate(zip(ca, cb)):
             assert x.shape == y.shape and np.array_equal(x, y), f"output {k} differs with padding-column skipping"
+
+
+def test_presplit_activations_are_bit_identical(monkeypatch):
+    """The default (f16x2) conv stack keeps its activations PRE-SPLIT in HBM (conv_bf16x3.hpp "P2": producers split once in
+    their epilogue, consumers stage by 16-byte copies).  The split is a deterministic function of the fp32 value, so the
+    same engine with the split done inside every consumer instead (POCR_NO_P2=1) must give bit-identical features, logits
+    and labels; the conv activations read back from the P2 layout are the values the two planes stand for
+    (h + l / 2048 = x to 2^-22)."""
+    if _native.conv_split() != 2:
+        pytest.skip("pre-split activations belong to the f16x2 arithmetic")
+    chars = synth.make_charset(50)
+    spec = netspec.NetSpec(num_classes=len(chars) + 1)
+    weights = netspec.pack_weights(spec, netspec.generate_weights(spec, 78))
+    widths = [300, 0, 1, 17, 640, 96, 33, 511, 64, 1000, 200, 5]
+    crops = synth.make_crops(10, widths)
+    pool = np.concatenate([c.reshape(-1) for c in crops])
+    offs = np.concatenate([[0], np.cumsum([c.size for c in crops])[:-1]]).astype(np.int64)
+    cases = [([-(-max(w, 1) // 32) * 32 + 64 for w in widths], 32), ([1088] * len(widths), 32)]
+
+    def run(p2):
+        if p2:
+            monkeypatch.delenv("POCR_NO_P2", raising=False)
+        else:
+            monkeypatch.setenv("POCR_NO_P2", "1")
+        eng = _native.NativeEngine(spec, weights, 0)
+        out = []
+        for w_pads, pad_left in cases:
+            eng.slot_stage_ragged(0, pool, offs, np.array(widths, np.int32), w_pads, pad_left)
+            eng.slot_launch(0, want_logits=True, want_argmax=True)
+            logits, amax, labels, lens = eng.slot_collect(0)
+            out.append(([eng.debug_read(k) for k in range(9)], [eng.debug_read(9), logits, amax, labels, lens]))
+        eng.close()
+        return out
+
+    a, b = run(True), run(False)
+    for (acts_a, outs_a), (acts_b, outs_b) in zip(a, b):
+        for k, (x, y) in enumerate(zip(outs_a, outs_b)):
+            assert x.shape == y.shape and np.array_equal(x, y), f"output {k} differs with pre-split activations"
+        for k, (x, y) in enumerate(zip(acts_a, acts_b)):
+            assert x.shape == y.shape
+            # (values below f16's normal range, 6.1e-5, keep an absolute precision of 2^-35 instead of a relative one)
+            assert np.all(np.abs(x - y) <= 2.0 ** -21 * np.abs(y) + 1e-9), f"conv{k + 1}: P2 read-back is not the fp32 value to 2^-21"

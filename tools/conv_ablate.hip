@@ -20,6 +20,13 @@ struct Shape { int cin, cout, H, W, ph, pw; };
 struct Variant { const char *name; void (*fn)(ConvArgs, hipStream_t); int split; };
 #define V(NAME, TH, MW, NS, WM, PH, PW, ACT, BN, MINW, BDIR, SPL) static void NAME(ConvArgs a, hipStream_t st) { \
     launch(conv3x3_bf16x3_kernel<TH, MW, NS, WM, PH, PW, ACT, BN, MINW, BDIR, 3, 3, 1, 1, false, SPL>, TH, 16 * MW, NS * (4 / WM) * 16, a, st); }
+#define VP(NAME, TH, MW, NS, WM, PH, PW, ACT, BN, MINW, BDIR) static void NAME(ConvArgs a, hipStream_t st) { \
+    launch(conv3x3_bf16x3_kernel<TH, MW, NS, WM, PH, PW, ACT, BN, MINW, BDIR, 3, 3, 1, 1, false, 2, true, true>, TH, 16 * MW, NS * (4 / WM) * 16, a, st); }
+VP(p9, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true)
+VP(p6, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
+VP(p4, 4, 1, 2, 1, 2, 2, ACT_RELU, false, 2, true)
+VP(p3, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
+V(h3, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true, 2)
 V(b9, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true, 3)
 V(h9, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true, 2)
 V(h8, 5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true, 2)
@@ -29,10 +36,11 @@ V(h2, 4, 2, 2, 2, 2, 2, ACT_RELU, false, 3, false, 2)
 int main(int argc, char **argv) {
     const int layer = argc > 1 ? atoi(argv[1]) : 9, n = argc > 2 ? atoi(argv[2]) : 256, wpad = argc > 3 ? atoi(argv[3]) : 576;
     Shape s; std::vector<Variant> vars;
-    if (layer == 9) { s = {512, 512, 5, wpad / 4, 1, 1}; vars = {{"bf16x3 5x16 NT128", b9, 3}, {"f16x2 5x16 NT128", h9, 2}}; }
+    if (layer == 9) { s = {512, 512, 5, wpad / 4, 1, 1}; vars = {{"bf16x3 5x16 NT128", b9, 3}, {"f16x2 5x16 NT128", h9, 2}, {"f16x2 P2 5x16 NT128", p9, 2}}; }
     else if (layer == 8) { s = {256, 512, 5, wpad / 4, 1, 1}; vars = {{"f16x2 5x16 NT128", h8, 2}}; }
-    else if (layer == 6) { s = {256, 256, 10, wpad / 4, 1, 1}; vars = {{"f16x2 5x16 NT128", h6, 2}}; }
-    else if (layer == 4) { s = {128, 128, 20, wpad / 2, 2, 2}; vars = {{"f16x2 4x16 NT128", h4, 2}}; }
+    else if (layer == 6) { s = {256, 256, 10, wpad / 4, 1, 1}; vars = {{"f16x2 5x16 NT128", h6, 2}, {"f16x2 P2 5x16 NT128", p6, 2}}; }
+    else if (layer == 4) { s = {128, 128, 20, wpad / 2, 2, 2}; vars = {{"f16x2 4x16 NT128", h4, 2}, {"f16x2 P2 4x16 NT128", p4, 2}}; }
+    else if (layer == 3) { s = {64, 128, 20, wpad / 2, 1, 1}; vars = {{"f16x2 5x16 NT128", h3, 2}, {"f16x2 P2 5x16 NT128", p3, 2}}; }
     else { s = {64, 64, 40, wpad, 2, 2}; vars = {{"f16x2 lds 4x32 NT64 3WG", h2, 2}}; }
     const size_t xin = (size_t)n * s.H * s.W * s.cin, yout = (size_t)n * (s.H / s.ph) * (s.W / s.pw) * s.cout;
     std::vector<float> hx(xin);
