@@ -428,7 +428,8 @@ def main():
         pn_path = os.path.join(tmp.name, "parsenet.pocrp")
         torch_parsenet.save_blob(pn_path, parsenet_spec.generate_weights(20261001))
         parsenet = torch_parsenet.TorchParseNet(pn_path, Dev(local_rank), downsample=4, adaptive_downsample=False)
-        cropper = LineCropper({"LINE_HEIGHT": str(spec.height), "INTERP": "2", "LINE_SCALE": "1.0"}, device_id=local_rank)
+        cropper = LineCropper({"LINE_HEIGHT": str(spec.height), "INTERP": "2", "LINE_SCALE": "1.0",
+                               "RESIDENT_CROPS": "no" if os.environ.get("POCR_BENCH_HOST_CROPS") == "1" else "yes"}, device_id=local_rank)
         page_ocr = PageOCR({"OCR_JSON": os.path.join(tmp.name, "ocr.json")}, Dev(local_rank))
         stage = {"layout_net": 0.0, "crop": 0.0, "ocr": 0.0}
         lines_done = 0
@@ -510,7 +511,7 @@ def main():
         extra["sparse_logits_nnz_per_frame"] = round(nnz_frames[0] / max(1, nnz_frames[1]), 2)
         extra["head_temperature"] = args.head_temperature
         workload_txt = (f"c5: stream of {ph}x{pw} synthetic pages, one per step per GPU: layout network (parsenet_unet64, downsample 4 -> {ph // 4}x{pw // 4}) -> "
-                        f"layout post-processing stub (ground-truth baselines of the {len(boxes[0])} pasted lines) -> resident GPU line cropper -> "
+                        f"layout post-processing stub (ground-truth baselines of the {len(boxes[0])} pasted lines) -> resident GPU line cropper (crops stay in HBM) -> "
                         f"VGG+BiLSTM+CTC line OCR (default batch_size 8, sparse logits + confidences) -> strings; inputs: host page per step; "
                         f"layout + crop of the next pages on a helper thread, the recogniser gets the lines of {ppb} pages per process_lines call")
         w_pad = None

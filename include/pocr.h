@@ -287,6 +287,21 @@ int pocr_cropper_measure(pocr_cropper *c, const pocr_crop_spec *specs, int32_t n
  * status [n]: final per-line status. */
 int pocr_cropper_crop(pocr_cropper *c, int32_t line_height, const int64_t *crop_off, uint8_t *crops, float *grid_out, int32_t *status);
 const uint8_t *pocr_cropper_pinned_crops(pocr_cropper *c);
+/* Crops that STAY in HBM between the cropper and the recogniser (reference: LineCropper.process_page fills line.crop,
+ * page_parser.py:384-393, and PageOCR.process_page hands the same arrays to process_lines, :418-430 - on the host both).
+ * pocr_cropper_crop_resident = pocr_cropper_crop without the copy back: the device buffer that holds the crops
+ * (line i uint8 [line_height][widths[i]][3] at crop_off[i]) is detached from the cropper and returned as a handle, so the
+ * next page can be cropped while the recogniser still reads this one.  pocr_slot_stage_resident stages lines straight
+ * from such buffers (one handle per line: a launch may mix lines of several pages; same device as the engine; nothing is
+ * copied - the handles must stay alive until the launch has been collected).  pocr_crops_read copies bytes back on
+ * demand (callers that want the numpy crop after all); pocr_crops_release returns the buffer to the cropper's pool. */
+typedef struct pocr_crops pocr_crops;
+int pocr_cropper_crop_resident(pocr_cropper *c, int32_t line_height, const int64_t *crop_off, int32_t *status, pocr_crops **out);
+void pocr_crops_release(pocr_crops *k);
+int64_t pocr_crops_bytes(const pocr_crops *k);
+int pocr_crops_read(const pocr_crops *k, int64_t offset, int64_t nbytes, uint8_t *out);
+int pocr_slot_stage_resident(pocr_engine *e, int32_t slot, const pocr_crops *const *crops_of_line, const int64_t *crop_offsets,
+                             const int32_t *widths, const int32_t *w_pads, int32_t n, int32_t pad_left);
 /* Test hook: the float64 per-column curves of the last crop call - line i (status 0 at measure time): [4][widths[i]]
  * (base_x, base_y, normal_x, normal_y), lines back to back - for bit-comparison with the numpy / scipy sequence. */
 int pocr_cropper_read_curves(pocr_cropper *c, double *out, int64_t cap);

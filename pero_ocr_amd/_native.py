@@ -78,6 +78,11 @@ SYMBOLS = {
                                        C.c_int64, _i32p, _i32p]),
     "pocr_cropper_crop": (C.c_int, [C.c_void_p, C.c_int32, _i64p, _u8p, _f32p, _i32p]),
     "pocr_cropper_pinned_crops": (C.c_void_p, [C.c_void_p]),
+    "pocr_cropper_crop_resident": (C.c_int, [C.c_void_p, C.c_int32, _i64p, _i32p, C.POINTER(C.c_void_p)]),
+    "pocr_crops_release": (None, [C.c_void_p]),
+    "pocr_crops_bytes": (C.c_int64, [C.c_void_p]),
+    "pocr_crops_read": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _u8p]),
+    "pocr_slot_stage_resident": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), _i64p, _i32p, _i32p, C.c_int32, C.c_int32]),
     "pocr_cropper_read_curves": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64]),
     "pocr_cropper_last_ms": (C.c_float, [C.c_void_p]),
     "pocr_num_slots": (C.c_int, []),
@@ -156,6 +161,7 @@ class NativeEngine:
             raise RuntimeError("pocr_create: " + self._err())
         self._n = 0
         self._T = 0
+        self.device_id = int(device_id)
         self.num_slots = int(self._lib.pocr_num_slots())
         # per slot: (n, T_max, rows, want_logits, want_argmax, uniform)
         self._slot_shape = [(0, 0, 0, False, False, True)] * self.num_slots
@@ -255,6 +261,24 @@ class NativeEngine:
             raise RuntimeError("pocr_slot_stage_ragged: " + self._err())
         frames = (wp // 2) // 2
         self._slot_shape[slot] = (int(wd.size), int(frames.max()), int(frames.sum()), False, False, False)
+        return frames
+
+    def slot_stage_resident(self, slot: int, crops, w_pads, pad_left: int):
+        """Lines whose crops are already in HBM (LazyCrop objects of ResidentCrops buffers, same device): nothing is copied,
+        the first kernel reads them where the cropper wrote them.  The ResidentCrops objects must stay referenced until the
+        launch has been collected (the LazyCrop objects do that)."""
+        n = len(crops)
+        handles = (C.c_void_p * n)(*[c.owner._h for c in crops])
+        off = np.array([c.offset for c in crops], dtype=np.int64)
+        wd = np.array([c.shape[1] for c in crops], dtype=np.int32)
+        wp = np.ascontiguousarray(w_pads, dtype=np.int32)
+        if self._lib.pocr_slot_stage_resident(self._h, int(slot), handles, _ptr(off, _i64p), _ptr(wd, _i32p), _ptr(wp, _i32p),
+                                              n, int(pad_left)):
+            raise RuntimeError("pocr_slot_stage_resident: " + self._err())
+        self._slot_resident = getattr(self, "_slot_resident", {})
+        self._slot_resident[slot] = list({id(c.owner): c.owner for c in crops}.values())      # keep the buffers alive
+        frames = (wp // 2) // 2
+        self._slot_shape[slot] = (n, int(frames.max()), int(frames.sum()), False, False, False)
         return frames
 
     def slot_launch(self, slot: int, want_logits=True, want_argmax=False):
@@ -483,6 +507,73 @@ class NativeParseNet:
         return float(ms.value)
 
 
+class ResidentCrops:
+    """One device buffer of crops that stayed in HBM (pocr_cropper_crop_resident): owns the pocr_crops handle."""
+
+    def __init__(self, lib, handle, device_id: int):
+        self._lib, self._h, self.device_id = lib, handle, int(device_id)
+        self.nbytes = int(lib.pocr_crops_bytes(handle))
+
+    def read(self, offset: int, nbytes: int) -> np.ndarray:
+        out = np.empty(int(nbytes), dtype=np.uint8)
+        if nbytes and self._lib.pocr_crops_read(self._h, int(offset), int(nbytes), _ptr(out, _u8p)):
+            raise RuntimeError("pocr_crops_read: " + (self._lib.pocr_last_error() or b"").decode("utf8", "replace"))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pocr_crops_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LazyCrop:
+    """A text-line crop `uint8 [H, w, C]` that lives in HBM (one line of a ResidentCrops buffer).  It quacks like the numpy
+    array the reference puts into `line.crop` (shape / ndim / dtype / size, np.asarray, indexing, copy) and is copied to the
+    host only when somebody actually looks at the pixels; PytorchEngineLineOCR.process_lines stages such crops on the GPU
+    directly (pocr_slot_stage_resident), so between the cropper and the recogniser nothing crosses PCIe."""
+    dtype = np.dtype(np.uint8)
+    ndim = 3
+
+    def __init__(self, owner: ResidentCrops, offset: int, shape):
+        self.owner, self.offset, self.shape = owner, int(offset), tuple(int(v) for v in shape)
+        self._host = None
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+    @property
+    def nbytes(self):
+        return self.size
+
+    def materialise(self) -> np.ndarray:
+        if self._host is None:
+            self._host = self.owner.read(self.offset, self.size).reshape(self.shape)
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.materialise()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, key):
+        return self.materialise()[key]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def copy(self):
+        return self.materialise().copy()
+
+    def astype(self, dtype, **kw):
+        return self.materialise().astype(dtype, **kw)
+
+
 class NativeCropper:
     """Owns one pocr_cropper handle: the resident line cropper of one GPU (include/pocr.h "resident line cropper")."""
 
@@ -539,6 +630,22 @@ class NativeCropper:
             raise RuntimeError("pocr_cropper_measure: " + self._err())
         self._n, self._widths, self._status0 = n, widths, status.copy()
         return widths, status
+
+    def crop_resident(self, line_height: int, device_id: int):
+        """Crops of the lines measured last, left in HBM -> (list of LazyCrop (None where the line failed), status)."""
+        n, widths = self._n, self._widths
+        ch = self.channels
+        sizes = widths.astype(np.int64) * int(line_height) * ch
+        crop_off = np.zeros(n, dtype=np.int64)
+        np.cumsum(sizes[:-1], out=crop_off[1:])
+        status = np.zeros(n, dtype=np.int32)
+        h = C.c_void_p()
+        if self._lib.pocr_cropper_crop_resident(self._h, int(line_height), _ptr(crop_off, _i64p), _ptr(status, _i32p), C.byref(h)):
+            raise RuntimeError("pocr_cropper_crop_resident: " + self._err())
+        owner = ResidentCrops(self._lib, h, device_id)
+        out = [LazyCrop(owner, crop_off[i], (line_height, int(widths[i]), ch)) if status[i] == 0 and widths[i] > 0 else None
+               for i in range(n)]
+        return out, status
 
     def crop(self, line_height: int, copy: bool = True, want_grids: bool = False):
         """Crops of the lines measured last -> (list of uint8 [line_height, w_i, C] (None where the line failed), status[, grids]).

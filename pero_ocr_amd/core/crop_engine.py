@@ -180,11 +180,13 @@ class EngineLineCropper:
         self._page_channels = img.shape[2] if img.ndim == 3 else 1
 
     def crop_lines(self, img: Optional[np.ndarray], lines: Sequence[Tuple[object, Sequence[float]]], copy: bool = True,
-                   want_grids: bool = False):
+                   want_grids: bool = False, resident: bool = False):
         """All lines of a page: upload (behind the host's per-line work), three launches, one download.
         lines: (baseline, heights) pairs.  img None: the page of the last set_page.  A line whose grid cannot be
         computed gets the reference's fallback crop: zeros [line_height, 32, C] (crop_engine.py:20-22).
-        copy=False: the crops are views of a pinned buffer that the next call overwrites."""
+        copy=False: the crops are views of a pinned buffer that the next call overwrites.
+        resident=True (3-channel pages): the crops stay in HBM and come back as `_native.LazyCrop` objects - array-likes that
+        the recogniser stages on the GPU directly and that turn into numpy arrays only when their pixels are looked at."""
         if img is not None:
             self.set_page(img)
         elif self._cropper is None:
@@ -221,7 +223,10 @@ class EngineLineCropper:
         if good:
             widths, _ = self._cropper.measure(specs[:len(good)], np.concatenate(knots) if knots else np.zeros(0),
                                                np.concatenate(coefs))
-            res = self._cropper.crop(self.line_height, copy=copy, want_grids=want_grids)
+            if resident and not want_grids and self._page_ndim == 3 and channels == 3:
+                res = self._cropper.crop_resident(self.line_height, self.device_id)
+            else:
+                res = self._cropper.crop(self.line_height, copy=copy, want_grids=want_grids)
             for k, i in enumerate(good):
                 out[i] = res[0][k]
                 if want_grids:

@@ -179,9 +179,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         const int tn = a.tiles_n;
         const int P = a.tiles ? a.n_ptiles : a.tiles_w * a.tiles_h * a.n;
         if (tn >= 2 && tn <= 8 && (tn & (tn - 1)) == 0) {
-            const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, groups = 8 / tn;
-            nt = xcd % tn;
-            ptile = k * groups + xcd / tn;
+            const int G = a.xcd_g > 1 && tn % a.xcd_g == 0 ? a.xcd_g : 1, xg = tn / G;      // (ConvArgs::xcd_g)
+            const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, groups = 8 / xg;
+            nt = (xcd % xg) * G + k % G;
+            ptile = (k / G) * groups + xcd / xg;
             if (ptile >= P) return;
         } else {
             int b = blockIdx.x;

@@ -110,6 +110,10 @@ struct ConvArgs {
     // STAGE_UPCAT: x = [n][H/2][W/2][cin_up] (upsampled on the fly), x2 = [n][H][W][cin - cin_up] (skip connection)
     const float *x2;
     int32_t cin_up;
+    // channel tiles per XCD (block -> tile mapping of conv3x3_bf16x3_kernel): 0 / 1 = every XCD works on ONE channel tile
+    // (its L2 holds 1 / tiles_n of the weights; a pixel tile's halo is fetched by tiles_n XCDs), G > 1 = consecutive
+    // workgroups of an XCD take G channel tiles of the SAME pixel tile (the halo is fetched once per G, the XCD's L2 holds G / tiles_n of the weights)
+    int32_t xcd_g;
 };
 
 // number of workgroups for a conv launch (must match the block -> tile mapping in the kernel)
@@ -117,8 +121,9 @@ inline size_t conv_grid_blocks(const ConvArgs &a) {
     const size_t P = a.tiles ? (size_t)a.n_ptiles : (size_t)a.tiles_w * a.tiles_h * a.n;
     const int tn = a.tiles_n;
     if (tn >= 2 && tn <= 8 && (tn & (tn - 1)) == 0) {
-        const size_t groups = 8 / tn;
-        return (P + groups - 1) / groups * 8;
+        const int G = a.xcd_g > 1 && tn % a.xcd_g == 0 ? a.xcd_g : 1;
+        const size_t groups = 8 * G / tn;              // XCDs that work on the same channel tiles
+        return (P + groups - 1) / groups * G * 8;
     }
     return P * tn;
 }

@@ -4,9 +4,27 @@
 // the caller's per-line host work) and stays in HBM for every line; the only host<->device traffic per page besides
 // the page itself is ~100 B of spline per line up, 4 B of width per line back, and the crops.
 #include <atomic>
+#include <memory>
+#include <mutex>
 #include <thread>
 
+// Crops that stay in HBM (pocr_cropper_crop_resident): the device buffer one crop call filled, detached from the
+// cropper so that the next page can be cropped while the recogniser still reads these.  Released buffers go back to the
+// cropper's pool (hipMalloc / hipFree synchronise the device: not once per page).
+struct CropPool {                              // shared by a cropper and the buffers detached from it (either may die first)
+    std::mutex mu;
+    std::vector<DevBuf> bufs;
+    bool alive = true;
+};
+struct pocr_crops {
+    int device = 0;
+    DevBuf buf;
+    size_t bytes = 0;
+    std::shared_ptr<CropPool> pool;
+};
+
 struct pocr_cropper {
+    std::shared_ptr<CropPool> pool = std::make_shared<CropPool>();     // crop buffers handed back by pocr_crops_release
     int device = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr;
     DevBuf page, specs, knots, coefs, state, curves, out, grid;
@@ -69,9 +87,16 @@ int pocr_cropper_create(int device_id, pocr_cropper **out) {
 void pocr_cropper_destroy(pocr_cropper *c) {
     if (!c) return;
     if (c->uploader.joinable()) c->uploader.join();
+    std::vector<DevBuf> pooled;
+    {   // detached crop buffers may outlive the cropper: they just stop returning to its pool
+        std::lock_guard<std::mutex> g(c->pool->mu);
+        c->pool->alive = false;
+        pooled.swap(c->pool->bufs);
+    }
     (void)hipSetDevice(c->device);
     (void)locked_device_sync();
     for (DevBuf *b : {&c->page, &c->specs, &c->knots, &c->coefs, &c->state, &c->curves, &c->out, &c->grid}) b->release();
+    for (DevBuf &b : pooled) b.release();
     for (void *p : {c->pin_page, c->pin_out, c->pin_small}) if (p) (void)locked_host_free(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -149,7 +174,8 @@ int pocr_cropper_measure(pocr_cropper *c, const pocr_crop_spec *specs, int32_t n
     return 0;
 }
 
-int pocr_cropper_crop(pocr_cropper *c, int32_t line_height, const int64_t *crop_off, uint8_t *crops, float *grid_out, int32_t *status) {
+static int cropper_crop_impl(pocr_cropper *c, int32_t line_height, const int64_t *crop_off, uint8_t *crops, float *grid_out, int32_t *status,
+                             bool to_host, size_t *out_bytes) {
     if (!c || !crop_off || !status) return fail("NULL pointer");
     if (c->n <= 0) return fail("pocr_cropper_measure has not run");
     if (line_height <= 0) return fail("bad line height %d", line_height);
@@ -170,8 +196,13 @@ int pocr_cropper_crop(pocr_cropper *c, int32_t line_height, const int64_t *crop_
     }
     const size_t stb = (size_t)n * sizeof(pocr::CropState);
     if (w_max > 0) {
+        if (!to_host && c->out.cap < (size_t)n_out) {      // a pooled buffer that is large enough, if there is one
+            std::lock_guard<std::mutex> g(c->pool->mu);
+            for (size_t k = 0; k < c->pool->bufs.size(); ++k)
+                if (c->pool->bufs[k].cap >= (size_t)n_out) { std::swap(c->out, c->pool->bufs[k]); break; }
+        }
         if (c->curves.reserve((size_t)n_curve * 8) || c->out.reserve((size_t)n_out) || (grid_out && c->grid.reserve((size_t)n_grid * 4)) ||
-            pin_reserve(&c->pin_out, &c->pin_out_cap, (size_t)n_out))
+            (to_host && pin_reserve(&c->pin_out, &c->pin_out_cap, (size_t)n_out)))
             return 1;
         pocr::CropState *hs = reinterpret_cast<pocr::CropState *>(c->pin_small);      // measure has synchronised: the block is free
         std::memcpy(hs, c->hstate.data(), stb);
@@ -185,18 +216,77 @@ int pocr_cropper_crop(pocr_cropper *c, int32_t line_height, const int64_t *crop_
                            c->out.as<uint8_t>(), grid_out ? c->grid.as<float>() : (float *)nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(hs, c->state.p, stb, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->pin_out, c->out.p, (size_t)n_out, hipMemcpyDeviceToHost, c->stream));
+        if (to_host) HIP_TRY(hipMemcpyAsync(c->pin_out, c->out.p, (size_t)n_out, hipMemcpyDeviceToHost, c->stream));
         if (grid_out) HIP_TRY(hipMemcpyAsync(grid_out, c->grid.p, (size_t)n_grid * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         (void)hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1);
         for (int i = 0; i < n; ++i) c->hstate[i].status = hs[i].status;
-        if (crops) std::memcpy(crops, c->pin_out, (size_t)n_out);
+        if (crops && to_host) std::memcpy(crops, c->pin_out, (size_t)n_out);
     } else if (cropper_join(c)) {
         return 1;
     }
     for (int i = 0; i < n; ++i) status[i] = c->hstate[i].status;
+    if (out_bytes) *out_bytes = (size_t)n_out;
     return 0;
+}
+
+int pocr_cropper_crop(pocr_cropper *c, int32_t line_height, const int64_t *crop_off, uint8_t *crops, float *grid_out, int32_t *status) {
+    return cropper_crop_impl(c, line_height, crop_off, crops, grid_out, status, true, nullptr);
+}
+
+int pocr_cropper_crop_resident(pocr_cropper *c, int32_t line_height, const int64_t *crop_off, int32_t *status, pocr_crops **out) {
+    if (!out) return fail("out is NULL");
+    *out = nullptr;
+    size_t bytes = 0;
+    if (cropper_crop_impl(c, line_height, crop_off, nullptr, nullptr, status, false, &bytes)) return 1;
+    auto *k = new pocr_crops();
+    k->device = c->device; k->pool = c->pool; k->bytes = bytes;
+    std::swap(k->buf, c->out);                         // the cropper allocates (or takes from its pool) another one next time
+    *out = k;
+    return 0;
+}
+
+void pocr_crops_release(pocr_crops *k) {
+    if (!k) return;
+    if (k->pool) {
+        std::lock_guard<std::mutex> g(k->pool->mu);
+        if (k->pool->alive && k->buf.p && k->pool->bufs.size() < 8) { k->pool->bufs.emplace_back(); std::swap(k->pool->bufs.back(), k->buf); }
+    }
+    (void)hipSetDevice(k->device);
+    k->buf.release();
+    delete k;
+}
+
+int64_t pocr_crops_bytes(const pocr_crops *k) { return k ? (int64_t)k->bytes : 0; }
+
+int pocr_crops_read(const pocr_crops *k, int64_t offset, int64_t nbytes, uint8_t *out) {
+    if (!k || !out) return fail("NULL pointer");
+    if (offset < 0 || nbytes < 0 || (size_t)(offset + nbytes) > k->bytes) return fail("range [%lld, +%lld) outside the %zu crop bytes", (long long)offset, (long long)nbytes, k->bytes);
+    if (nbytes == 0) return 0;
+    HIP_TRY(hipSetDevice(k->device));
+    HIP_TRY(locked_memcpy(out, static_cast<const uint8_t *>(k->buf.p) + offset, (size_t)nbytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pocr_slot_stage_resident(pocr_engine *e, int32_t slot, const pocr_crops *const *crops_of_line, const int64_t *crop_offsets,
+                             const int32_t *widths, const int32_t *w_pads, int32_t n, int32_t pad_left) {
+    if (check_slot(e, slot)) return 1;
+    if (!crops_of_line || !crop_offsets || !widths || !w_pads) return fail("NULL input pointer");
+    if (n <= 0) return fail("n must be positive (got %d)", n);
+    const int H = e->cfg.height;
+    const uint8_t *base = nullptr;
+    std::vector<int64_t> rel((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const pocr_crops *k = crops_of_line[i];
+        if (!k || !k->buf.p) return fail("line %d: no resident crop buffer", i);
+        if (k->device != e->device) return fail("line %d: its crops live on device %d, the engine on device %d", i, k->device, e->device);
+        if (widths[i] < 0 || crop_offsets[i] < 0 || (size_t)crop_offsets[i] + (size_t)H * widths[i] * 3 > k->bytes)
+            return fail("line %d: crop [%d x %d x 3] at offset %lld lies outside its %zu-byte buffer", i, H, widths[i], (long long)crop_offsets[i], k->bytes);
+        if (!base) base = static_cast<const uint8_t *>(k->buf.p);
+        rel[i] = (static_cast<const uint8_t *>(k->buf.p) - base) + crop_offsets[i];       // lines of several buffers: offsets of either sign
+    }
+    return stage_ragged_impl(e, slot, nullptr, rel.data(), widths, w_pads, n, pad_left, nullptr, base);
 }
 
 int pocr_cropper_read_curves(pocr_cropper *c, double *out, int64_t cap) {

@@ -195,7 +195,9 @@ struct DecAttnArgs {
     float scale;
 };
 
-template <int D>
+// MEMORY only names the instantiation (keys / values = the encoder output of the line, row_off set) so that a kernel
+// trace tells the HBM-bound memory attention from the short self attention over the cache; the code is the same.
+template <int D, bool MEMORY = false>
 __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnArgs a) {
     static_assert(D == 32 || D == 64 || D == 128, "head dim");
     // A key / value row of one head is D floats = LPR lanes x 16 bytes; a wave instruction therefore fetches RPW whole

@@ -200,11 +200,14 @@ int pocr_parsenet_get_maps(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, 
         const int32_t wl = Wp;
         const int64_t off0 = 0;
         if (p->tiles.reserve(tiles.size() * sizeof(PixelTile)) || p->lines.reserve(sizeof(LineDesc)) || p->wline.reserve(16) || p->ooff.reserve(16)) return 1;
-        HIP_TRY(hipMemcpyAsync(p->tiles.p, tiles.data(), tiles.size() * sizeof(PixelTile), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(p->lines.p, &ld, sizeof(ld), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(p->wline.p, &wl, sizeof(wl), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(p->ooff.p, &off0, sizeof(off0), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));          // the sources above are stack / pageable memory
+        {   // the sources are stack / pageable memory: these copies are synchronising calls (g_unsafe_mu, pocr_hip.hip)
+            UnsafeLock lock;
+            HIP_TRY(hipMemcpyAsync(p->tiles.p, tiles.data(), tiles.size() * sizeof(PixelTile), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(p->lines.p, &ld, sizeof(ld), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(p->wline.p, &wl, sizeof(wl), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(p->ooff.p, &off0, sizeof(off0), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
         Conv1Args c1{};
         c1.crops = src; c1.lines = p->lines.as<LineDesc>(); c1.lut = p->lut.as<float>();
         c1.wfrag = p->enc[0].w.as<float>(); c1.bias = p->enc[0].b.as<float>(); c1.y = p->x[0].as<float>();

@@ -24,7 +24,6 @@
 #include "decoder.hpp"
 #include "crop.hpp"
 #include "lstm.hpp"
-#include "lstm_persist.hpp"
 #include "sparsify.hpp"
 #include "comm.hpp"
 #include "parsenet.hpp"
@@ -56,7 +55,11 @@ int fail(const char *fmt, ...) {
 // synchronising copies and device-wide synchronisation) and the capture itself exclude each other: a page stream runs the
 // layout network and the cropper on a helper thread while the recogniser's thread may be capturing its recurrence
 // (hipStreamCaptureModeThreadLocal permits that on paper; the lock is cheap insurance - it costs nothing in the steady state,
-// where no buffer grows and every graph is cached).
+// where no buffer grows and every graph is cached).  Under the lock: hipMalloc / hipFree (DevBuf, the RCCL staging buffers),
+// hipHostMalloc / hipHostFree, hipMemcpy, hipDeviceSynchronize, copies from pageable memory, stream capture + instantiation.
+// Deliberately NOT under it: hipStreamSynchronize / hipEventSynchronize on a stream of the calling thread's own object
+// (slot, cropper, layout network), hipMemcpyAsync between pinned and device memory, and kernel launches - none of them is
+// on HIP's list of calls that invalidate another thread's thread-local capture, and they are the steady state of a page stream.
 std::recursive_mutex g_unsafe_mu;
 struct UnsafeLock { std::lock_guard<std::recursive_mutex> g{g_unsafe_mu}; };
 inline hipError_t locked_host_malloc(void **p, size_t n, unsigned flags) { UnsafeLock l; return hipHostMalloc(p, n, flags); }
@@ -121,6 +124,11 @@ int launch_conv(Kern kern, int TH, int TW, int NT, int nthreads, ConvArgs a, hip
         a.tiles_h = (a.Ho + TH - 1) / TH;
     }
     a.tiles_n = (a.cout16 * 16) / NT;
+    // Two channel tiles per XCD: a pixel tile's halo is fetched from HBM by tiles_n / 2 XCDs instead of tiles_n (conv9: reads
+    // 6x -> 3x the algorithmic bytes), the XCD's L2 holds 2 / tiles_n of the layer's weights; throughput-neutral
+    // (profiles/r03_xcd_mapping_experiment.txt).  POCR_XCD_G=1|2|4 overrides.
+    static const int xcd_g_env = getenv("POCR_XCD_G") ? atoi(getenv("POCR_XCD_G")) : 2;
+    if (a.xcd_g == 0) a.xcd_g = xcd_g_env;
     const size_t blocks = conv_grid_blocks(a);
     if (blocks == 0) return 0;
     if (blocks > 0x7fffffffull) return fail("conv grid too large (%zu blocks)", blocks);
@@ -302,6 +310,7 @@ struct Slot {
                                          // latency-bound kernels are dispatched ahead of the other slot's conv workgroups
     // staged chunk
     DevBuf crops, lines;
+    const uint8_t *crops_ext = nullptr;   // staged from device-resident crops (pocr_slot_stage_resident): conv1 reads them in place
     void *host_in = nullptr;         // pinned staging for the crop pool
     size_t host_in_cap = 0;
     int n = 0, w_pad = 0;            // w_pad = widest padded row of the staged lines
@@ -348,9 +357,6 @@ struct Slot {
     // BiLSTM recurrence as replayable hipGraphs: key (layer, T, slice bucket) -> 2 memsets + T step launches.
     // Node parameters hold this slot's buffer addresses; any re-allocation of those buffers flushes the cache.
     std::map<std::tuple<int, int, int>, hipGraphExec_t> lstm_graphs;
-    DevBuf lstm_flags;               // persistent recurrence: [layer][2][n_slices] item counters, then one error word
-    int lstm_err_off = -1;           // index of that error word (uint32) inside lstm_flags; -1 = none this launch
-    uint32_t *lstm_err_host = nullptr;   // pinned copy of the error word, read at collect time
     DevBuf lstm_dims;                // device {n, npad} read by the replayed step kernels
     int32_t *lstm_dims_host = nullptr;   // pinned source of that copy
     size_t h_stride = 0;             // floats between the two h ping-pong buffers (capacity-based, stable)
@@ -392,9 +398,6 @@ struct pocr_engine {
     int embed_id = -1;
     std::unordered_set<const void *> b3_weights;   // weight buffers laid out for the bf16x3 kernels (wsplit): the GEMM-mode / aggregation launches ask
     std::vector<DevBuf> proj_w, proj_b, whh;       // per LSTM layer
-    std::vector<DevBuf> whh_p;                     // per LSTM layer: W_hh as wave-private register fragments (lstm_persist.hpp)
-    bool lstm_persist = false;                     // POCR_LSTM_PERSIST=1: one persistent launch per layer (lstm_persist.hpp) instead
-                                                   // of T step launches; measured slower on MI355X, so opt-in
     // self-attention encoder (POCR_ARCH_SA): per layer in_proj, out_proj, lin1, lin2 (fragment order) + LN params
     struct SaLayer { DevBuf w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b; };
     std::vector<SaLayer> sa;
@@ -409,10 +412,6 @@ struct pocr_engine {
     std::vector<DecLayer> dec;
     DevBuf dec_embed, dec_out_w, dec_out_b;
     int dec_out_cout16 = 0;
-    int lstm_multi = 1;              // POCR_LSTM_MULTI=2|4: split-K step kernel with 2 / 4 slices per workgroup (lstm_step_multi_kernel)
-    bool lstm_wide = false;          // POCR_LSTM_WIDE=1: recurrence step with four 16-line slices per workgroup (lstm_step_wide_kernel);
-                                     // measured: a quarter of the workgroups and less disturbance of the first convs, but 18 us
-                                     // instead of 12 us per step and 64 KB of LDS that conv2's workgroups leave no room for - slower in all
     bool p2 = false;                 // f16x2 with pre-split activations between conv1 and the aggregation conv (conv_bf16x3.hpp "P2"; POCR_NO_P2=1: split in every consumer)
     bool bf16x3 = true;              // conv2..conv9 on the bf16 matrix pipe with the exact 3-way operand split (POCR_CONV_FP32=1: fp32 MFMA)
     DevBuf cconst[9];                // per conv layer: the output column [H_out][cout] far inside zero padding
@@ -538,7 +537,7 @@ int run_network(pocr_engine *e, Slot &s) {
         int rc = 0;
         if (i == 0) {
             Conv1Args c1{};
-            c1.crops = s.crops.as<uint8_t>(); c1.lines = s.lines.as<LineDesc>(); c1.lut = e->lut.as<float>();
+            c1.crops = s.crops_ext ? s.crops_ext : s.crops.as<uint8_t>(); c1.lines = s.lines.as<LineDesc>(); c1.lut = e->lut.as<float>();
             c1.wfrag = e->conv_w[0].as<float>(); c1.bias = e->conv_b[0].as<float>(); c1.y = s.act[0].as<float>();
             c1.tiles = s.g_tiles[0]; c1.line_w = s.g_lvl_w[0]; c1.out_off = s.g_act_off[0];
             c1.H = h; c1.n_ptiles = s.g_ntiles[0];
@@ -720,25 +719,6 @@ int run_network(pocr_engine *e, Slot &s) {
         la.c = s.cbuf.as<float>(); la.y = s.lstm_y[l].as<float>(); la.dims = dims;
         la.line_T = s.g_line_T; la.row_off = s.g_row_off; la.slice_T = s.g_slice_T;
         la.n = n; la.npad = npad; la.T = T; la.H = Hh; la.step = step;
-        if (e->lstm_wide && (Hh == 64 || Hh == 128 || Hh == 256 || Hh == 512)) {
-            const dim3 wgrid(Hh / 16, (slices + 3) / 4, 2);          // four 16-line slices per workgroup (lstm.hpp)
-            switch (Hh) {
-                case 64: hipLaunchKernelGGL(lstm_step_wide_kernel<1>, wgrid, dim3(256), 0, st, la); break;
-                case 128: hipLaunchKernelGGL(lstm_step_wide_kernel<2>, wgrid, dim3(256), 0, st, la); break;
-                case 256: hipLaunchKernelGGL(lstm_step_wide_kernel<4>, wgrid, dim3(256), 0, st, la); break;
-                default: hipLaunchKernelGGL(lstm_step_wide_kernel<8>, wgrid, dim3(256), 0, st, la); break;
-            }
-            return;
-        }
-        if (e->lstm_multi > 1 && (Hh == 128 || Hh == 256)) {          // SL slices per workgroup, split K (lstm.hpp)
-            const int SLn = e->lstm_multi >= 4 ? 4 : 2;
-            const dim3 mgrid(Hh / 16, (slices + SLn - 1) / SLn, 2);
-            if (Hh == 256 && SLn == 2) hipLaunchKernelGGL((lstm_step_multi_kernel<4, 2>), mgrid, dim3(256), 0, st, la);
-            else if (Hh == 256) hipLaunchKernelGGL((lstm_step_multi_kernel<4, 4>), mgrid, dim3(256), 0, st, la);
-            else if (SLn == 2) hipLaunchKernelGGL((lstm_step_multi_kernel<2, 2>), mgrid, dim3(256), 0, st, la);
-            else hipLaunchKernelGGL((lstm_step_multi_kernel<2, 4>), mgrid, dim3(256), 0, st, la);
-            return;
-        }
         const dim3 grid(Hh / 16, slices, 2);
         switch (Hh) {
             case 64: hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, st, la); break;
@@ -750,64 +730,14 @@ int run_network(pocr_engine *e, Slot &s) {
     };
     int bucket = 1;                          // slices rounded up to a power of two: few distinct graphs
     while (bucket * 16 < npad) bucket *= 2;
-    const int nsl = npad / 16;
-    const bool persist = e->lstm_persist && (Hh == 64 || Hh == 128 || Hh == 256 || Hh == 512) && npad <= LSTM_PERSIST_MAX_LINES &&
-                         (size_t)rows * 2 * Hh * sizeof(float) < 0x7ffffff0ull;
-    s.lstm_err_off = -1;
-    if (persist) {
-        const size_t words = (size_t)c.lstm_layers * 2 * nsl + 1;
-        if (s.lstm_flags.reserve(words * sizeof(uint32_t))) return 1;
-        HIP_TRY(hipMemsetAsync(s.lstm_flags.p, 0, words * sizeof(uint32_t), st));
-        s.lstm_err_off = (int)(words - 1);
-    } else {
-        s.lstm_dims_host[0] = n; s.lstm_dims_host[1] = npad;
-        HIP_TRY(hipMemcpyAsync(s.lstm_dims.p, s.lstm_dims_host, 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    }
+    s.lstm_dims_host[0] = n; s.lstm_dims_host[1] = npad;
+    HIP_TRY(hipMemcpyAsync(s.lstm_dims.p, s.lstm_dims_host, 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
     for (int l = 0; l < c.lstm_layers; ++l) {
         ConvArgs a{};
         a.x = layer_in; a.n = 1; a.H = 1; a.W = rows; a.Ho = 1; a.Wo = rows; a.cin = din;
         a.cout16 = e->proj_cout16; a.cout_valid = 8 * Hh; a.out_stride = 8 * Hh;
         a.wfrag = e->proj_w[l].as<float>(); a.bias = e->proj_b[l].as<float>(); a.y = s.xproj.as<float>();
         if (e->b3_weights.count(e->proj_w[l].p) ? gemm128_b3(a, st) : gemm128_k(a, st)) return 1;
-        if (persist) {
-            // the serial part in ONE launch: 2 x H/16 resident workgroups walk (step, 16-line slice) items (lstm_persist.hpp)
-            LstmPersistArgs pa{};
-            pa.xproj = s.xproj.as<float>(); pa.whh_p = e->whh_p[l].as<float>(); pa.y = s.lstm_y[l].as<float>();
-            pa.c = s.cbuf.as<float>();
-            pa.flags = s.lstm_flags.as<unsigned>() + (size_t)l * 2 * nsl;
-            pa.err = s.lstm_flags.as<unsigned>() + s.lstm_err_off;
-            pa.line_T = s.g_line_T; pa.row_off = s.g_row_off; pa.slice_T = s.g_slice_T;
-            pa.n = n; pa.npad = npad; pa.n_slices = nsl; pa.T = T;
-            pa.y_bytes = (int32_t)((size_t)rows * 2 * Hh * sizeof(float));
-            if (getenv("POCR_LSTM_DBG")) {
-                static DevBuf dbgbuf;
-                if (dbgbuf.reserve(sizeof(unsigned long long) * (16 + 128))) return 1;
-                pa.dbg = dbgbuf.as<unsigned long long>();
-                if (const char *m = getenv("POCR_LSTM_DBG_MASK")) pa.dbg_mask = atoi(m);
-            }
-            // slices are independent chains: with many of them, a few workgroups per unit group take every z-th slice
-            // (more waves per CU cover each other's hand-off latency); every workgroup keeps >= 8 slices to pipeline over
-            int zs = std::max(1, std::min(4, nsl / 8));
-            if (const char *env = getenv("POCR_LSTM_Z")) zs = std::max(1, std::min(nsl, atoi(env)));
-            // 8 waves (32 hidden units) per workgroup = 2 waves per SIMD; H = 512 keeps 128 + 2 x 128 registers per wave: 4 waves
-            switch (Hh) {
-                case 64: hipLaunchKernelGGL((lstm_persist_kernel<4, 8>), dim3(Hh / 32, 2, zs), dim3(512), 0, st, pa); break;
-                case 128: hipLaunchKernelGGL((lstm_persist_kernel<8, 8>), dim3(Hh / 32, 2, zs), dim3(512), 0, st, pa); break;
-                case 256: hipLaunchKernelGGL((lstm_persist_kernel<16, 8>), dim3(Hh / 32, 2, zs), dim3(512), 0, st, pa); break;
-                default: hipLaunchKernelGGL((lstm_persist_kernel<32, 4>), dim3(Hh / 16, 2, zs), dim3(256), 0, st, pa); break;
-            }
-            HIP_TRY(hipGetLastError());
-            if (pa.dbg) {       // POCR_LSTM_DBG=1: phase cycle counts of workgroup (0, 0, 0), wave 0 (blocks the stream)
-                unsigned long long h[16 + 128];
-                HIP_TRY(hipStreamSynchronize(st));
-                HIP_TRY(locked_memcpy(h, pa.dbg, sizeof(h), hipMemcpyDeviceToHost));
-                fprintf(stderr, "[lstm dbg] layer %d z %d: items %llu blocking %llu | cycles/item: wait %.0f barrier %.0f mfma %.0f cell %.0f publish %.0f store %.0f fetch %.0f | total %.0f | first miss: step %llu slice %llu flag %llu\n",
-                        l, zs, h[0], h[1], (double)h[2] / h[0], (double)h[4] / h[0], (double)h[5] / h[0], (double)h[6] / h[0], (double)h[3] / h[0], (double)h[8] / h[0], (double)h[9] / h[0], (double)h[7] / h[0], h[4] >> 48, (h[4] >> 32) & 0xffff, h[4] & 0xffffffffull);
-            }
-            layer_in = s.lstm_y[l].as<float>();
-            din = 2 * Hh;
-            continue;
-        }
         // the serial part: 2 memsets + T dependent step launches, replayed from a captured graph
         const auto key = std::make_tuple(l, T, bucket);
         auto it = s.lstm_graphs.find(key);
@@ -891,10 +821,6 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
         s.pinned_cap = need + need / 4;
     }
     char *pin = static_cast<char *>(s.pinned);
-    if (s.lstm_err_off >= 0) {
-        if (!s.lstm_err_host) HIP_TRY(locked_host_malloc(reinterpret_cast<void **>(&s.lstm_err_host), 16, hipHostMallocDefault));
-        HIP_TRY(hipMemcpyAsync(s.lstm_err_host, s.lstm_flags.as<uint32_t>() + s.lstm_err_off, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    }
     HIP_TRY(hipMemcpyAsync(pin, s.labels.p, nt_bytes, hipMemcpyDeviceToHost, st));
     if (s.want_argmax) HIP_TRY(hipMemcpyAsync(pin + nt_bytes, s.best.p, (size_t)rows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(pin + 2 * nt_bytes, s.lens.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -952,8 +878,6 @@ int collect_outputs(pocr_engine *e, Slot &s, float *logits_ntc, int32_t *frame_a
     const int n = s.n, T = s.t_max, C = e->cfg.num_classes, rows = s.rows;
     HIP_TRY(hipStreamSynchronize(s.seq_stream));
     s.in_flight = false;
-    if (s.lstm_err_off >= 0 && s.lstm_err_host && *s.lstm_err_host != 0)
-        return fail("BiLSTM recurrence: a hand-off between workgroups timed out (not all workgroups of the persistent launch became resident)");
     const size_t nt_bytes = (size_t)n * T * sizeof(int32_t);
     const char *pin = static_cast<const char *>(s.pinned);
     if (logits_ntc && !s.want_logits) return fail("logits were not requested at launch");
@@ -1069,7 +993,7 @@ size_t pocr_num_weight_floats(const pocr_config *c) {
 
 static int stage_ragged_impl(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
                              const int32_t *widths, const int32_t *w_pads, int32_t n, int32_t pad_left,
-                             const int32_t *pad_lefts);
+                             const int32_t *pad_lefts, const uint8_t *dev_base = nullptr);
 
 // The constant padding column of every conv layer (conv_igemm.hpp, FillSeg): one all-zero line of 256 columns goes
 // through the network once; column W/2 of every layer's output is far enough from both row ends (26 input pixels
@@ -1121,11 +1045,8 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     pocr_engine *e = new pocr_engine();
     e->cfg = *cfg;
     if (const char *env = getenv("POCR_NO_GRAPHS")) e->use_graphs = atoi(env) == 0;
-    if (const char *env = getenv("POCR_LSTM_PERSIST")) e->lstm_persist = atoi(env) != 0;
     e->bf16x3 = conv_split() != 0;
     e->p2 = conv_split() == 2 && !(getenv("POCR_NO_P2") && atoi(getenv("POCR_NO_P2")) != 0);
-    if (const char *env = getenv("POCR_LSTM_WIDE")) e->lstm_wide = atoi(env) != 0;
-    if (const char *env = getenv("POCR_LSTM_MULTI")) e->lstm_multi = atoi(env);
     e->device = device_id;
     auto bail = [&](int rc) { pocr_destroy(e); return rc; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
@@ -1264,7 +1185,6 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         e->proj_cout16 = round_up(8 * Hh, kProjNT) / 16;
         e->proj_w.resize(cfg->lstm_layers); e->proj_b.resize(cfg->lstm_layers);
         e->whh.resize(cfg->lstm_layers);
-        e->whh_p.resize(cfg->lstm_layers);
         for (int l = 0; l < cfg->lstm_layers; ++l) {
             const int din = l == 0 ? cfg->conv_out : 2 * Hh;
             const float *wih[2], *whh[2], *bih[2], *bhh[2];
@@ -1292,19 +1212,6 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
                                     wf[o++] = whh[d][(size_t)(g * Hh + 16 * ug + (lane & 15)) * Hh + 16 * kg + 4 * (lane >> 4) + j];
             if ((proj_b3 ? upload_u16(e->proj_w[l], proj_split, st) : upload(e->proj_w[l], frag, st)) || upload(e->proj_b[l], bias, st) || upload(e->whh[l], wf, st)) return bail(1);
             if (proj_b3) e->b3_weights.insert(e->proj_w[l].p);
-            // whh_p[dir][unit quad][kg][lane][j] = W_hh[(lane & 15) / 4 * H + 4 * quad + (lane & 3)][16 kg + 4 (lane >> 4) + j]:
-            // the 16 gate columns (gate-major) of 4 hidden units, the B operand a wave of lstm_persist_kernel keeps in registers
-            std::vector<float> wpf((size_t)2 * (Hh / 4) * KGT * 256);
-            o = 0;
-            for (int d = 0; d < 2; ++d)
-                for (int quad = 0; quad < Hh / 4; ++quad)
-                    for (int kg = 0; kg < KGT; ++kg)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int j = 0; j < 4; ++j) {
-                                const int col = lane & 15, g = col >> 2, us = col & 3;
-                                wpf[o++] = whh[d][(size_t)(g * Hh + 4 * quad + us) * Hh + 16 * kg + 4 * (lane >> 4) + j];
-                            }
-            if (upload(e->whh_p[l], wpf, st)) return bail(1);
         }
     }
     {   // head
@@ -1346,7 +1253,7 @@ void pocr_destroy(pocr_engine *e) {
     for (auto &b : e->conv_w) b.release();
     for (auto &b : e->cconst) b.release();
     for (auto &b : e->conv_b) b.release();
-    for (auto &v : {&e->proj_w, &e->proj_b, &e->whh, &e->whh_p})
+    for (auto &v : {&e->proj_w, &e->proj_b, &e->whh})
         for (auto &b : *v) b.release();
     for (auto &L : e->sa)
         for (DevBuf *b : {&L.w_in, &L.b_in, &L.w_out, &L.b_out, &L.w1, &L.b1, &L.w2, &L.b2, &L.n1w, &L.n1b, &L.n2w, &L.n2b}) b->release();
@@ -1375,9 +1282,7 @@ void pocr_destroy(pocr_engine *e) {
         for (auto &kv : s.lstm_graphs) (void)hipGraphExecDestroy(kv.second);
         s.lstm_graphs.clear();
         s.lstm_dims.release();
-        s.lstm_flags.release();
         if (s.lstm_dims_host) (void)locked_host_free(s.lstm_dims_host);
-        if (s.lstm_err_host) (void)locked_host_free(s.lstm_err_host);
         if (s.host_in) (void)locked_host_free(s.host_in);
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);
@@ -1542,21 +1447,24 @@ static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n,
     return 0;
 }
 
+// dev_base != nullptr: the crops are already in HBM (pocr_slot_stage_resident) - crop_offsets are byte offsets from
+// dev_base (any sign: lines of several resident buffers), nothing is copied, conv1 reads them where they lie
 static int stage_ragged_impl(pocr_engine *e, int32_t slot, const uint8_t *crops, const int64_t *crop_offsets,
                              const int32_t *widths, const int32_t *w_pads, int32_t n, int32_t pad_left,
-                             const int32_t *pad_lefts) {
+                             const int32_t *pad_lefts, const uint8_t *dev_base) {
     if (slot != POCR_NUM_SLOTS && check_slot(e, slot)) return 1;         // POCR_NUM_SLOTS = the internal slot
     Slot &s = e->slot[slot];
     if (s.in_flight) return fail("slot %d has a launch in flight: collect it first", slot);
     s.staged = false;
     if (n <= 0) return fail("n must be positive (got %d)", n);
     if (pad_left < 0) return fail("pad_left must be >= 0");
-    if (!crops || !crop_offsets || !widths || !w_pads) return fail("NULL input pointer");
+    if ((!crops && !dev_base) || !crop_offsets || !widths || !w_pads) return fail("NULL input pointer");
     HIP_TRY(hipSetDevice(e->device));
     const int H = e->cfg.height;
     size_t total = 0;
     for (int i = 0; i < n; ++i) {
         if (widths[i] < 0) return fail("line %d has negative width", i);
+        if (dev_base) continue;
         if (crop_offsets[i] < 0) return fail("line %d has negative offset", i);
         if (w_pads[i] < 4) return fail("line %d: w_pad must be >= 4 (got %d)", i, w_pads[i]);
         const size_t end = (size_t)crop_offsets[i] + (size_t)H * widths[i] * 3;
@@ -1580,7 +1488,8 @@ static int stage_ragged_impl(pocr_engine *e, int32_t slot, const uint8_t *crops,
         desc[i].pad_left = pad_lefts ? pad_lefts[i] : pad_left;
     }
     if (total) memcpy(static_cast<char *>(s.host_in) + desc_bytes, crops, total);
-    if (s.crops.reserve(total ? total : 1)) return 1;
+    s.crops_ext = dev_base;
+    if (!dev_base && s.crops.reserve(total ? total : 1)) return 1;
     if (s.lines.reserve((size_t)n * sizeof(LineDesc))) return 1;
     if (total) HIP_TRY(hipMemcpyAsync(s.crops.p, static_cast<char *>(s.host_in) + desc_bytes, total, hipMemcpyHostToDevice, s.stream));
     HIP_TRY(hipMemcpyAsync(s.lines.p, desc, (size_t)n * sizeof(LineDesc), hipMemcpyHostToDevice, s.stream));
@@ -1979,9 +1888,13 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
         a.out = s.s2s_ctx.as<float>(); a.line_done = d_line_done; a.stop = d_remaining;
         a.E = E; a.scale = 1.0f / sqrtf((float)D);
         const dim3 grid(heads, n);
-        if (D == 32) hipLaunchKernelGGL(dec_attention_kernel<32>, grid, dim3(256), 0, st, a);
-        else if (D == 64) hipLaunchKernelGGL(dec_attention_kernel<64>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(dec_attention_kernel<128>, grid, dim3(256), 0, st, a);
+        if (a.row_off) {           // memory attention (encoder rows of the line)
+            if (D == 32) hipLaunchKernelGGL((dec_attention_kernel<32, true>), grid, dim3(256), 0, st, a);
+            else if (D == 64) hipLaunchKernelGGL((dec_attention_kernel<64, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((dec_attention_kernel<128, true>), grid, dim3(256), 0, st, a);
+        } else if (D == 32) hipLaunchKernelGGL((dec_attention_kernel<32, false>), grid, dim3(256), 0, st, a);
+        else if (D == 64) hipLaunchKernelGGL((dec_attention_kernel<64, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((dec_attention_kernel<128, false>), grid, dim3(256), 0, st, a);
     };
     const bool fuse_ln = (E == 512 || E == 256) && getenv("POCR_S2S_NO_LN_FUSION") == nullptr;
     int blocks = 0;

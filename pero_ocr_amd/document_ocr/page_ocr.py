@@ -18,13 +18,17 @@ class LineCropper:
     for every text line of a page - here with ONE GPU call for all lines (pero_ocr_amd/core/crop_engine.py)."""
 
     def __init__(self, config, config_path="", device_id: int = 0):
+        """Build-specific key RESIDENT_CROPS (default no): `line.crop` becomes an array-like that stays in HBM
+        (`_native.LazyCrop`) - PageOCR on the same GPU then recognises the lines without the crops crossing PCIe;
+        anything that reads the pixels (np.asarray, indexing) gets a numpy copy on demand."""
         from ..core.crop_engine import EngineLineCropper
         self.crop_engine = EngineLineCropper(line_height=int(config["LINE_HEIGHT"]), poly=int(config["INTERP"]),
                                              scale=float(config["LINE_SCALE"]), device_id=device_id)
+        self.resident = str(config.get("RESIDENT_CROPS", "no")).lower() in ("1", "yes", "true", "on")
 
     def process_page(self, img, page_layout):
         lines = list(page_layout.lines_iterator())
-        crops = self.crop_engine.crop_lines(img, [(line.baseline, line.heights) for line in lines])
+        crops = self.crop_engine.crop_lines(img, [(line.baseline, line.heights) for line in lines], resident=self.resident)
         for line, crop in zip(lines, crops):
             line.crop = crop
         return page_layout

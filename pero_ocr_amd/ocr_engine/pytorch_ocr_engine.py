@@ -180,8 +180,15 @@ class PytorchEngineLineOCR(BaseEngineLineOCR):
         the slot's streams.  sparse_rows = None: dense logits (if wanted); (row_begin, row_end) or
         (None, None): the softmax / p < 1e-4 / CSC step of line_ocr_engine.py:168-171 runs on the GPU."""
         ids = launch.line_ids
-        pool, offsets, widths = self._pack_lines(lines, ids)
-        frames = self.model.slot_stage_ragged(slot, pool, offsets, widths, launch.w_pads, self.line_padding_px)
+        mine = [lines[i] for i in ids]
+        dev = getattr(self.model, "device_id", None)
+        if all(isinstance(c, _native.LazyCrop) and c._host is None and c.owner.device_id == dev and c.shape[2] == 3 for c in mine):
+            # crops the resident cropper left in HBM on this GPU: staged in place (reference: the same numpy arrays go from
+            # LineCropper to PageOCR, page_parser.py:384-393 -> 418-430)
+            frames = self.model.slot_stage_resident(slot, mine, launch.w_pads, self.line_padding_px)
+        else:
+            pool, offsets, widths = self._pack_lines(lines, ids)
+            frames = self.model.slot_stage_ragged(slot, pool, offsets, widths, launch.w_pads, self.line_padding_px)
         if sparse_rows is not None and want_logits:
             self.model.slot_launch_sparse(slot, sparse_rows[0], sparse_rows[1], SPARSE_PROB_THRESHOLD)
             return ("sparse", slot, sparse_rows, frames)

@@ -404,57 +404,6 @@ def test_c4_full_batch_matches_reference_golden(golden, tmp_path):
     assert hip_t < LOGIT_TOL and n_hip_ref == 0
 
 
-def test_lstm_persistent_launch_matches_step_kernel(monkeypatch):
-    """The one-launch-per-layer recurrence (csrc/lstm_persist.hpp: resident workgroups, h handed over through L2 with
-    per-slice counters; opt-in with POCR_LSTM_PERSIST=1) against the shipped per-step kernel (csrc/lstm.hpp) and the oracle, on launch shapes
-    that exercise every path of its item pipeline: one slice (every item waits), two, three and many slices, ragged
-    line lengths inside a slice, a line count that is not a multiple of 16, a batch of one, hidden sizes 64 / 128 / 256."""
-    chars = synth.make_charset(40)
-    for hidden, layers in ((256, 2), (128, 1), (64, 2)):
-        spec = netspec.NetSpec(num_classes=len(chars) + 1, lstm_hidden=hidden, lstm_layers=layers)
-        weights = netspec.generate_weights(spec, 20260928 + hidden)
-        flat = netspec.pack_weights(spec, weights)
-        monkeypatch.setenv("POCR_LSTM_PERSIST", "0")
-        step_eng = _native.NativeEngine(spec, flat, 0)
-        monkeypatch.setenv("POCR_LSTM_PERSIST", "1")
-        pers_eng = _native.NativeEngine(spec, flat, 0)
-        net = model_oracle.OracleNet(spec, weights)
-        cases = [[96], [130, 40, 77], [64] * 16, [200, 33] + [90] * 19, [48] * 35 + [300, 17, 5], [120] * 70 + [64, 31]]
-        if hidden != 256:
-            cases = cases[:4]
-        for k, widths in enumerate(cases):
-            crops = synth.make_crops(50 + k, widths)
-            w_pads = [(-(-w // 32) * 32) + 64 for w in widths]          # every line padded on its own: ragged frame counts
-            pool = np.concatenate([c.reshape(-1) for c in crops])
-            sizes = np.array([c.size for c in crops], dtype=np.int64)
-            offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
-            outs = []
-            for eng in (step_eng, pers_eng):
-                eng.slot_stage_ragged(0, pool, offs, np.array(widths, np.int32), w_pads, 32)
-                eng.slot_launch(0, want_logits=True, want_argmax=True)
-                logits, amax, labels, lens = eng.slot_collect(0)
-                ys = [eng.debug_read(10 + l) for l in range(layers)]
-                outs.append((logits, amax, labels, lens, ys))
-            (l0, a0, lab0, len0, y0), (l1, a1, lab1, len1, y1) = outs
-            for l in range(layers):
-                assert y0[l].shape == y1[l].shape
-                assert float(np.max(np.abs(y0[l] - y1[l]))) < 5e-6, f"H={hidden} case {k} layer {l}"
-            assert float(np.max(np.abs(l0 - l1))) < 1e-4
-            srt = np.sort(l0, axis=1)
-            safe = (srt[:, -1] - srt[:, -2]) > 1e-3
-            assert np.array_equal(a0[safe], a1[safe])
-            # and against the oracle, line by line (each line in its own padded width)
-            row = 0
-            for i, (crop, wp) in enumerate(zip(crops, w_pads)):
-                batch = engine_oracle.assemble_batch([crop], [0], spec.height, wp - 64, 3840)
-                ref = model_oracle.forward_logits(net, batch)[0].T                  # [T, C]
-                got = l1[row:row + ref.shape[0]]
-                assert float(np.max(np.abs(got - ref))) < LOGIT_TOL, f"H={hidden} case {k} line {i}"
-                row += ref.shape[0]
-        step_eng.close()
-        pers_eng.close()
-
-
 def test_pipelined_slots_match_blocking_calls(small):
     """stage/launch/collect on both slots (two chunks in flight) == the blocking calls, bit for bit;
     misuse of the slot protocol is reported, not silently accepted."""
@@ -583,50 +532,6 @@ def test_rccl_through_the_c_abi_in_a_process_that_imported_pytorch():
         "print('RCCL-AFTER-TORCH-OK')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "RCCL-AFTER-TORCH-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
-
-
-def test_lstm_wide_step_kernel_matches_the_fixture(golden, tmp_path, monkeypatch):
-    """POCR_LSTM_WIDE=1 (four 16-line slices per workgroup, full-K chains instead of split-K partial sums): same strings and
-    per-frame arg-max as the reference fixture, logits within the tolerance - on ragged widths (lines that finish early)."""
-    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
-    monkeypatch.setenv("POCR_LSTM_WIDE", "1")
-    g = golden("ragged")
-    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=g.batch_size)
-    texts, logits, _ = eng.process_lines(g.crops(), sparse_logits=False)
-    assert texts == g.transcriptions
-    for i in range(g.n):
-        li = np.asarray(logits[i])
-        assert np.array_equal(np.argmax(li, axis=1), g.argmax(i))
-        assert float(np.max(np.abs(li[g.sample_rows[i]] - g.rows(i)))) < LOGIT_TOL
-
-
-@pytest.mark.parametrize("kw", [
-    dict(height=32, conv_out=64, lstm_hidden=64, lstm_layers=1),       # aggregation 4 x 1, H = 64 recurrence
-    dict(height=48, conv_out=128, lstm_hidden=128, lstm_layers=2),     # aggregation 6 x 1
-    dict(height=64, conv_out=256, lstm_hidden=64, lstm_layers=1),      # aggregation 8 x 1
-    dict(height=40, conv_out=48, lstm_hidden=48, lstm_layers=2),       # widths that are not multiples of 32: fp32-MFMA projections
-    dict(height=40, conv_out=128, sa_heads=4, sa_ff=272, sa_layers=1, arch=netspec.ARCH_SA),   # encoder, feed-forward width not a multiple of 32
-])
-def test_other_heights_and_widths_against_oracle(kw, tmp_path):
-    """Line heights 32 / 48 / 64 (the other aggregation kernels), other widths of the recurrent and encoder layers (which decide
-    whether a linear layer runs on the bf16x3 kernel in GEMM mode or on the fp32-MFMA one): engine vs the reference-pinned oracle."""
-    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
-    chars = synth.make_charset(40)
-    spec = netspec.NetSpec(num_classes=len(chars) + 1, **kw)
-    weights = netspec.generate_weights(spec, 4242)
-    netspec.save_blob(os.path.join(str(tmp_path), "w.pocrw"), spec, weights)
-    path = os.path.join(str(tmp_path), "ocr.json")
-    with open(path, "w", encoding="utf8") as f:
-        json.dump({"line_px_height": spec.height, "line_vertical_scale": 1.0, "checkpoint": "w.pocrw", "characters": chars, "net_name": "t"}, f)
-    eng = PytorchEngineLineOCR(path, Dev(), batch_size=8)
-    crops = synth.make_crops(77, [200, 64, 333, 517, 90, 33, 700], spec.height)
-    net = model_oracle.OracleNet(spec, weights)
-    want_t, want_l, want_c, _ = engine_oracle.process_lines(lambda b: model_oracle.forward_logits(net, b), crops, eng.characters,
-                                                            spec.height, 480 * 8, sparse_logits=False)
-    got_t, got_l, got_c = eng.process_lines(crops, sparse_logits=False)
-    assert got_t == want_t and got_c == want_c
-    worst = max(float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) for a, b in zip(got_l, want_l))
-    assert worst < LOGIT_TOL, worst
 
 
 def test_recurrence_graphs_follow_the_hidden_state_stride(golden, tmp_path):
