@@ -18,8 +18,10 @@ __device__ __forceinline__ bool argmax_better(float av, int ai, float bv, int bi
     return av > bv || (av == bv && ai < bi);
 }
 
-// logits [frames][C] (frames = n*T), out [frames]
-__global__ __launch_bounds__(256) void frame_argmax_kernel(const float *logits, int32_t *out, int frames, int C) {
+// logits [frames][C] (frames = n*T), out [frames].  nonfinite (or NULL): set to 1 when a frame's winner is NaN / +-inf - the
+// reference would decode such logits silently (torch.argmax: NaN is maximal); the engine prints a warning, because with the
+// f16x2 arithmetic an activation beyond f16's range (65504) is the one thing that can produce them (conv_bf16x3.hpp).
+__global__ __launch_bounds__(256) void frame_argmax_kernel(const float *logits, int32_t *out, int frames, int C, int32_t *nonfinite = nullptr) {
     const int lane = threadIdx.x & 63;
     const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (frame >= frames) return;
@@ -38,7 +40,10 @@ __global__ __launch_bounds__(256) void frame_argmax_kernel(const float *logits, 
         const bool oh = __shfl_xor((int)have, off, 64) != 0;
         if (oh && (!have || argmax_better(ov, oi, bv, bi))) { bv = ov; bi = oi; have = true; }
     }
-    if (lane == 0) out[frame] = bi;
+    if (lane == 0) {
+        out[frame] = bi;
+        if (nonfinite && !(fabsf(bv) <= 3.4028234e38f)) *nonfinite = 1;
+    }
 }
 
 // best [rows] -> labels [n][stride] (compacted, -1 padded), len [n].  Line i owns rows row_off[i] ..

@@ -1,6 +1,7 @@
 // pocr_hip.hip — C ABI (include/pocr.h) + host-side orchestration of the gfx950 kernels.
 // One engine = one GPU, one HIP stream.  No CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cmath>
 #include <cstdarg>
@@ -264,8 +265,10 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // wsplit[tap][cin/32][cout16][plane][lane][8 x 16 bit] = plane of W(co = 16 s + (lane & 15), ci = 32 g + 8 (lane >> 4) + j, tap),
 // zero outside cout_valid.  conv_split() == 3: hi / mid / lo of the exact bf16 truncation split; == 2: h = f16(w) and
 // l = f16((w - h) * 2^11), both rounded to nearest (conv_bf16x3.hpp)
+std::atomic<bool> g_f16_weight_overflow{false};      // a weight beyond f16's range met the f16x2 split (checked by the create calls)
 inline void split_weight(float wv, int split, uint16_t *planes) {
     if (split == 2) {
+        if (!(std::fabs(wv) <= 65504.0f)) g_f16_weight_overflow.store(true);
         const _Float16 h = (_Float16)wv;
         const _Float16 l = (_Float16)((wv - (float)h) * 2048.0f);
         memcpy(&planes[0], &h, 2); memcpy(&planes[1], &l, 2);
@@ -359,6 +362,8 @@ struct Slot {
     std::map<std::tuple<int, int, int>, hipGraphExec_t> lstm_graphs;
     DevBuf lstm_dims;                // device {n, npad} read by the replayed step kernels
     int32_t *lstm_dims_host = nullptr;   // pinned source of that copy
+    DevBuf nf_flag;                      // set by frame_argmax_kernel when a winning logit is NaN / inf
+    int32_t *nf_host = nullptr;          // pinned copy, read at collect time
     size_t h_stride = 0;             // floats between the two h ping-pong buffers (capacity-based, stable)
     const void *graph_geom = nullptr;    // address of `seqgeom` the cached graphs were captured with
     // Sequence-part tables (frames per line, first row, per-slice maximum) live in their own buffer with a
@@ -412,6 +417,7 @@ struct pocr_engine {
     std::vector<DecLayer> dec;
     DevBuf dec_embed, dec_out_w, dec_out_b;
     int dec_out_cout16 = 0;
+    bool warned_nonfinite = false;
     bool p2 = false;                 // f16x2 with pre-split activations between conv1 and the aggregation conv (conv_bf16x3.hpp "P2"; POCR_NO_P2=1: split in every consumer)
     bool bf16x3 = true;              // conv2..conv9 on the bf16 matrix pipe with the exact 3-way operand split (POCR_CONV_FP32=1: fp32 MFMA)
     DevBuf cconst[9];                // per conv layer: the output column [H_out][cout] far inside zero padding
@@ -796,8 +802,14 @@ int run_network(pocr_engine *e, Slot &s) {
         if (s.lens.reserve((size_t)n * sizeof(int32_t))) return 1;
         mark(POCR_STAGE_CTC);
         const int frames = rows;
+        if (!s.nf_flag.p) {
+            if (s.nf_flag.reserve(16)) return 1;
+            HIP_TRY(locked_host_malloc(reinterpret_cast<void **>(&s.nf_host), 16, hipHostMallocDefault));
+        }
+        HIP_TRY(hipMemsetAsync(s.nf_flag.p, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(frame_argmax_kernel, dim3((frames + 3) / 4), dim3(256), 0, st,
-                           s.logits.as<float>(), s.best.as<int32_t>(), frames, C);
+                           s.logits.as<float>(), s.best.as<int32_t>(), frames, C, s.nf_flag.as<int32_t>());
+        HIP_TRY(hipMemcpyAsync(s.nf_host, s.nf_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         hipLaunchKernelGGL(ctc_collapse_kernel, dim3(n), dim3(64), 0, st, s.best.as<int32_t>(),
                            s.labels.as<int32_t>(), s.lens.as<int32_t>(), T, C - 1, s.g_line_T, s.g_row_off, T);
         HIP_TRY(hipGetLastError());
@@ -878,6 +890,11 @@ int collect_outputs(pocr_engine *e, Slot &s, float *logits_ntc, int32_t *frame_a
     const int n = s.n, T = s.t_max, C = e->cfg.num_classes, rows = s.rows;
     HIP_TRY(hipStreamSynchronize(s.seq_stream));
     s.in_flight = false;
+    if (s.nf_host && *s.nf_host && !e->warned_nonfinite) {
+        e->warned_nonfinite = true;
+        fprintf(stderr, "WARNING: non-finite logits (NaN / inf) in a launch of %d lines - decoded like torch.argmax would (NaN is maximal).%s\n", n,
+                conv_split() == 2 ? "  With the default f16x2 arithmetic an activation or weight beyond 65504 produces them: POCR_CONV_SPLIT=3 (bf16x3) has fp32's range." : "");
+    }
     const size_t nt_bytes = (size_t)n * T * sizeof(int32_t);
     const char *pin = static_cast<const char *>(s.pinned);
     if (logits_ntc && !s.want_logits) return fail("logits were not requested at launch");
@@ -1239,6 +1256,9 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         const char *env = getenv("POCR_NO_PAD_SKIP");
         e->pad_skip = !(env && atoi(env) != 0);
     }
+    if (g_f16_weight_overflow.exchange(false))
+        return bail(fail("a convolution / projection weight lies outside f16's range (|w| > 65504 or not finite): the default f16x2 "
+                         "arithmetic cannot represent it - set POCR_CONV_SPLIT=3 (bf16x3, fp32's range)"));
     *out = e;
     return 0;
 }
@@ -1283,6 +1303,8 @@ void pocr_destroy(pocr_engine *e) {
         s.lstm_graphs.clear();
         s.lstm_dims.release();
         if (s.lstm_dims_host) (void)locked_host_free(s.lstm_dims_host);
+        s.nf_flag.release();
+        if (s.nf_host) (void)locked_host_free(s.nf_host);
         if (s.host_in) (void)locked_host_free(s.host_in);
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);

@@ -972,3 +972,38 @@ def test_presplit_activations_are_bit_identical(monkeypatch):
             assert x.shape == y.shape
             # (values below f16's normal range, 6.1e-5, keep an absolute precision of 2^-35 instead of a relative one)
             assert np.all(np.abs(x - y) <= 2.0 ** -21 * np.abs(y) + 1e-9), f"conv{k + 1}: P2 read-back is not the fp32 value to 2^-21"
+
+
+def test_layer_rescaling_leaves_the_logits_alone():
+    """Size-independent property: scaling one conv layer (weights and bias) by 2^-k and the next layer's weights by 2^k
+    leaves the network's function unchanged (ReLU is positively homogeneous; powers of two are exact in fp32).  With
+    k = 10 the scaled layer's weights (~4e-5) and outputs fall BELOW f16's normal range: the f16x2 split then holds them
+    as subnormal high planes plus scaled low planes - if the matrix pipe flushed f16 subnormals the high planes would vanish
+    and the logits would move by ~1e-2.  They must stay within the logit tolerance (the same bound holds for bf16x3 / fp32
+    MFMA, where the rescaling is exact up to rounding)."""
+    chars = synth.make_charset(99)
+    spec = netspec.NetSpec(num_classes=len(chars) + 1)
+    base = netspec.generate_weights(spec, 20260928)
+    crops = synth.make_crops(55, [256, 131, 300, 64])
+    pool = np.concatenate([c.reshape(-1) for c in crops])
+    offs = np.concatenate([[0], np.cumsum([c.size for c in crops])[:-1]]).astype(np.int64)
+    widths = np.array([c.shape[1] for c in crops], np.int32)
+
+    def run(weights):
+        eng = _native.NativeEngine(spec, netspec.pack_weights(spec, weights), 0)
+        eng.slot_stage_ragged(0, pool, offs, widths, [384] * len(crops), 32)
+        eng.slot_launch(0, want_logits=True, want_argmax=True)
+        logits, amax, _labels, _lens = eng.slot_collect(0)
+        eng.close()
+        return logits, amax
+
+    ref_logits, ref_amax = run(base)
+    for k, (a, b) in ((10, ("conv5", "conv6")), (8, ("conv2", "conv3")), (10, ("conv8", "conv9"))):
+        w = dict(base)
+        s = np.float32(2.0 ** -k)
+        w[f"{a}.weight"], w[f"{a}.bias"] = base[f"{a}.weight"] * s, base[f"{a}.bias"] * s
+        w[f"{b}.weight"] = base[f"{b}.weight"] / s
+        logits, amax = run(w)
+        err = float(np.max(np.abs(logits - ref_logits)))
+        print(f"[rescale {a} x 2^-{k}] max |dlogit| {err:.3e}")
+        assert err < LOGIT_TOL, (a, err)
