@@ -654,7 +654,7 @@ def main():
         if w_pad is not None:
             traffic = None          # HBM bytes per launch of the dominant kernel, from the committed PMC passes
             pmc_file = {2: "r03_pmc_summary.json", 3: "r02_pmc_summary.json", 0: "pmc_summary.json"}[split]
-            dom_sig = {2: "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false, 2>",
+            dom_sig = {2: "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false, 2, true, true>",
                        3: "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false>", 0: "5, 1, 4, 4, 16, 1, 1, 2, true"}[split]
             try:
                 pmc = json.load(open(os.path.join(REPO, "profiles", pmc_file)))

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     constexpr int A_U = SPL * PS;                       // A tile (single-buffered, refilled once per chunk; BDIR: two of them)
     constexpr int B_F4 = BDIR ? 0 : (NT / 16) * WU;     // 16-byte units per B buffer (one (chunk, tap) step)
     constexpr int NP8 = (NP + 7) / 8 * 8;               // PRE_IN: 64 consecutive staging slots = 8 pixels x 8 sixteen-byte units
-    constexpr int A_LD = PRE_IN ? (8 * NP8 + NTHR - 1) / NTHR : (CQ * NP + NTHR - 1) / NTHR;
+    constexpr int A_LD = (8 * NP8 + NTHR - 1) / NTHR;   // staging slots per thread and chunk (CQ = 8 quads or 8 pre-split units per pixel)
     constexpr int B_LD = BDIR ? 1 : (B_F4 + NTHR - 1) / NTHR;
     static_assert(POOLH == 1 || TH % 2 == 0, "H-pool needs an even tile height");
     __shared__ u32x4 lds[BDIR ? 2 * A_U : A_U + 2 * B_F4];      // one scalar type (unsigned) for every access: no type punning
@@ -236,17 +236,21 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             a_lds[r] = p < NP ? (u >> 2) * PS + (u & 3) * NPPAD + p : -1;                       // 16-byte units
             continue;
         }
-        const int cq = e % CQ, p = e / CQ;
+        // Slot e of the in-kernel split: as above, eight consecutive lanes take the same channel quad cq of eight consecutive
+        // pixels - their 8-byte plane stores land in one contiguous LDS row (with cq fastest the eight quads of a pixel hit
+        // rows NPPAD * 16 bytes apart, i.e. the same banks: the 40 % bank-conflict share of the GEMM-mode layers in
+        // profiles/r02_pmc_summary.json) - and the wave still reads whole 128-byte pixel chunks.
+        const int l6 = e & 63, p = (e >> 6) * 8 + (l6 & 7), cq = l6 >> 3;
         const int hr = p / HW, wc = p % HW;
         const int hi = h0 - PADH + hr, wi = w0 - PADW + wc;
-        a_ok[r] = e < CQ * NP && hi >= 0 && hi < a.H && wi >= 0 && wi < Win;
+        a_ok[r] = p < NP && hi >= 0 && hi < a.H && wi >= 0 && wi < Win;
         if constexpr (UPCAT) {
             a_off[r] = a_ok[r] ? (unsigned)(((hi >> 1) * (Win >> 1) + (wi >> 1)) * a.cin_up + cq * 4) : 0u;
             a_off2[r] = a_ok[r] ? (unsigned)((hi * Win + wi) * (a.cin - a.cin_up) + cq * 4) : 0u;
         } else {
             a_off[r] = a_ok[r] ? (unsigned)((hi * Win + wi) * a.cin + cq * 4) : 0u;
         }
-        a_lds[r] = e < CQ * NP ? ((cq >> 1) * NPPAD + p) * 2 + (cq & 1) : -1;
+        a_lds[r] = p < NP ? ((cq >> 1) * NPPAD + p) * 2 + (cq & 1) : -1;
     }
     const float *ximg = UPCAT ? a.x + (size_t)img * (a.H >> 1) * (Win >> 1) * a.cin_up : a.x + img_base;
     const float *ximg2 = UPCAT ? a.x2 + (size_t)img * a.H * Win * (a.cin - a.cin_up) : nullptr;

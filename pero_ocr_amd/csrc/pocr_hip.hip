@@ -125,10 +125,11 @@ int launch_conv(Kern kern, int TH, int TW, int NT, int nthreads, ConvArgs a, hip
         a.tiles_h = (a.Ho + TH - 1) / TH;
     }
     a.tiles_n = (a.cout16 * 16) / NT;
-    // Two channel tiles per XCD: a pixel tile's halo is fetched from HBM by tiles_n / 2 XCDs instead of tiles_n (conv9: reads
-    // 6x -> 3x the algorithmic bytes), the XCD's L2 holds 2 / tiles_n of the layer's weights; throughput-neutral
-    // (profiles/r03_xcd_mapping_experiment.txt).  POCR_XCD_G=1|2|4 overrides.
-    static const int xcd_g_env = getenv("POCR_XCD_G") ? atoi(getenv("POCR_XCD_G")) : 2;
+    // Channel tiles per XCD (ConvArgs::xcd_g).  One per XCD (the default) keeps 1 / tiles_n of a layer's weights in each L2 and
+    // lets tiles_n XCDs fetch the same halo tile; two per XCD was measured: same time, and the HBM-side read bytes of conv9
+    // do NOT drop (2.34 -> 2.14 GB per launch: what the halo re-reads save, the weight stream - now 4.7 MB per XCD, over
+    // the 4 MB L2 - costs) - profiles/r03_xcd_mapping_experiment.txt.  POCR_XCD_G=2|4 selects the other mappings.
+    static const int xcd_g_env = getenv("POCR_XCD_G") ? atoi(getenv("POCR_XCD_G")) : 1;
     if (a.xcd_g == 0) a.xcd_g = xcd_g_env;
     const size_t blocks = conv_grid_blocks(a);
     if (blocks == 0) return 0;

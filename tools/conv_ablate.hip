@@ -22,26 +22,49 @@ struct Variant { const char *name; void (*fn)(ConvArgs, hipStream_t); int split;
     launch(conv3x3_bf16x3_kernel<TH, MW, NS, WM, PH, PW, ACT, BN, MINW, BDIR, 3, 3, 1, 1, false, SPL>, TH, 16 * MW, NS * (4 / WM) * 16, a, st); }
 #define VP(NAME, TH, MW, NS, WM, PH, PW, ACT, BN, MINW, BDIR) static void NAME(ConvArgs a, hipStream_t st) { \
     launch(conv3x3_bf16x3_kernel<TH, MW, NS, WM, PH, PW, ACT, BN, MINW, BDIR, 3, 3, 1, 1, false, 2, true, true>, TH, 16 * MW, NS * (4 / WM) * 16, a, st); }
+// shipped P2 configurations
 VP(p9, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true)
+VP(p8, 5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true)
+VP(p7, 2, 2, 2, 1, 2, 1, ACT_RELU, false, 2, true)
 VP(p6, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
 VP(p4, 4, 1, 2, 1, 2, 2, ACT_RELU, false, 2, true)
 VP(p3, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
-V(h3, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true, 2)
-V(b9, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true, 3)
+VP(p2, 4, 2, 2, 2, 2, 2, ACT_RELU, false, 3, false)
+// candidates (POCR sweep of round 3, P2 input / output)
+VP(p2_b, 8, 2, 2, 2, 2, 2, ACT_RELU, false, 2, false)     // conv2: 8x32, LDS weights
+VP(p2_c, 4, 2, 2, 2, 2, 2, ACT_RELU, false, 3, true)      // conv2: 4x32, weights from L2
+VP(p2_d, 8, 2, 2, 2, 2, 2, ACT_RELU, false, 2, true)      // conv2: 8x32, weights from L2
+VP(p2_e, 4, 4, 4, 4, 2, 2, ACT_RELU, false, 2, false)     // conv2: 4x64, waves split the pixels, NS 4
+VP(p2_f, 4, 4, 4, 4, 2, 2, ACT_RELU, false, 2, true)
+VP(p2_g, 4, 2, 2, 2, 2, 2, ACT_RELU, false, 2, false)     // shipped tile, 2 WG/CU budget
+VP(p2_h, 2, 4, 2, 2, 2, 2, ACT_RELU, false, 3, false)     // 2x64
+VP(p3_b, 4, 1, 2, 1, 1, 1, ACT_RELU, false, 3, true)      // conv3/5/6: 4x16, 3 WG/CU   (H = 20 only)
+VP(p3_c, 4, 2, 2, 1, 1, 1, ACT_RELU, false, 2, true)      // 4x32 (MS 8)
+VP(p3_d, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 3, true)      // shipped tile, 3 WG/CU budget
+VP(p3_e, 2, 2, 2, 1, 1, 1, ACT_RELU, false, 3, true)      // 2x32
+VP(p3_f, 5, 2, 1, 1, 1, 1, ACT_RELU, false, 2, true)      // 5x32, NS 1 (NT 64): MS 10
+VP(p3_g, 10, 1, 1, 1, 1, 1, ACT_RELU, false, 2, true)     // 10x16, NS 1 (NT 64): MS 10
+VP(p4_b, 4, 1, 2, 1, 2, 2, ACT_RELU, false, 3, true)      // conv4: shipped tile, 3 WG/CU budget
+VP(p4_c, 4, 2, 2, 1, 2, 2, ACT_RELU, false, 2, true)      // 4x32
+VP(p4_d, 2, 2, 2, 1, 2, 2, ACT_RELU, false, 3, true)      // 2x32
+VP(p7_b, 2, 2, 2, 1, 2, 1, ACT_RELU, false, 3, true)
+VP(p7_c, 2, 1, 2, 1, 2, 1, ACT_RELU, false, 3, true)      // 2x16 (MS 2)
+VP(p7_d, 10, 1, 1, 1, 2, 1, ACT_RELU, false, 2, true)     // 10x16 NS 1
+VP(p7_e, 2, 4, 1, 1, 2, 1, ACT_RELU, false, 2, true)      // 2x64 NS 1 (MS 8)
+VP(p9_b, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 3, true)      // conv8/9: 3 WG/CU budget
+VP(p9_c, 5, 2, 1, 1, 1, 1, ACT_LEAKY, true, 2, true)      // 5x32 NS 1 (NT 64)
+VP(p9_d, 5, 1, 1, 1, 1, 1, ACT_LEAKY, true, 4, true)      // 5x16 NS 1 (NT 64), 4 WG/CU
 V(h9, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true, 2)
-V(h8, 5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true, 2)
-V(h6, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true, 2)
-V(h4, 4, 1, 2, 1, 2, 2, ACT_RELU, false, 2, true, 2)
-V(h2, 4, 2, 2, 2, 2, 2, ACT_RELU, false, 3, false, 2)
 int main(int argc, char **argv) {
     const int layer = argc > 1 ? atoi(argv[1]) : 9, n = argc > 2 ? atoi(argv[2]) : 256, wpad = argc > 3 ? atoi(argv[3]) : 576;
     Shape s; std::vector<Variant> vars;
-    if (layer == 9) { s = {512, 512, 5, wpad / 4, 1, 1}; vars = {{"bf16x3 5x16 NT128", b9, 3}, {"f16x2 5x16 NT128", h9, 2}, {"f16x2 P2 5x16 NT128", p9, 2}}; }
-    else if (layer == 8) { s = {256, 512, 5, wpad / 4, 1, 1}; vars = {{"f16x2 5x16 NT128", h8, 2}}; }
-    else if (layer == 6) { s = {256, 256, 10, wpad / 4, 1, 1}; vars = {{"f16x2 5x16 NT128", h6, 2}, {"f16x2 P2 5x16 NT128", p6, 2}}; }
-    else if (layer == 4) { s = {128, 128, 20, wpad / 2, 2, 2}; vars = {{"f16x2 4x16 NT128", h4, 2}, {"f16x2 P2 4x16 NT128", p4, 2}}; }
-    else if (layer == 3) { s = {64, 128, 20, wpad / 2, 1, 1}; vars = {{"f16x2 5x16 NT128", h3, 2}, {"f16x2 P2 5x16 NT128", p3, 2}}; }
-    else { s = {64, 64, 40, wpad, 2, 2}; vars = {{"f16x2 lds 4x32 NT64 3WG", h2, 2}}; }
+    if (layer == 9) { s = {512, 512, 5, wpad / 4, 1, 1}; vars = {{"f16x2 in-kernel split 5x16 NT128", h9, 2}, {"P2 5x16 NT128 (shipped)", p9, 2}, {"P2 5x16 NT128 3WG", p9_b, 2}, {"P2 5x32 NT64", p9_c, 2}, {"P2 5x16 NT64 4WG", p9_d, 2}}; }
+    else if (layer == 8) { s = {256, 512, 5, wpad / 4, 1, 1}; vars = {{"P2 5x16 NT128 (shipped)", p8, 2}}; }
+    else if (layer == 7) { s = {256, 256, 10, wpad / 4, 2, 1}; vars = {{"P2 2x32 NT128 (shipped)", p7, 2}, {"P2 2x32 3WG", p7_b, 2}, {"P2 2x16 3WG", p7_c, 2}, {"P2 10x16 NT64", p7_d, 2}, {"P2 2x64 NT64", p7_e, 2}}; }
+    else if (layer == 6 || layer == 5) { s = {layer == 5 ? 128 : 256, 256, 10, wpad / 4, 1, 1}; vars = {{"P2 5x16 NT128 (shipped)", p6, 2}, {"P2 5x16 3WG", p3_d, 2}, {"P2 2x32 3WG", p3_e, 2}, {"P2 5x32 NT64", p3_f, 2}, {"P2 10x16 NT64", p3_g, 2}}; }
+    else if (layer == 4) { s = {128, 128, 20, wpad / 2, 2, 2}; vars = {{"P2 4x16 NT128 (shipped)", p4, 2}, {"P2 4x16 3WG", p4_b, 2}, {"P2 4x32", p4_c, 2}, {"P2 2x32 3WG", p4_d, 2}}; }
+    else if (layer == 3) { s = {64, 128, 20, wpad / 2, 1, 1}; vars = {{"P2 5x16 NT128 (shipped)", p3, 2}, {"P2 4x16 3WG", p3_b, 2}, {"P2 4x32", p3_c, 2}, {"P2 5x16 3WG", p3_d, 2}, {"P2 2x32 3WG", p3_e, 2}, {"P2 5x32 NT64", p3_f, 2}, {"P2 10x16 NT64", p3_g, 2}}; }
+    else { s = {64, 64, 40, wpad, 2, 2}; vars = {{"P2 lds 4x32 NT64 3WG (shipped)", p2, 2}, {"P2 lds 8x32", p2_b, 2}, {"P2 direct 4x32 3WG", p2_c, 2}, {"P2 direct 8x32", p2_d, 2}, {"P2 lds 4x64 M-split NS4", p2_e, 2}, {"P2 direct 4x64 M-split NS4", p2_f, 2}, {"P2 lds 4x32 2WG", p2_g, 2}, {"P2 lds 2x64 3WG", p2_h, 2}}; }
     const size_t xin = (size_t)n * s.H * s.W * s.cin, yout = (size_t)n * (s.H / s.ph) * (s.W / s.pw) * s.cout;
     std::vector<float> hx(xin);
     unsigned r = 12345;
@@ -59,7 +82,7 @@ int main(int argc, char **argv) {
     for (auto &v : vars) {
         ConvArgs a{};
         a.x = dx; a.wfrag = dw; a.bias = db; a.bn_scale = db; a.bn_shift = db; a.y = dy;
-        a.n = n; a.H = s.H; a.W = s.W; a.Ho = s.H; a.Wo = s.W; a.cin = s.cin; a.cout16 = s.cout / 16; a.cout_valid = s.cout; a.out_stride = s.cout;
+        a.n = n; a.H = s.H; a.W = s.W; a.Ho = s.H; a.Wo = s.W; a.cin = s.cin; a.cout16 = s.cout / 16; a.xcd_g = 2; a.cout_valid = s.cout; a.out_stride = s.cout;
         for (int w = 0; w < 3; ++w) v.fn(a, st);
         CK(hipStreamSynchronize(st)); CK(hipGetLastError());
         float sum = 0, best = 1e30f;

@@ -1,4 +1,7 @@
-mkdir -p gpurun_out/r3k
-timeout 1700 python -m pytest tests -x -q -m gpu -s > gpurun_out/r3k/pytest_gpu.txt 2>&1; echo "rc $?" >> gpurun_out/r3k/pytest_gpu.txt
-timeout 900 python bench.py > gpurun_out/r3k/bench_default.json 2> gpurun_out/r3k/bench_default.err
-grep -E "^\[|\[rescale|\[c[0-9]|passed|failed|rc " gpurun_out/r3k/pytest_gpu.txt | tail -14; cut -c1-700 gpurun_out/r3k/bench_default.json
+mkdir -p gpurun_out/r3n
+timeout 300 python tools/stage_times.py 256 512 > gpurun_out/r3n/stage_c2.txt 2>&1
+timeout 300 python tools/stage_times.py 256 768 vgg_sa_ctc > gpurun_out/r3n/stage_c4.txt 2>&1
+POCR_CONV_SPLIT=3 timeout 300 python tools/stage_times.py 256 512 > gpurun_out/r3n/stage_c2_bf16x3.txt 2>&1
+timeout 300 python tools/parsenet_bench.py > gpurun_out/r3n/parsenet.txt 2>&1
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_parsenet.py -x -q -m gpu > gpurun_out/r3n/pytest.txt 2>&1; echo "rc $?" >> gpurun_out/r3n/pytest.txt
+cat gpurun_out/r3n/stage_c2.txt gpurun_out/r3n/stage_c4.txt gpurun_out/r3n/stage_c2_bf16x3.txt; tail -3 gpurun_out/r3n/parsenet.txt; tail -3 gpurun_out/r3n/pytest.txt
