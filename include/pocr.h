@@ -330,6 +330,14 @@ int pocr_parsenet_create(const float *weights, size_t n_floats, int device_id, p
 void pocr_parsenet_destroy(pocr_parsenet *p);
 int pocr_parsenet_out_shape(int32_t h, int32_t w, int32_t downsample, int32_t *out_h, int32_t *out_w);
 int pocr_parsenet_get_maps(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, int32_t W, int32_t downsample, float *out_hw5);
+/* The same for a FRACTIONAL down-sampling factor (get_maps_with_optimal_resolution remembers one after the first page,
+ * torch_parsenet.py:60-93): the area resample runs on the device from separable tap tables the caller builds - output row o
+ * = sum over a < taps_y of wy[o][a] * source row min(y0[o] + a, H - 1), columns alike; float64, rows first, products rounded
+ * before they are added, then rint - exactly the host restatement `resize_area` (parity of cv2.resize(INTER_AREA) itself:
+ * unpinned, no OpenCV in the build image).  out_hw5: float32 [out_h][out_w][5]. */
+int pocr_parsenet_get_maps_area(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
+                                const double *wy, const int32_t *y0, int32_t taps_y, const double *wx, const int32_t *x0, int32_t taps_x,
+                                float *out_hw5);
 /* GPU time in ms of the last get_maps between the end of the upload and the end of the last kernel (HIP events). */
 int pocr_parsenet_last_ms(pocr_parsenet *p, float *ms);
 

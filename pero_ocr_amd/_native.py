@@ -114,6 +114,8 @@ SYMBOLS = {
     "pocr_parsenet_destroy": (None, [C.c_void_p]),
     "pocr_parsenet_out_shape": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p]),
     "pocr_parsenet_get_maps": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, C.c_int32, _f32p]),
+    "pocr_parsenet_get_maps_area": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), _i32p,
+                                              C.c_int32, C.POINTER(C.c_double), _i32p, C.c_int32, _f32p]),
     "pocr_parsenet_last_ms": (C.c_int, [C.c_void_p, _f32p]),
     "pocr_last_stage_ms": (C.c_int, [C.c_void_p, _f32p, C.c_int32]),
     "pocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -499,6 +501,21 @@ class NativeParseNet:
         out = np.empty((h, w, 5), dtype=np.float32)
         if self._lib.pocr_parsenet_get_maps(self._h, _ptr(im, _u8p), im.shape[0], im.shape[1], int(downsample), _ptr(out, _f32p)):
             raise RuntimeError("pocr_parsenet_get_maps: " + (self._lib.pocr_last_error() or b"").decode("utf8", "replace"))
+        return out
+
+    def get_maps_area(self, img: np.ndarray, wy, y0, wx, x0) -> np.ndarray:
+        """Fractional INTER_AREA on the device from separable tap tables (wy [oh, ty], y0 [oh], wx [ow, tx], x0 [ow]),
+        then the network: uint8 [H, W, 3] -> float32 [oh, ow, 5]."""
+        im = np.ascontiguousarray(img, dtype=np.uint8)
+        wy_, wx_ = np.ascontiguousarray(wy, dtype=np.float64), np.ascontiguousarray(wx, dtype=np.float64)
+        y0_, x0_ = np.ascontiguousarray(y0, dtype=np.int32), np.ascontiguousarray(x0, dtype=np.int32)
+        oh, ow = wy_.shape[0], wx_.shape[0]
+        out = np.empty((oh, ow, 5), dtype=np.float32)
+        dp = C.POINTER(C.c_double)
+        if self._lib.pocr_parsenet_get_maps_area(self._h, _ptr(im, _u8p), im.shape[0], im.shape[1], oh, ow, wy_.ctypes.data_as(dp),
+                                                 _ptr(y0_, _i32p), wy_.shape[1], wx_.ctypes.data_as(dp), _ptr(x0_, _i32p), wx_.shape[1],
+                                                 _ptr(out, _f32p)):
+            raise RuntimeError("pocr_parsenet_get_maps_area: " + (self._lib.pocr_last_error() or b"").decode("utf8", "replace"))
         return out
 
     def last_ms(self) -> float:

@@ -244,9 +244,99 @@ class EngineLineCropper:
         return (out, grids) if want_grids else out
 
     def crop(self, img, baseline, heights, return_mapping=False, return_forward_mapping=False):
-        if return_mapping:
-            raise NotImplementedError("return_mapping (reverse mapping for blend_in) is not built for MI355X")
+        """crop_engine.py:16-30.  return_mapping: (crop, reverse mapping, offset) for `blend_in`; return_forward_mapping:
+        (crop, float32 [H, w, 2] sampling grid).  The reference computes the reverse mapping from `line_coords` even when the
+        crop failed (then line_coords is unbound and it raises UnboundLocalError / NameError); here that case raises ValueError."""
         (line_crop,) = self.crop_lines(img, [(baseline, heights)])
+        if return_mapping:
+            try:
+                line_coords = self.get_crop_inputs(baseline, heights, self.line_height)
+            except Exception as exc:
+                raise ValueError("return_mapping: the line has no sampling grid (the crop is the fallback crop)") from exc
+            line_mapping, offset = self.reverse_xy_mapping(line_coords, img.shape)
+            return line_crop, line_mapping, offset
         if return_forward_mapping:
             return line_crop, self.get_crop_inputs(baseline, heights, self.line_height)
         return line_crop
+
+    # ---- writing a (changed) crop back into the page: crop_engine.py:32-52, 113-145 (host code, like the reference) ----
+    @staticmethod
+    def _resize4_linear(a: np.ndarray) -> np.ndarray:
+        """cv2.resize(a, (0, 0), fx=4, fy=4, interpolation=cv2.INTER_LINEAR) for a float 2-D array, restated from OpenCV's
+        resize (pixel centres aligned: source x = (i + 0.5) / 4 - 0.5; outside [0, n - 1] the edge sample is taken with
+        weight 1; float32 weights, rows then columns).  PARITY UNPINNED like the other OpenCV halves (no cv2 in this image)."""
+        a = np.asarray(a, dtype=np.float32)
+
+        def taps(n):
+            f = (np.arange(4 * n, dtype=np.float32) + np.float32(0.5)) * np.float32(0.25) - np.float32(0.5)
+            i0 = np.floor(f).astype(np.int64)
+            w = (f - i0.astype(np.float32)).astype(np.float32)
+            lo = i0 < 0
+            hi = i0 >= n - 1
+            i0 = np.clip(i0, 0, max(n - 1, 0))
+            w = np.where(lo | hi, np.float32(0), w)
+            return i0, np.minimum(i0 + 1, n - 1), w
+        y0, y1, wy = taps(a.shape[0])
+        x0, x1, wx = taps(a.shape[1])
+        rows = a[:, x0] * (np.float32(1) - wx)[None, :] + a[:, x1] * wx[None, :]
+        return (rows[y0] * (np.float32(1) - wy)[:, None] + rows[y1] * wy[:, None]).astype(np.float32)
+
+    def reverse_xy_mapping(self, forward_mapping, shape):
+        """crop_engine.py:113-137: the sampling grid upsampled x4, every upsampled sample rounded to its page pixel, and for
+        each page pixel of the line's bounding box the crop coordinates (x, y) of the LAST sample that landed on it
+        (-1: none).  -> (float32 [h, w, 2], (ystart, xstart))."""
+        fm = np.asarray(forward_mapping)
+        y_mapping = np.round(np.clip(self._resize4_linear(fm[:, :, 1]), 0, shape[0] - 1)).astype(int)
+        x_mapping = np.round(np.clip(self._resize4_linear(fm[:, :, 0]), 0, shape[1] - 1)).astype(int)
+        ystart, ystop = int(np.amin(y_mapping)), int(np.amax(y_mapping)) + 1
+        xstart, xstop = int(np.amin(x_mapping)), int(np.amax(x_mapping)) + 1
+        y_map = self._resize4_linear(np.tile(np.arange(0, fm.shape[0]), (fm.shape[1], 1)).T.astype(np.float32))
+        x_map = self._resize4_linear(np.tile(np.arange(0, fm.shape[1]), (fm.shape[0], 1)).astype(np.float32))
+        reverse_mapping = np.ones((ystop - ystart, xstop - xstart, 2), dtype=np.float32) * -1
+        # the reference's Python loop assigns sample after sample in row-major order: the last one wins, which is what
+        # numpy's indexed assignment does for repeated indices
+        dy, dx = (y_mapping - ystart).reshape(-1), (x_mapping - xstart).reshape(-1)
+        reverse_mapping[dy, dx, 0] = x_map.reshape(-1)
+        reverse_mapping[dy, dx, 1] = y_map.reshape(-1)
+        return reverse_mapping, (ystart, xstart)
+
+    def get_blend_mask(self, mapping):
+        """crop_engine.py:139-145."""
+        from scipy import ndimage
+        b = self.blend_border
+        mask = mapping[:, :, 0] > -1
+        mask = np.pad(mask, ((b, b), (b, b)))
+        mask = ndimage.uniform_filter(mask.astype(float), size=2 * b + 1)
+        mask = mask[b:-b, b:-b]
+        mask = 2 * np.clip(mask - 0.5, 0, 1)
+        return mask[:, :, np.newaxis]
+
+    @staticmethod
+    def _remap_transparent_u8(src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray, dst: np.ndarray) -> None:
+        """cv2.remap(src, map_x, map_y, INTER_LINEAR, borderMode=BORDER_TRANSPARENT, dst=dst) for 8-bit images, in place:
+        OpenCV's fixed-point bilinear (coordinates to 1/32 pixel, 15-bit weights, (sum + 2^14) >> 15 - the arithmetic of
+        csrc/crop.hpp) for the destination pixels whose 2 x 2 source footprint lies inside `src`; all others keep dst."""
+        h, w = src.shape[:2]
+        sx = np.rint(map_x.astype(np.float32) * np.float32(32)).astype(np.int64)
+        sy = np.rint(map_y.astype(np.float32) * np.float32(32)).astype(np.int64)
+        ix, iy, fx, fy = sx >> 5, sy >> 5, sx & 31, sy & 31
+        ok = (ix >= 0) & (iy >= 0) & (ix < w - 1) & (iy < h - 1)
+        if not ok.any():
+            return
+        ixo, iyo, fxo, fyo = ix[ok], iy[ok], fx[ok], fy[ok]
+        s = src.astype(np.int64)
+        ex = (lambda a: a[:, None]) if src.ndim == 3 else (lambda a: a)
+        acc = (ex((32 - fxo) * (32 - fyo) * 32) * s[iyo, ixo] + ex(fxo * (32 - fyo) * 32) * s[iyo, ixo + 1] +
+               ex((32 - fxo) * fyo * 32) * s[iyo + 1, ixo] + ex(fxo * fyo * 32) * s[iyo + 1, ixo + 1])
+        dst[ok] = np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+
+    def blend_in(self, img, line_crop, mapping, offset):
+        """crop_engine.py:32-52: writes `line_crop` back over the page region it was cropped from (in place, returns img)."""
+        ystart, xstart = offset[0], offset[1]
+        ystop, xstop = ystart + mapping.shape[0], xstart + mapping.shape[1]
+        blended_img = img[ystart:ystop, xstart:xstop].copy()
+        mask = self.get_blend_mask(mapping)
+        self._remap_transparent_u8(np.asarray(line_crop), mapping[:, :, 0], mapping[:, :, 1], blended_img)
+        blended_img = np.round((1 - mask) * img[ystart:ystop, xstart:xstop] + mask * blended_img).astype(np.uint8)
+        img[ystart:ystop, xstart:xstop] = blended_img
+        return img

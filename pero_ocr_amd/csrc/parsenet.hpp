@@ -30,6 +30,35 @@ __global__ __launch_bounds__(256) void area_downsample_u8_kernel(const uint8_t *
     dst[idx] = (uint8_t)min(max(v, 0), 255);
 }
 
+// INTER_AREA for a FRACTIONAL factor (what get_maps_with_optimal_resolution asks for on every page after the first): the host
+// builds the separable tap tables (pero_ocr_amd/layout_engines/torch_parsenet._area_taps: output o covers the source interval
+// [o * scale, (o + 1) * scale), <= ceil(scale) + 1 taps weighted by the covered length, rows normalised) and this kernel applies
+// them in float64 exactly as the host's two sparse products do - rows first, then columns, every product rounded before it is
+// added (no fma contraction), taps in ascending order from 0.0 - so device and host agree bit for bit; then rint, clip.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void area_resample_u8_kernel(const uint8_t *src, int H, int W, const double *wy, const int32_t *y0, int ty,
+                                                               const double *wx, const int32_t *x0, int tx, uint8_t *dst, int Ho, int Wo) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Ho * Wo * 3) return;
+    const int c = idx % 3, x = (idx / 3) % Wo, y = idx / (3 * Wo);
+    const int ys = y0[y], xs = x0[x];
+    double acc = 0.0;
+    for (int b = 0; b < tx; ++b) {
+        const int xx = min(xs + b, W - 1);
+        double col = 0.0;
+        for (int a = 0; a < ty; ++a) {
+            const int yy = min(ys + a, H - 1);
+            const double prod = wy[(size_t)y * ty + a] * (double)src[((size_t)yy * W + xx) * 3 + c];
+            col = col + prod;
+        }
+        const double prod2 = wx[(size_t)x * tx + b] * col;
+        acc = acc + prod2;
+    }
+    const double r = rint(acc);
+    dst[idx] = (uint8_t)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
+}
+#pragma clang fp contract(fast)
+
 // y0 [Hp][Wp][64] (decoder output) -> out [h][w][5]: z = W y + b (fmaf chain over the 64 channels), channels 0, 1 ReLU,
 // channels 2..4 sigmoid; only the un-padded h x w pixels are written.
 __global__ __launch_bounds__(256) void parsenet_head_kernel(const float *y0, int Wp, const float *w5x64, const float *b5, float *out, int h, int w) {

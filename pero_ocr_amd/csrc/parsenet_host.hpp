@@ -21,6 +21,9 @@ struct pocr_parsenet {
     PnLayer enc[13], dec[6];
     DevBuf head_w, head_b, lut, lines, tiles, wline, ooff;
     DevBuf page, small;                    // uint8 page as uploaded / after the area down-sampling
+    DevBuf taps;                           // separable area weights of a fractional down-sampling (pocr_parsenet_get_maps_area)
+    void *pin_taps = nullptr;
+    size_t pin_taps_cap = 0;
     DevBuf x[7], p[7], y[6], out;          // skips x0..x5 + bottleneck x6, pooled maps p1..p6, decoder outputs y5..y0
     void *pin_in = nullptr, *pin_out = nullptr;
     size_t pin_in_cap = 0, pin_out_cap = 0;
@@ -57,7 +60,8 @@ void pocr_parsenet_destroy(pocr_parsenet *p) {
     (void)locked_device_sync();
     for (auto &l : p->enc) { l.w.release(); l.b.release(); }
     for (auto &l : p->dec) { l.w.release(); l.b.release(); }
-    for (DevBuf *b : {&p->head_w, &p->head_b, &p->lut, &p->lines, &p->tiles, &p->wline, &p->ooff, &p->page, &p->small, &p->out}) b->release();
+    for (DevBuf *b : {&p->head_w, &p->head_b, &p->lut, &p->lines, &p->tiles, &p->wline, &p->ooff, &p->page, &p->small, &p->taps, &p->out}) b->release();
+    if (p->pin_taps) (void)locked_host_free(p->pin_taps);
     for (auto &b : p->x) b.release();
     for (auto &b : p->p) b.release();
     for (auto &b : p->y) b.release();
@@ -147,7 +151,26 @@ int pocr_parsenet_out_shape(int32_t h, int32_t w, int32_t downsample, int32_t *o
     return 0;
 }
 
+struct AreaTaps { const double *wy, *wx; const int32_t *y0, *x0; int oh, ow, ty, tx; };
+
+static int parsenet_get_maps_impl(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, int32_t W, int32_t downsample, const AreaTaps *taps, float *out_hw5);
+
 int pocr_parsenet_get_maps(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, int32_t W, int32_t downsample, float *out_hw5) {
+    return parsenet_get_maps_impl(p, img_hwc, H, W, downsample, nullptr, out_hw5);
+}
+
+int pocr_parsenet_get_maps_area(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, int32_t W, int32_t out_h, int32_t out_w,
+                                const double *wy, const int32_t *y0, int32_t taps_y, const double *wx, const int32_t *x0, int32_t taps_x,
+                                float *out_hw5) {
+    if (!wy || !y0 || !wx || !x0) return fail("NULL tap table");
+    if (out_h < 1 || out_w < 1 || taps_y < 1 || taps_x < 1 || taps_y > 64 || taps_x > 64) return fail("invalid resample geometry");
+    for (int i = 0; i < out_h; ++i) if (y0[i] < 0 || y0[i] >= H) return fail("row tap start %d outside the page", y0[i]);
+    for (int i = 0; i < out_w; ++i) if (x0[i] < 0 || x0[i] >= W) return fail("column tap start %d outside the page", x0[i]);
+    AreaTaps t{wy, wx, y0, x0, out_h, out_w, taps_y, taps_x};
+    return parsenet_get_maps_impl(p, img_hwc, H, W, 1, &t, out_hw5);
+}
+
+static int parsenet_get_maps_impl(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, int32_t W, int32_t downsample, const AreaTaps *taps, float *out_hw5) {
     if (!p) return fail("handle is NULL");
     if (!img_hwc || !out_hw5) return fail("NULL buffer");
     if (H <= 0 || W <= 0 || downsample < 1) return fail("invalid page size / downsample");
@@ -155,6 +178,7 @@ int pocr_parsenet_get_maps(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, 
     hipStream_t st = p->stream;
     int h = H, w = W;
     if (downsample > 1) { h = cv_round_div(H, downsample); w = cv_round_div(W, downsample); }
+    if (taps) { h = taps->oh; w = taps->ow; }
     if (h < 1 || w < 1) return fail("page too small for this downsample");
     const int Hp = round_up(h, 64), Wp = round_up(w, 64);
     if ((size_t)Hp * Wp * 128 >= 0xffffffffull) return fail("page too large (%d x %d after padding)", Hp, Wp);
@@ -171,6 +195,28 @@ int pocr_parsenet_get_maps(pocr_parsenet *p, const uint8_t *img_hwc, int32_t H, 
     HIP_TRY(hipMemcpyAsync(p->page.p, p->pin_in, in_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipEventRecord(p->ev0, st));
     const uint8_t *src = p->page.as<uint8_t>();
+    if (taps) {          // fractional factor: separable area weights from the host, applied in float64 (parsenet.hpp)
+        const size_t yb = (size_t)h * taps->ty * 8, xb = (size_t)w * taps->tx * 8, y0b = (size_t)h * 4, x0b = (size_t)w * 4;
+        const size_t need = yb + xb + y0b + x0b;
+        if (p->small.reserve((size_t)h * w * 3) || p->taps.reserve(need)) return 1;
+        if (need > p->pin_taps_cap) {
+            if (p->pin_taps) (void)locked_host_free(p->pin_taps);
+            p->pin_taps = nullptr; p->pin_taps_cap = 0;
+            HIP_TRY(locked_host_malloc(&p->pin_taps, need + need / 4, hipHostMallocDefault));
+            p->pin_taps_cap = need + need / 4;
+        }
+        char *pt = static_cast<char *>(p->pin_taps);
+        memcpy(pt, taps->wy, yb); memcpy(pt + yb, taps->wx, xb); memcpy(pt + yb + xb, taps->y0, y0b); memcpy(pt + yb + xb + y0b, taps->x0, x0b);
+        HIP_TRY(hipMemcpyAsync(p->taps.p, pt, need, hipMemcpyHostToDevice, st));
+        const char *dt = static_cast<const char *>(p->taps.p);
+        const int total = h * w * 3;
+        hipLaunchKernelGGL(area_resample_u8_kernel, dim3((total + 255) / 256), dim3(256), 0, st, src, H, W,
+                           reinterpret_cast<const double *>(dt), reinterpret_cast<const int32_t *>(dt + yb + xb), taps->ty,
+                           reinterpret_cast<const double *>(dt + yb), reinterpret_cast<const int32_t *>(dt + yb + xb + y0b), taps->tx,
+                           p->small.as<uint8_t>(), h, w);
+        HIP_TRY(hipGetLastError());
+        src = p->small.as<uint8_t>();
+    } else
     if (downsample > 1) {
         if (p->small.reserve((size_t)h * w * 3)) return 1;
         const int total = h * w * 3;

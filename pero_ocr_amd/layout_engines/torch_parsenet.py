@@ -46,20 +46,31 @@ def load_blob(path: str) -> np.ndarray:
     return flat
 
 
-def _area_weights(n_in: int, n_out: int):
-    """Sparse [n_out, n_in] matrix of INTER_AREA weights: output o covers the source interval [o * scale, (o + 1) * scale),
-    at most ceil(scale) + 1 taps, each weighted by the covered length, rows normalised."""
-    from scipy import sparse
+def _area_taps(n_in: int, n_out: int):
+    """INTER_AREA tap table of one axis: output o covers the source interval [o * scale, (o + 1) * scale) - at most
+    ceil(scale) + 1 taps starting at first[o], each weighted by the covered length, rows normalised (float64).
+    -> (weights [n_out, taps], first [n_out]); tap a of output o reads source index min(first[o] + a, n_in - 1)."""
     scale = n_in / n_out
     taps = int(np.ceil(scale)) + 1
     o = np.arange(n_out, dtype=np.float64)
     a, b = o * scale, np.minimum((o + 1.0) * scale, float(n_in))
-    idx = np.floor(a).astype(np.int64)[:, None] + np.arange(taps, dtype=np.int64)[None, :]
+    first = np.floor(a).astype(np.int64)
+    idx = first[:, None] + np.arange(taps, dtype=np.int64)[None, :]
     wgt = np.minimum(b[:, None], idx + 1.0) - np.maximum(a[:, None], idx.astype(np.float64))
     wgt = np.where((idx < n_in) & (wgt > 0), wgt, 0.0)
     wgt /= wgt.sum(axis=1, keepdims=True)
+    return wgt, first.astype(np.int32)
+
+
+def _area_weights(n_in: int, n_out: int):
+    """The same table as a sparse [n_out, n_in] matrix (host resample)."""
+    from scipy import sparse
+    wgt, first = _area_taps(n_in, n_out)
+    taps = wgt.shape[1]
+    idx = first.astype(np.int64)[:, None] + np.arange(taps, dtype=np.int64)[None, :]
     rows = np.repeat(np.arange(n_out, dtype=np.int64), taps)
-    return sparse.csr_matrix((wgt.reshape(-1), (rows, np.minimum(idx, n_in - 1).reshape(-1))), shape=(n_out, n_in))
+    m = sparse.coo_matrix((wgt.reshape(-1), (rows, np.minimum(idx, n_in - 1).reshape(-1))), shape=(n_out, n_in))
+    return m.tocsr()
 
 
 def resize_area(img: np.ndarray, downsample: float) -> np.ndarray:
@@ -113,7 +124,12 @@ class TorchParseNet(Net):
         ds = float(downsample)
         if ds == int(ds) and ds >= 1:
             return self.net.get_maps(img, int(ds))
-        return self.net.get_maps(resize_area(np.asarray(img), ds), 1)
+        # fractional factor (every page after the first once the adaptive factor is remembered): the area resample runs on
+        # the device from the same tap tables the host restatement `resize_area` uses - bit-identical to it (tested)
+        im = np.asarray(img)
+        oh, ow = int(np.rint(im.shape[0] / ds)), int(np.rint(im.shape[1] / ds))
+        (wy, y0), (wx, x0) = _area_taps(im.shape[0], oh), _area_taps(im.shape[1], ow)
+        return self.net.get_maps_area(im, wy, y0, wx, x0)
 
     def get_maps_with_optimal_resolution(self, img):
         """The reference's memory-safe two-pass scheme (:60-93): a first pass at max(last_downsample, megapixel limit);

@@ -122,8 +122,26 @@ def test_gpu_cropper_end_to_end():
     assert many[-1].shape == (40, 32, 3) and not many[-1].any()
     crop0, fwd = eng.crop(page, np.array([[50, 180], [562, 180]]), [30, 10], return_forward_mapping=True)
     assert crop0.shape[:2] == fwd.shape[:2] == (40, 512)
-    with pytest.raises(NotImplementedError):
-        eng.crop(page, np.array([[50, 180], [562, 180]]), [30, 10], return_mapping=True)
+    # reverse mapping + blend_in (crop_engine.py:24-26, 32-52, 113-145).  The reference's reverse mapping is crude by design
+    # (each page pixel gets the crop coordinates of the LAST of the x4-upsampled samples that round to it: up to 0.4 px
+    # off), so the round-trip property is stated on a SMOOTH page: writing the unchanged crop back leaves it within a few
+    # grey levels, nothing outside the line's bounding box moves, and writing an inverted crop back changes the line's interior.
+    yy, xx = np.mgrid[0:700, 0:700]
+    smooth = np.repeat((128 + 60 * np.sin(xx / 23.0) * np.cos(yy / 31.0) + 0.08 * xx)[:, :, None], 3, axis=2).astype(np.uint8)
+    for baseline, heights in ((np.array([[50, 180], [562, 180]]), [30, 10]), (np.array([[60, 300], [300, 320], [600, 290]]), [25, 12])):
+        crop1, mapping, (y0, x0) = eng.crop(smooth, baseline, heights, return_mapping=True)
+        assert mapping.dtype == np.float32 and mapping.shape[2] == 2 and mapping.min() >= -1
+        covered = mapping[:, :, 0] > -1
+        assert covered.mean() > 0.5 and mapping[:, :, 0].max() <= crop1.shape[1] - 1 and mapping[:, :, 1].max() <= crop1.shape[0] - 1
+        back = eng.blend_in(smooth.copy(), crop1, mapping, (y0, x0))
+        region = (slice(y0, y0 + mapping.shape[0]), slice(x0, x0 + mapping.shape[1]))
+        diff = np.abs(back.astype(int) - smooth.astype(int))
+        assert not diff[:y0].any() and not diff[y0 + mapping.shape[0]:].any()              # nothing outside the line's box
+        assert np.mean(diff[region]) < 1.5 and diff.max() <= 8, (np.mean(diff[region]), diff.max())
+        inv = eng.blend_in(smooth.copy(), 255 - crop1, mapping, (y0, x0))
+        changed = np.abs(inv.astype(int) - smooth.astype(int))[region].mean(axis=2) > 10
+        inner = eng.get_blend_mask(mapping)[:, :, 0] > 0.99
+        assert inner.mean() > 0.3 and changed[inner].mean() > 0.8          # (grey levels near 128 invert onto themselves)
 
 
 @pytest.mark.gpu
@@ -353,3 +371,29 @@ def test_crops_stay_in_hbm_between_cropper_and_recogniser(golden, tmp_path):
     staged.clear()
     ocr.process_pages(c)
     assert [ln.transcription for ln in lc] == [ln.transcription for ln in la]
+
+
+def test_reverse_mapping_host_pieces():
+    """CPU: the x4 bilinear upsampling of reverse_xy_mapping on a ramp is the ramp at quarter steps (edge samples held), the
+    reverse mapping of an axis-aligned grid points every covered page pixel back at its own crop coordinates, and a pixel no
+    sample lands on stays -1."""
+    eng = EngineLineCropper(line_height=8)
+    ramp = np.tile(np.arange(6, dtype=np.float32), (3, 1))
+    up = eng._resize4_linear(ramp)
+    assert up.shape == (12, 24)
+    want = np.clip((np.arange(24) + 0.5) / 4 - 0.5, 0, 5)
+    assert np.allclose(up[0], want, atol=1e-6) and np.allclose(up[5], want, atol=1e-6)
+    # a grid that maps crop pixel (r, c) to page pixel (20 + r, 30 + c)
+    gy, gx = np.meshgrid(np.arange(8, dtype=np.float32), np.arange(16, dtype=np.float32), indexing="ij")
+    fwd = np.stack((gx + 30, gy + 20), axis=2)
+    rev, (y0, x0) = eng.reverse_xy_mapping(fwd, (100, 100, 3))
+    assert (y0, x0) == (20, 30) and rev.shape == (8, 16, 2)
+    assert np.all(np.abs(rev[:, :, 0] - gx) <= 0.5 + 1e-6) and np.all(np.abs(rev[:, :, 1] - gy) <= 0.5 + 1e-6)
+    # stretched x2 horizontally: every second page column is hit by upsampled samples too (x4), none stays empty
+    rev2, _ = eng.reverse_xy_mapping(np.stack((2 * gx + 30, gy + 20), axis=2), (100, 100, 3))
+    assert rev2.shape == (8, 31, 2) and (rev2[:, :, 0] > -1).all()
+    # stretched x8: the x4 upsampling leaves gaps -> -1 entries, and the blend mask is < 1 there
+    rev8, _ = eng.reverse_xy_mapping(np.stack((8 * gx + 30, gy + 20), axis=2), (200, 200, 3))
+    assert (rev8[:, :, 0] == -1).any()
+    m = eng.get_blend_mask(rev8)
+    assert m.shape == rev8.shape[:2] + (1,) and 0.0 <= m.min() and m.max() <= 1.0

@@ -123,6 +123,16 @@ def test_gpu_area_downsampling_and_engine_surface(tmp_path):
     for ds in (2, 3, 4):
         small = po.area_downsample_int(page, ds)
         assert np.array_equal(eng.get_maps(page, ds), eng.get_maps(small, 1)), ds
+    # fractional factors (what every page after the first takes once the adaptive factor is remembered): the
+    # area resample runs on the device from the host's tap tables - the maps must equal those of the host resample exactly
+    import time
+    for ds in (3.3, 1.7, 2.05, 4.6):
+        assert np.array_equal(eng.get_maps(page, ds), eng.get_maps(tp.resize_area(page, ds), 1)), ds
+    big = synth.make_page(22, 1500, 2000)
+    eng.get_maps(big, 3.3)
+    t0 = time.perf_counter()
+    got = eng.get_maps(big, 3.3)
+    assert got.shape == (455, 606, 5) and time.perf_counter() - t0 < 0.25          # (host resample alone: ~0.2-0.5 s)
     out, used = eng.get_maps_with_optimal_resolution(page)
     assert used == 4 and out.shape == (101, 152, 5)
     eng.adaptive_downsample = True

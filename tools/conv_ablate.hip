@@ -55,10 +55,29 @@ VP(p9_b, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 3, true)      // conv8/9: 3 WG/CU bu
 VP(p9_c, 5, 2, 1, 1, 1, 1, ACT_LEAKY, true, 2, true)      // 5x32 NS 1 (NT 64)
 VP(p9_d, 5, 1, 1, 1, 1, 1, ACT_LEAKY, true, 4, true)      // 5x16 NS 1 (NT 64), 4 WG/CU
 V(h9, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true, 2)
+// GEMM mode (1x1): rows x cin -> cout, "pixels" = rows.  (TH, MW, NS, WM, MINW, BDIR, PRE_IN, PRE_OUT)
+#define VG(NAME, MW, NS, WM, MINW, BDIR, PIN, POUT) static void NAME(ConvArgs a, hipStream_t st) { \
+    launch(conv3x3_bf16x3_kernel<1, MW, NS, WM, 1, 1, ACT_NONE, false, MINW, BDIR, 1, 1, 0, 0, false, 2, PIN, POUT>, 1, 16 * MW, NS * (4 / WM) * 16, a, st); }
+VG(g_ship, 8, 4, 2, 2, false, false, false)     // shipped: 128 x 128, LDS weights, split inside
+VG(g_pin, 8, 4, 2, 2, false, true, false)       // the same with pre-split input
+VG(g_pin_d, 8, 4, 2, 2, true, true, false)      // + weights straight from L2
+VG(g_pin_out, 8, 4, 2, 2, false, true, true)    // pre-split in and out
+VG(g_pin_8x2, 8, 2, 1, 2, true, true, false)    // 128 rows x 128 cols, waves split the columns (MS 8, NS 2), direct weights
+VG(g_pin_4x4, 4, 4, 1, 1, true, true, false)    // 64 rows x 256 cols (MS 4, NS 4), direct weights
+VG(g_pin_8x4m, 8, 4, 4, 2, false, true, false)  // 128 rows x 64 cols, waves split the rows (MS 2, NS 4), LDS weights
+VG(g_pin_16, 16, 4, 4, 1, false, true, false)   // 256 rows x 64 cols, waves split the rows (MS 4, NS 4), LDS weights
 int main(int argc, char **argv) {
-    const int layer = argc > 1 ? atoi(argv[1]) : 9, n = argc > 2 ? atoi(argv[2]) : 256, wpad = argc > 3 ? atoi(argv[3]) : 576;
+    const int layer = argc > 1 ? atoi(argv[1]) : 9, wpad = argc > 3 ? atoi(argv[3]) : 576;
+    int n = argc > 2 ? atoi(argv[2]) : 256;
+    if (layer >= 100) n = 1;
     Shape s; std::vector<Variant> vars;
-    if (layer == 9) { s = {512, 512, 5, wpad / 4, 1, 1}; vars = {{"f16x2 in-kernel split 5x16 NT128", h9, 2}, {"P2 5x16 NT128 (shipped)", p9, 2}, {"P2 5x16 NT128 3WG", p9_b, 2}, {"P2 5x32 NT64", p9_c, 2}, {"P2 5x16 NT64 4WG", p9_d, 2}}; }
+    if (layer >= 100) {       // GEMM mode: 100 = 512 -> 2048 (FFN1 / LSTM projection), 101 = 2048 -> 512 (FFN2), 102 = 512 -> 512
+        const int rows = 53248;
+        s = {layer == 101 ? 2048 : 512, layer == 100 ? 2048 : 512, 1, rows, 1, 1};
+        vars = {{"GEMM 128x128 LDS, split inside (shipped)", g_ship, 2}, {"GEMM P2 in", g_pin, 2}, {"GEMM P2 in, direct weights", g_pin_d, 2},
+                {"GEMM P2 in + out", g_pin_out, 2}, {"GEMM P2 128x128 N-split direct", g_pin_8x2, 2}, {"GEMM P2 64x256 direct", g_pin_4x4, 2},
+                {"GEMM P2 128x64 M-split LDS", g_pin_8x4m, 2}, {"GEMM P2 256x64 M-split LDS", g_pin_16, 2}};
+    } else if (layer == 9) { s = {512, 512, 5, wpad / 4, 1, 1}; vars = {{"f16x2 in-kernel split 5x16 NT128", h9, 2}, {"P2 5x16 NT128 (shipped)", p9, 2}, {"P2 5x16 NT128 3WG", p9_b, 2}, {"P2 5x32 NT64", p9_c, 2}, {"P2 5x16 NT64 4WG", p9_d, 2}}; }
     else if (layer == 8) { s = {256, 512, 5, wpad / 4, 1, 1}; vars = {{"P2 5x16 NT128 (shipped)", p8, 2}}; }
     else if (layer == 7) { s = {256, 256, 10, wpad / 4, 2, 1}; vars = {{"P2 2x32 NT128 (shipped)", p7, 2}, {"P2 2x32 3WG", p7_b, 2}, {"P2 2x16 3WG", p7_c, 2}, {"P2 10x16 NT64", p7_d, 2}, {"P2 2x64 NT64", p7_e, 2}}; }
     else if (layer == 6 || layer == 5) { s = {layer == 5 ? 128 : 256, 256, 10, wpad / 4, 1, 1}; vars = {{"P2 5x16 NT128 (shipped)", p6, 2}, {"P2 5x16 3WG", p3_d, 2}, {"P2 2x32 3WG", p3_e, 2}, {"P2 5x32 NT64", p3_f, 2}, {"P2 10x16 NT64", p3_g, 2}}; }
@@ -69,7 +88,7 @@ int main(int argc, char **argv) {
     std::vector<float> hx(xin);
     unsigned r = 12345;
     for (auto &v : hx) { r = r * 1664525u + 1013904223u; v = ((r >> 8) & 0xffff) / 32768.0f - 1.0f; }
-    std::vector<uint16_t> hw((size_t)9 * s.cin * 512 * 3);
+    std::vector<uint16_t> hw((size_t)9 * s.cin * 2048 * 3);
     for (auto &v : hw) { r = r * 1664525u + 1013904223u; v = (uint16_t)(0x2c00 + ((r >> 9) & 0x3ff)) | (uint16_t)((r >> 3) & 0x8000); }   // random small f16 / bf16 bit patterns
     float *dx, *dw, *db, *dy;
     CK(hipMalloc(&dx, xin * 4)); CK(hipMalloc(&dw, hw.size() * 2)); CK(hipMalloc(&db, 4096 * 4)); CK(hipMalloc(&dy, yout * 4));
@@ -77,7 +96,7 @@ int main(int argc, char **argv) {
     CK(hipMemset(db, 0, 4096 * 4));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const double flops = 2.0 * n * s.H * s.W * (double)s.cout * s.cin * 9;
+    const double flops = 2.0 * n * s.H * s.W * (double)s.cout * s.cin * (layer >= 100 ? 1 : 9);
     printf("DBG=%d conv%d %d->%d @%dx%d n=%d\n", POCR_BF16X3_DBG, layer, s.cin, s.cout, s.H, s.W, n);
     for (auto &v : vars) {
         ConvArgs a{};
