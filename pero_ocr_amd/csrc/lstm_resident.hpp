@@ -1,0 +1,252 @@
+// lstm_resident.hpp — a whole BiLSTM layer's recurrence in ONE launch: the hidden state is handed from step to step inside the
+// chip, through the L2 of the XCD the cooperating workgroups sit on.
+//
+// lstm.hpp runs one launch per time step (the kernel boundary is the step barrier): a step costs ~7.8 us of which 1.1 us are
+// MFMAs - the rest is launch gap and L2 round trips, and every step re-reads the unit group's 64 KB of W_hh.  That chain
+// (2 T L steps) is what bounds pages of long lines (BASELINE config 5: 2 x 975 steps per launch = 15 ms against 5 ms of
+// convolutions) and what the convolutions of the next launch pay for on config 2.
+//
+// Here a CLUSTER of H/16 workgroups owns one (16-line slice, direction) pair for the whole layer.  Member `ug` keeps its
+// W_hh fragments (the four gates of 16 hidden units, all of K) in REGISTERS for all steps and the cell state c of its
+// (line, unit) pairs in registers too; per step it
+//   1. waits until the cluster's counter says every member has published step s-1,
+//   2. reads the slice's h_{s-1} (16 lines x H) with L1-bypassing loads,
+//   3. runs the same split-K MFMA GEMM + LDS reduction + gate arithmetic as lstm_step_kernel (bit-identical results),
+//   4. stores its 16 x 16 piece of h_s, waits for the stores to be acknowledged, bumps the counter (and stores the layer output y).
+// The hand-off is cheap only because all members of a cluster run on ONE XCD: plain stores are written through to that XCD's
+// L2, `s_waitcnt vmcnt(0)` waits for L2's acknowledgement, the counter is an atomic EXECUTED IN THAT L2 (workgroup scope),
+// polls and h reads bypass the L1 (sc1 / nt: L2-served).  Measured (tools/xcd_cluster_probe.hip, every word of every hand-off
+// checked, idle and under a memory-bound background kernel): 1.1 us per step for up to 256 workgroups, 1.9 us for 512, zero
+// stale words - against 3.4-24 us for the agent-scope release / acquire protocol that cross-XCD hand-offs need (round 2's
+// persistent variants paid that and lost).  Measured and dropped: the data as its own flag (8-byte {value, step tag} pairs,
+// no counter / acknowledgement wait / barrier) - every waiting wave then re-reads its 8 KB of state until the tags match, and
+// that polling traffic costs more than the three waits it removes (11.7 k against 8.5 k cycles per step).
+//
+// HIP promises nothing about workgroup -> XCD placement; observed: block b runs on XCD b % 8.  The grid is laid out for that
+// (cluster c = blocks {(c / 8 * UG + m) * 8 + c % 8}), but correctness does not depend on it: at start every member publishes the
+// XCC_ID it really runs on (agent scope, once per launch); a cluster whose members do NOT share an XCD runs the same loop with
+// the agent-scope protocol (release fence + agent atomic / acquire fence).  Every spin is bounded; a timeout sets an error word
+// the host checks at collect time.  Deadlock freedom: a cluster only waits for its own members, workgroups are dispatched in
+// block order, and a cluster's blocks are (UG * 8)-aligned runs of the grid - a resident cluster is complete or is the
+// launch's last, partly dispatched group, which only waits for earlier (complete) clusters to retire.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "conv_igemm.hpp"
+#include "lstm.hpp"
+
+#ifndef POCR_LSTM_RES_DBG
+#define POCR_LSTM_RES_DBG 0          // 1: workgroup 0 accumulates cycles per phase into err[8..] (timing experiments only)
+#endif
+namespace pocr {
+
+struct LstmResidentArgs {
+    const float *xproj;      // [rows][8H]  (dir, gate, unit), as LstmStepArgs
+    const float *whh_frag;   // [2][H/16][H/16][4][64][4], as LstmStepArgs
+    float *hbuf;             // [clusters][2][16][H]: the slice's hidden state, ping-pong
+    float *y;                // [rows][2H]
+    unsigned *sync;          // [clusters][32], ZEROED before the launch: word 0 step counter; slice 0 of a group also: word 1 arrivals of the placement check, words 8..8+UG-1 the members' XCC ids + 1
+    unsigned *err;           // [2]: [0] a spin timed out, [1] clusters that had to take the agent-scope protocol (diagnostic)
+    const int32_t *line_T, *row_off, *slice_T;   // ragged batches, as LstmStepArgs (NULL: uniform T)
+    int32_t n, npad, T;
+    int32_t spin_limit;      // polls before a wait gives up
+};
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kXccIdGetreg = (3 << 11) | (0 << 6) | 20;      // s_getreg_b32 HW_REG_XCC_ID, bits [3:0]
+
+// H = 64 * KPW (64, 128, 256); UG = H / 16 members per cluster.
+// SL: slices per workgroup.  A workgroup serves SL consecutive 16-line slices of one direction round-robin (slice 0 step s,
+// slice 1 step s, ..., slice 0 step s + 1): the W_hh registers are shared, and while one slice's hand-off is in flight the
+// workgroup computes the next slice - the hand-off latency disappears from the chain, and the launch needs 1 / SL of the
+// workgroups (c2: 256 instead of 512, one per CU, which leaves the convolutions of the next launch two workgroups per CU).
+template <int KPW, int SL>
+__global__ __launch_bounds__(256) void lstm_resident_kernel(LstmResidentArgs a) {
+    constexpr int H = 64 * KPW, KGT = H / 16, UG = KGT;
+    __shared__ float part[4 * 4 * 64 * 4];      // [wave][gate][lane][reg]
+    __shared__ int s_fast, s_abort;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.x, xcd = b & 7, k = b >> 3;
+    const int group = (k / UG) * 8 + xcd, ug = k % UG;          // group = (SL slices, direction); its members share an XCD
+    const int n_slices = a.npad / 16, n_sg = (n_slices + SL - 1) / SL;
+    if (group >= 2 * n_sg) return;
+    const int sg = group >> 1, dir = group & 1;
+    // sync words of slice j of this group: cluster id = (sg * SL + j) * 2 + dir; the group's placement words live in slice 0's block
+    unsigned *gsync = a.sync + (size_t)((sg * SL) * 2 + dir) * 32;
+    int Tmax = 0;
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+        const int slice = sg * SL + j;
+        if (slice < n_slices) Tmax = max(Tmax, a.slice_T ? a.slice_T[slice] : a.T);
+    }
+    if (Tmax <= 0) return;                                       // (uniform over the group)
+
+    // ---- placement check (once): do all members of this group share an XCD?
+    if (tid == 0) {
+        const unsigned my = (unsigned)__builtin_amdgcn_s_getreg(kXccIdGetreg) + 1u;
+        __hip_atomic_store(gsync + 8 + ug, my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(gsync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0, ok = 1;
+        while (__hip_atomic_load(gsync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)UG) {
+            if (++spins > a.spin_limit) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        int fast = 1;
+        for (int m = 0; m < UG; ++m) fast &= __hip_atomic_load(gsync + 8 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my;
+        if (!ok) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (ok && !fast && ug == 0) __hip_atomic_fetch_add(a.err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_fast = fast; s_abort = !ok;
+    }
+    __syncthreads();
+    if (s_abort) return;
+    const bool fast = s_fast != 0;
+
+    // ---- per-thread roles: MFMA operand lane (li = line, kq) and epilogue thread (line i, unit u)
+    const int u = tid & 15, i = tid >> 4;
+    const int unit = ug * 16 + u;
+    int Ti[SL], Ts[SL];
+    size_t row0[SL];
+    float cprev[SL], xg[SL][4];
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+        const int slice = sg * SL + j, line = slice * 16 + i;
+        const bool have = slice < n_slices;
+        Ts[j] = have ? (a.slice_T ? a.slice_T[slice] : a.T) : 0;
+        Ti[j] = have && line < a.n ? (a.line_T ? a.line_T[line] : a.T) : 0;
+        row0[j] = a.row_off ? (size_t)a.row_off[min(line, a.n - 1)] : (size_t)line * a.T;
+        cprev[j] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xg[j][g] = 0.f;
+    }
+    // gate pre-activations of (slice j, step s): requested a full round ahead, so they are in registers when the gates need them
+    auto load_x = [&](int j, int s) {
+        if (s < Ti[j]) {
+            const int t = dir == 0 ? s : Ti[j] - 1 - s;
+            const float *xp = a.xproj + (row0[j] + (size_t)t) * (8 * H) + (size_t)dir * 4 * H + unit;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xg[j][g] = xp[(size_t)g * H];
+        }
+    };
+    // W_hh fragments of this unit group, resident for the whole layer (the step kernel re-reads them every step)
+    f32x4 bv[KPW][4];
+    {
+        const f32x4 *wf = reinterpret_cast<const f32x4 *>(a.whh_frag) + ((size_t)(dir * KGT + ug) * KGT) * 4 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < KPW; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[q][g] = wf[((size_t)(wave + 4 * q) * 4 + g) * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < SL; ++j) load_x(j, 0);
+    const int src = (((i >> 2) * 16 + u) * 4) + (i & 3);      // D layout of the reduced gates (as lstm_step_kernel)
+
+#if POCR_LSTM_RES_DBG
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;
+#define POCR_TICK(k) do { if (b == 0 && tid == 0) { const unsigned long long t1 = __builtin_readcyclecounter(); tph[k] += t1 - t0; t0 = t1; } } while (0)
+#else
+#define POCR_TICK(k) do { } while (0)
+#endif
+    for (int s = 0; s < Tmax; ++s) {
+#pragma unroll
+        for (int j = 0; j < SL; ++j) {
+            if (s >= Ts[j]) continue;                          // (uniform over the group: slice_T)
+#if POCR_LSTM_RES_DBG
+            if (b == 0 && tid == 0) t0 = __builtin_readcyclecounter();
+#endif
+            const int cl = (sg * SL + j) * 2 + dir;
+            unsigned *sync = a.sync + (size_t)cl * 32;
+            float *hc = a.hbuf + (size_t)cl * 2 * 16 * H;     // [2][16][H]
+            const bool live = s < Ti[j];
+            const int t = dir == 0 ? s : Ti[j] - 1 - s;
+            const size_t row = row0[j] + (size_t)(live ? t : 0);
+            // ---- wait for h_{s-1} of the whole slice
+            if (s > 0) {
+                if (tid == 0) {
+                    const unsigned want = (unsigned)UG * (unsigned)s;
+                    int spins = 0;
+                    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {   // sc1 load: served by L2
+                        if (++spins > a.spin_limit) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; break; }
+                        if (spins > 64) __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (!fast) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                if (s_abort) return;
+            }
+            POCR_TICK(0);                                      // wait for the hand-off
+            f32x4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float xcur[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xcur[g] = xg[j][g];
+            if (s > 0) {
+                const float *hrow = hc + (size_t)(s & 1) * 16 * H + (size_t)li * H;
+                f32x4 av[KPW];
+#pragma unroll
+                for (int q = 0; q < KPW; ++q)                 // nt loads bypass the L1 (a plain load could return what this CU read two steps ago)
+                    av[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(hrow + (wave + 4 * q) * 16 + kq * 4));
+                load_x(j, s + 1);                             // behind the h loads in the (in-order) return queue
+#pragma unroll
+                for (int q = 0; q < KPW; ++q)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][jj], bv[q][g][jj], acc[g], 0, 0, 0);
+            } else {
+                load_x(j, s + 1);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4 *>(&part[((wave * 4 + g) * 64 + lane) * 4]) = acc[g];
+            POCR_TICK(1);                                      // h loads + MFMAs
+            __syncthreads();
+            POCR_TICK(2);                                      // barrier
+            float gate[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float sum = part[(0 * 4 + g) * 256 + src];
+                sum += part[(1 * 4 + g) * 256 + src];
+                sum += part[(2 * 4 + g) * 256 + src];
+                sum += part[(3 * 4 + g) * 256 + src];
+                gate[g] = sum;
+            }
+            float hn = 0.f;                                    // finished / padding lines publish zeros (never used)
+            if (live) {
+                float cn;
+                lstm_cell(gate, xcur, cprev[j], cn, hn);
+                cprev[j] = cn;
+            }
+            POCR_TICK(3);                                      // gates
+            if (s + 1 < Ts[j]) {
+                hc[(size_t)((s + 1) & 1) * 16 * H + (size_t)i * H + unit] = hn;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's state store is acknowledged by L2
+                POCR_TICK(4);                                  // store acknowledged (and the prefetched x landed)
+                __syncthreads();                                    // ... and everybody's; `part` may be overwritten again
+                POCR_TICK(5);
+                if (tid == 0) {
+                    if (fast) {
+                        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // executed in this XCD's L2
+                    } else {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            } else {
+                __syncthreads();
+            }
+            if (live) a.y[row * (2 * H) + (size_t)dir * H + unit] = hn;      // (after the hand-off: nobody waits for this store)
+        }
+    }
+#if POCR_LSTM_RES_DBG
+    if (b == 0 && tid == 0)
+        for (int q = 0; q < 6; ++q) reinterpret_cast<unsigned long long *>(a.err + 8)[q] = tph[q];
+#endif
+}
+
+}  // namespace pocr

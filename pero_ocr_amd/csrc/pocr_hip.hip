@@ -25,6 +25,7 @@
 #include "decoder.hpp"
 #include "crop.hpp"
 #include "lstm.hpp"
+#include "lstm_resident.hpp"
 #include "sparsify.hpp"
 #include "comm.hpp"
 #include "parsenet.hpp"
@@ -363,6 +364,10 @@ struct Slot {
     std::map<std::tuple<int, int, int>, hipGraphExec_t> lstm_graphs;
     DevBuf lstm_dims;                // device {n, npad} read by the replayed step kernels
     int32_t *lstm_dims_host = nullptr;   // pinned source of that copy
+    DevBuf lstm_sync;                    // resident recurrence (lstm_resident.hpp): [clusters][32] sync words, then 4 error / diagnostic words
+    size_t lstm_err_off = 0;             // index (uint32) of the error words inside lstm_sync
+    bool lstm_resident_used = false;     // this launch ran the resident kernel: collect checks the error word
+    uint32_t *lstm_err_host = nullptr;   // pinned copy of the error words
     DevBuf nf_flag;                      // set by frame_argmax_kernel when a winning logit is NaN / inf
     int32_t *nf_host = nullptr;          // pinned copy, read at collect time
     size_t h_stride = 0;             // floats between the two h ping-pong buffers (capacity-based, stable)
@@ -418,7 +423,8 @@ struct pocr_engine {
     std::vector<DecLayer> dec;
     DevBuf dec_embed, dec_out_w, dec_out_b;
     int dec_out_cout16 = 0;
-    bool warned_nonfinite = false;
+    bool lstm_resident = true;       // one launch per BiLSTM layer with the hidden state handed over inside an XCD (lstm_resident.hpp); POCR_LSTM_RESIDENT=0: one launch per step
+    bool warned_nonfinite = false, warned_placement = false;
     bool p2 = false;                 // f16x2 with pre-split activations between conv1 and the aggregation conv (conv_bf16x3.hpp "P2"; POCR_NO_P2=1: split in every consumer)
     bool bf16x3 = true;              // conv2..conv9 on the bf16 matrix pipe with the exact 3-way operand split (POCR_CONV_FP32=1: fp32 MFMA)
     DevBuf cconst[9];                // per conv layer: the output column [H_out][cout] far inside zero padding
@@ -739,12 +745,74 @@ int run_network(pocr_engine *e, Slot &s) {
     while (bucket * 16 < npad) bucket *= 2;
     s.lstm_dims_host[0] = n; s.lstm_dims_host[1] = npad;
     HIP_TRY(hipMemcpyAsync(s.lstm_dims.p, s.lstm_dims_host, 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    // resident recurrence: hidden sizes whose W_hh fragments fit a workgroup's registers, launches whose clusters the chip can
+    // hold (1024 workgroups = 512 lines at H = 256); otherwise one launch per step as before
+    const int n_clusters = 2 * (npad / 16);
+    const bool resident = e->lstm_resident && (Hh == 64 || Hh == 128 || Hh == 256) && c.lstm_layers <= 8 &&
+                          (size_t)n_clusters * (Hh / 16) <= 1024;
+    const size_t sync_words = (size_t)n_clusters * 32 + 32;     // + error / diagnostic words
+    s.lstm_resident_used = resident;
+    if (resident) {
+        if (s.lstm_sync.reserve(((sync_words + 3) / 4 * 4) * sizeof(uint32_t))) return 1;
+        s.lstm_err_off = (size_t)n_clusters * 32;
+        if (!s.lstm_err_host) {
+            HIP_TRY(locked_host_malloc(reinterpret_cast<void **>(&s.lstm_err_host), 8 * 4 * sizeof(uint32_t), hipHostMallocDefault));
+        }
+        memset(s.lstm_err_host, 0, 8 * 4 * sizeof(uint32_t));
+    }
     for (int l = 0; l < c.lstm_layers; ++l) {
         ConvArgs a{};
         a.x = layer_in; a.n = 1; a.H = 1; a.W = rows; a.Ho = 1; a.Wo = rows; a.cin = din;
         a.cout16 = e->proj_cout16; a.cout_valid = 8 * Hh; a.out_stride = 8 * Hh;
         a.wfrag = e->proj_w[l].as<float>(); a.bias = e->proj_b[l].as<float>(); a.y = s.xproj.as<float>();
         if (e->b3_weights.count(e->proj_w[l].p) ? gemm128_b3(a, st) : gemm128_k(a, st)) return 1;
+        if (resident) {
+            // the serial part in ONE launch: clusters of H / 16 workgroups, one per (16-line slice, direction), hand the hidden
+            // state from step to step through their XCD's L2 (lstm_resident.hpp)
+            const size_t n4 = (sync_words + 3) / 4;
+            hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)std::min<size_t>(256, (n4 + 255) / 256)), dim3(256), 0, st, s.lstm_sync.as<f32x4>(), n4);
+            LstmResidentArgs ra{};
+            ra.xproj = s.xproj.as<float>(); ra.whh_frag = e->whh[l].as<float>(); ra.hbuf = s.hbuf.as<float>(); ra.y = s.lstm_y[l].as<float>();
+            ra.sync = s.lstm_sync.as<unsigned>(); ra.err = s.lstm_sync.as<unsigned>() + s.lstm_err_off;
+            ra.line_T = s.g_line_T; ra.row_off = s.g_row_off; ra.slice_T = s.g_slice_T;
+            ra.n = n; ra.npad = npad; ra.T = T; ra.spin_limit = 1 << 22;
+            // slices per workgroup: 1 for launches of a few slices (pages of long lines: the chain's latency is what counts),
+            // 2 / 4 for many slices (the chain hides behind the next launch's convolutions: fewer resident workgroups cost
+            // those less).  Measured (profiles/r03_lstm_resident.txt): c5 SL 1, c3 SL 2, c2 SL 4.
+            static const int sl_env = getenv("POCR_LSTM_SL") ? atoi(getenv("POCR_LSTM_SL")) : 0;
+            const int n_sl = npad / 16, ug_n = Hh / 16;
+            int SLn = sl_env ? sl_env : (n_sl <= 4 ? 1 : (n_sl >= 16 && T <= 160) ? 4 : 2);
+            if (SLn != 1 && SLn != 2 && SLn != 4) SLn = 2;
+            const int groups = 2 * ((n_sl + SLn - 1) / SLn);
+            const unsigned grid = (unsigned)((groups + 7) / 8 * ug_n * 8);
+#define POCR_RES(KPW_)                                                                                                             \
+            do {                                                                                                                   \
+                if (SLn == 1) hipLaunchKernelGGL((lstm_resident_kernel<KPW_, 1>), dim3(grid), dim3(256), 0, st, ra);                 \
+                else if (SLn == 2) hipLaunchKernelGGL((lstm_resident_kernel<KPW_, 2>), dim3(grid), dim3(256), 0, st, ra);            \
+                else hipLaunchKernelGGL((lstm_resident_kernel<KPW_, 4>), dim3(grid), dim3(256), 0, st, ra);                          \
+            } while (0)
+            switch (Hh) {
+                case 64: POCR_RES(1); break;
+                case 128: POCR_RES(2); break;
+                default: POCR_RES(4); break;
+            }
+#undef POCR_RES
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(s.lstm_err_host + 4 * l, s.lstm_sync.as<unsigned>() + s.lstm_err_off, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+#if POCR_LSTM_RES_DBG
+            {
+                unsigned long long ph[6];
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(locked_memcpy(ph, s.lstm_sync.as<unsigned>() + s.lstm_err_off + 8, sizeof(ph), hipMemcpyDeviceToHost));
+                const double items = (double)T * SLn;
+                fprintf(stderr, "[lstm resident dbg] layer %d SL %d T %d: cycles per slice-step: wait %.0f  loads+mfma %.0f  barrier %.0f  gates %.0f  store-ack %.0f  barrier2 %.0f\n",
+                        l, SLn, T, ph[0] / items, ph[1] / items, ph[2] / items, ph[3] / items, ph[4] / items, ph[5] / items);
+            }
+#endif
+            layer_in = s.lstm_y[l].as<float>();
+            din = 2 * Hh;
+            continue;
+        }
         // the serial part: 2 memsets + T dependent step launches, replayed from a captured graph
         const auto key = std::make_tuple(l, T, bucket);
         auto it = s.lstm_graphs.find(key);
@@ -891,6 +959,17 @@ int collect_outputs(pocr_engine *e, Slot &s, float *logits_ntc, int32_t *frame_a
     const int n = s.n, T = s.t_max, C = e->cfg.num_classes, rows = s.rows;
     HIP_TRY(hipStreamSynchronize(s.seq_stream));
     s.in_flight = false;
+    if (s.lstm_resident_used && s.lstm_err_host) {
+        for (int l = 0; l < e->cfg.lstm_layers && l < 8; ++l)
+            if (s.lstm_err_host[4 * l])
+                return fail("BiLSTM layer %d: a hand-off of the resident recurrence timed out (a cluster's workgroups did not all become resident) - "
+                            "set POCR_LSTM_RESIDENT=0 for one launch per step", l);
+        for (int l = 0; l < e->cfg.lstm_layers && l < 8; ++l)
+            if (s.lstm_err_host[4 * l + 1] && !e->warned_placement) {
+                e->warned_placement = true;
+                fprintf(stderr, "NOTE: %u cluster(s) of the resident recurrence were not placed on one XCD and used the (slower) agent-scope hand-off.\n", s.lstm_err_host[4 * l + 1]);
+            }
+    }
     if (s.nf_host && *s.nf_host && !e->warned_nonfinite) {
         e->warned_nonfinite = true;
         fprintf(stderr, "WARNING: non-finite logits (NaN / inf) in a launch of %d lines - decoded like torch.argmax would (NaN is maximal).%s\n", n,
@@ -1064,6 +1143,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     e->cfg = *cfg;
     if (const char *env = getenv("POCR_NO_GRAPHS")) e->use_graphs = atoi(env) == 0;
     e->bf16x3 = conv_split() != 0;
+    if (const char *env = getenv("POCR_LSTM_RESIDENT")) e->lstm_resident = atoi(env) != 0;
     e->p2 = conv_split() == 2 && !(getenv("POCR_NO_P2") && atoi(getenv("POCR_NO_P2")) != 0);
     e->device = device_id;
     auto bail = [&](int rc) { pocr_destroy(e); return rc; };
@@ -1306,6 +1386,8 @@ void pocr_destroy(pocr_engine *e) {
         if (s.lstm_dims_host) (void)locked_host_free(s.lstm_dims_host);
         s.nf_flag.release();
         if (s.nf_host) (void)locked_host_free(s.nf_host);
+        s.lstm_sync.release();
+        if (s.lstm_err_host) (void)locked_host_free(s.lstm_err_host);
         if (s.host_in) (void)locked_host_free(s.host_in);
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);

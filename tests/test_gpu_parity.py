@@ -1007,3 +1007,43 @@ def test_layer_rescaling_leaves_the_logits_alone():
         err = float(np.max(np.abs(logits - ref_logits)))
         print(f"[rescale {a} x 2^-{k}] max |dlogit| {err:.3e}")
         assert err < LOGIT_TOL, (a, err)
+
+
+def test_resident_recurrence_equals_the_step_kernels(monkeypatch):
+    """The one-launch-per-layer recurrence (csrc/lstm_resident.hpp: clusters of H / 16 workgroups on one XCD hand the hidden
+    state over through that XCD's L2) against one launch per step (csrc/lstm.hpp, POCR_LSTM_RESIDENT=0): the same split-K
+    MFMA chains and the same gate arithmetic, so layer outputs, logits and labels must be BIT-IDENTICAL - on launch shapes
+    that exercise a single slice, several, ragged line lengths inside a slice, line counts that are not multiples of 16,
+    a batch of one, long lines (hundreds of hand-offs), and the three hidden sizes."""
+    chars = synth.make_charset(30)
+    shapes = [  # (hidden, conv_out, widths)
+        (256, 512, [300, 17, 641, 640, 300, 1, 96, 33, 512, 300, 64, 257, 200, 199, 31, 480, 481, 100, 7, 333]),
+        (256, 512, [1500]),
+        (128, 128, [64, 700, 33, 20, 350] * 7),
+        (64, 64, [40] * 16 + [900] * 3),
+        (256, 512, [512] * 48),
+    ]
+    for hidden, conv_out, widths in shapes:
+        spec = netspec.NetSpec(num_classes=len(chars) + 1, conv_out=conv_out, lstm_hidden=hidden, lstm_layers=2)
+        weights = netspec.pack_weights(spec, netspec.generate_weights(spec, 91 + hidden))
+        crops = synth.make_crops(12, widths)
+        pool = np.concatenate([c.reshape(-1) for c in crops])
+        offs = np.concatenate([[0], np.cumsum([c.size for c in crops])[:-1]]).astype(np.int64)
+        w_pads = [-(-max(w, 1) // 32) * 32 + 64 for w in widths]
+
+        def run(resident):
+            monkeypatch.setenv("POCR_LSTM_RESIDENT", "1" if resident else "0")
+            eng = _native.NativeEngine(spec, weights, 0)
+            out = []
+            for rep in range(2):                  # twice: the second launch re-uses (re-zeroed) sync words and state buffers
+                eng.slot_stage_ragged(0, pool, offs, np.array(widths, np.int32), w_pads, 32)
+                eng.slot_launch(0, want_logits=True, want_argmax=True)
+                logits, amax, labels, lens = eng.slot_collect(0)
+                out.append([eng.debug_read(10), eng.debug_read(11), logits, amax, labels, lens])
+            eng.close()
+            return out
+
+        a, b = run(True), run(False)
+        for ra, rb in zip(a, b):
+            for k, (x, y) in enumerate(zip(ra, rb)):
+                assert x.shape == y.shape and np.array_equal(x, y), f"H {hidden}, {len(widths)} lines: output {k} differs"
