@@ -19,12 +19,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_igemm.hpp"
+#include "conv_bf16x3.hpp"
 
 namespace pocr {
 
 struct LstmStepArgs {
     const float *xproj;     // [n][T][8H]   (dir, gate, unit)
     const float *whh_frag;  // [2][H/16][H/16][4][64][4]
+    const void *whh2;       // f16x2 fragments (lstm_gemm_f16x2 below) or NULL: the recurrent GEMM on the fp32 MFMA
     const float *h_in;      // [2][npad][H]
     float *h_out;           // [2][npad][H]
     float *c;               // [2][npad][H]  (in place)
@@ -58,6 +60,62 @@ __device__ __forceinline__ void lstm_cell(const float (&gate)[4], const float (&
     hn = go * tanh_f32(cn);
 }
 #pragma clang fp contract(fast)
+
+// ---- the recurrent GEMM on the f16 matrix pipe (conv_bf16x3.hpp "f16x2": operands as two f16 planes, three MFMAs per
+// 32-deep block): 24 v_mfma_f32_16x16x32_f16 per wave and step at H = 256 instead of 64 v_mfma_f32_16x16x4_f32 (384 against
+// 2048 cycles of a step's ~7600).  W_hh is split on the host:
+//   whh2[dir][unit group][K block = k / 32][gate][plane][lane][8 x f16] = plane of W_hh[gate*H + 16*ug + (lane&15)][32*blk + 8*(lane>>4) + j];
+// h_{s-1} is split by the wave that reads it (8 values per lane and block).  K blocks are dealt to the four waves round-robin
+// (wave w: blocks w, w + 4, ...); both recurrence kernels call these two functions, so their results agree bit for bit.
+template <int KPW> struct LstmW2 { u32x4 b[(2 * KPW + 3) / 4][4][2]; };
+
+template <int KPW>
+__device__ __forceinline__ void lstm_load_w_f16x2(const void *whh2, int dir, int ug, int wave, int lane, LstmW2<KPW> &w) {
+    constexpr int NB = 2 * KPW, QB = (NB + 3) / 4, KGT = 4 * KPW;
+    const u32x4 *base = reinterpret_cast<const u32x4 *>(whh2) + ((size_t)(dir * KGT + ug) * NB) * 4 * 2 * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int blk = wave + 4 * q;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                w.b[q][g][p] = blk < NB ? base[((size_t)(blk * 4 + g) * 2 + p) * 64] : (u32x4){0u, 0u, 0u, 0u};
+    }
+}
+
+// hrow: the lane's line of h_{s-1} (H floats); NT: read with L1-bypassing loads (resident kernel).  acc = this wave's partial gates.
+template <int KPW, bool NT>
+__device__ __forceinline__ void lstm_gemm_f16x2(const float *hrow, int wave, int kq, const LstmW2<KPW> &w, f32x4 (&acc)[4]) {
+    constexpr int NB = 2 * KPW, QB = (NB + 3) / 4;
+    f32x4 x0[QB], x1[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int blk = min(wave + 4 * q, NB - 1);
+        const f32x4 *p = reinterpret_cast<const f32x4 *>(hrow + blk * 32 + kq * 8);
+        if constexpr (NT) { x0[q] = __builtin_nontemporal_load(p); x1[q] = __builtin_nontemporal_load(p + 1); }
+        else { x0[q] = p[0]; x1[q] = p[1]; }
+    }
+    f32x4 main_[4], cross[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { main_[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; cross[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        if (wave + 4 * q >= NB) continue;                 // (wave-uniform: H = 64 has two blocks for four waves)
+        u32x2 h01, l01, h23, l23;
+        split2_quad(x0[q], h01, l01);
+        split2_quad(x1[q], h23, l23);
+        const u32x4 ah = {h01[0], h01[1], h23[0], h23[1]}, al = {l01[0], l01[1], l23[0], l23[1]};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cross[g] = POCR_MFMA_F16(al, w.b[q][g][0], cross[g]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) main_[g] = POCR_MFMA_F16(ah, w.b[q][g][0], main_[g]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cross[g] = POCR_MFMA_F16(ah, w.b[q][g][1], cross[g]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = main_[g] + cross[g] * (1.0f / kF16x2Scale);
+}
 
 // KPW > 0: H == 64 * KPW, fully unrolled.  KPW == 0: generic H (multiple of 16).
 template <int KPW>
@@ -93,7 +151,13 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
     for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float *hrow = a.h_in + ((size_t)dir * a.npad + slice * 16 + li) * H;
     const f32x4 *wf = reinterpret_cast<const f32x4 *>(a.whh_frag) + ((size_t)(dir * KGT + ug) * KGT) * 4 * 64 + lane;
-    if constexpr (KPW > 0) {
+    if (KPW > 0 && a.whh2) {
+        if constexpr (KPW > 0) {
+            LstmW2<KPW> w2;
+            lstm_load_w_f16x2<KPW>(a.whh2, dir, ug, wave, lane, w2);
+            lstm_gemm_f16x2<KPW, false>(hrow, wave, kq, w2, acc);
+        }
+    } else if constexpr (KPW > 0) {
         f32x4 av[KPW], bv[KPW][4];
 #pragma unroll
         for (int q = 0; q < KPW; ++q) {

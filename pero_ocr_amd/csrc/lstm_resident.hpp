@@ -42,6 +42,7 @@ namespace pocr {
 struct LstmResidentArgs {
     const float *xproj;      // [rows][8H]  (dir, gate, unit), as LstmStepArgs
     const float *whh_frag;   // [2][H/16][H/16][4][64][4], as LstmStepArgs
+    const void *whh2;        // f16x2 fragments (lstm.hpp: lstm_gemm_f16x2) or NULL = fp32 MFMA
     float *hbuf;             // [clusters][2][16][H]: the slice's hidden state, ping-pong
     float *y;                // [rows][2H]
     unsigned *sync;          // [clusters][32], ZEROED before the launch: word 0 step counter; slice 0 of a group also: word 1 arrivals of the placement check, words 8..8+UG-1 the members' XCC ids + 1
@@ -131,8 +132,12 @@ __global__ __launch_bounds__(256) void lstm_resident_kernel(LstmResidentArgs a) 
         }
     };
     // W_hh fragments of this unit group, resident for the whole layer (the step kernel re-reads them every step)
+    const bool f16 = a.whh2 != nullptr;
+    LstmW2<KPW> w2;
     f32x4 bv[KPW][4];
-    {
+    if (f16) {
+        lstm_load_w_f16x2<KPW>(a.whh2, dir, ug, wave, lane, w2);
+    } else {
         const f32x4 *wf = reinterpret_cast<const f32x4 *>(a.whh_frag) + ((size_t)(dir * KGT + ug) * KGT) * 4 * 64 + lane;
 #pragma unroll
         for (int q = 0; q < KPW; ++q)
@@ -183,7 +188,10 @@ __global__ __launch_bounds__(256) void lstm_resident_kernel(LstmResidentArgs a) 
             float xcur[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) xcur[g] = xg[j][g];
-            if (s > 0) {
+            if (s > 0 && f16) {
+                lstm_gemm_f16x2<KPW, true>(hc + (size_t)(s & 1) * 16 * H + (size_t)li * H, wave, kq, w2, acc);
+                load_x(j, s + 1);
+            } else if (s > 0) {
                 const float *hrow = hc + (size_t)(s & 1) * 16 * H + (size_t)li * H;
                 f32x4 av[KPW];
 #pragma unroll

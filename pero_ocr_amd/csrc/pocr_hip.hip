@@ -409,6 +409,7 @@ struct pocr_engine {
     int embed_id = -1;
     std::unordered_set<const void *> b3_weights;   // weight buffers laid out for the bf16x3 kernels (wsplit): the GEMM-mode / aggregation launches ask
     std::vector<DevBuf> proj_w, proj_b, whh;       // per LSTM layer
+    std::vector<DevBuf> whh2;                      // per LSTM layer: W_hh as f16x2 fragments (lstm.hpp: lstm_gemm_f16x2); empty = fp32 MFMA recurrence
     // self-attention encoder (POCR_ARCH_SA): per layer in_proj, out_proj, lin1, lin2 (fragment order) + LN params
     struct SaLayer { DevBuf w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b; };
     std::vector<SaLayer> sa;
@@ -727,6 +728,7 @@ int run_network(pocr_engine *e, Slot &s) {
     auto launch_step = [&](int l, int step, int slices, const int32_t *dims) {
         LstmStepArgs la{};
         la.xproj = s.xproj.as<float>(); la.whh_frag = e->whh[l].as<float>();
+        la.whh2 = e->whh2.empty() ? nullptr : e->whh2[l].p;
         la.h_in = s.hbuf.as<float>() + (size_t)(step & 1) * s.h_stride;
         la.h_out = s.hbuf.as<float>() + (size_t)((step + 1) & 1) * s.h_stride;
         la.c = s.cbuf.as<float>(); la.y = s.lstm_y[l].as<float>(); la.dims = dims;
@@ -772,6 +774,7 @@ int run_network(pocr_engine *e, Slot &s) {
             const size_t n4 = (sync_words + 3) / 4;
             hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)std::min<size_t>(256, (n4 + 255) / 256)), dim3(256), 0, st, s.lstm_sync.as<f32x4>(), n4);
             LstmResidentArgs ra{};
+            ra.whh2 = e->whh2.empty() ? nullptr : e->whh2[l].p;
             ra.xproj = s.xproj.as<float>(); ra.whh_frag = e->whh[l].as<float>(); ra.hbuf = s.hbuf.as<float>(); ra.y = s.lstm_y[l].as<float>();
             ra.sync = s.lstm_sync.as<unsigned>(); ra.err = s.lstm_sync.as<unsigned>() + s.lstm_err_off;
             ra.line_T = s.g_line_T; ra.row_off = s.g_row_off; ra.slice_T = s.g_slice_T;
@@ -1283,6 +1286,10 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         e->proj_cout16 = round_up(8 * Hh, kProjNT) / 16;
         e->proj_w.resize(cfg->lstm_layers); e->proj_b.resize(cfg->lstm_layers);
         e->whh.resize(cfg->lstm_layers);
+        // the recurrent GEMM follows the conv arithmetic: f16x2 (hidden sizes the unrolled kernels cover), POCR_LSTM_FP32=1: fp32 MFMA
+        const bool lstm_f16 = conv_split() == 2 && (cfg->lstm_hidden == 64 || cfg->lstm_hidden == 128 || cfg->lstm_hidden == 256 || cfg->lstm_hidden == 512) &&
+                              !(getenv("POCR_LSTM_FP32") && atoi(getenv("POCR_LSTM_FP32")) != 0);
+        if (lstm_f16) e->whh2.resize(cfg->lstm_layers);
         for (int l = 0; l < cfg->lstm_layers; ++l) {
             const int din = l == 0 ? cfg->conv_out : 2 * Hh;
             const float *wih[2], *whh[2], *bih[2], *bhh[2];
@@ -1309,6 +1316,27 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
                                 for (int j = 0; j < 4; ++j)
                                     wf[o++] = whh[d][(size_t)(g * Hh + 16 * ug + (lane & 15)) * Hh + 16 * kg + 4 * (lane >> 4) + j];
             if ((proj_b3 ? upload_u16(e->proj_w[l], proj_split, st) : upload(e->proj_w[l], frag, st)) || upload(e->proj_b[l], bias, st) || upload(e->whh[l], wf, st)) return bail(1);
+            if (lstm_f16) {
+                // whh2[dir][ug][blk][gate][plane][lane][8 f16] = plane of W_hh[gate*H + 16 ug + (lane & 15)][32 blk + 8 (lane >> 4) + j]
+                const int NB = Hh / 32;
+                std::vector<uint16_t> w2((size_t)2 * KGT * NB * 4 * 2 * 64 * 8);
+                size_t o2 = 0;
+                for (int d = 0; d < 2; ++d)
+                    for (int ug = 0; ug < KGT; ++ug)
+                        for (int blk = 0; blk < NB; ++blk)
+                            for (int g = 0; g < 4; ++g) {
+                                uint16_t part[2][64][8];
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int j = 0; j < 8; ++j) {
+                                        uint16_t pl[3] = {0, 0, 0};
+                                        split_weight(whh[d][(size_t)(g * Hh + 16 * ug + (lane & 15)) * Hh + 32 * blk + 8 * (lane >> 4) + j], 2, pl);
+                                        part[0][lane][j] = pl[0]; part[1][lane][j] = pl[1];
+                                    }
+                                memcpy(&w2[o2], part, sizeof(part));
+                                o2 += 2 * 64 * 8;
+                            }
+                if (upload_u16(e->whh2[l], w2, st)) return bail(1);
+            }
             if (proj_b3) e->b3_weights.insert(e->proj_w[l].p);
         }
     }
@@ -1354,7 +1382,7 @@ void pocr_destroy(pocr_engine *e) {
     for (auto &b : e->conv_w) b.release();
     for (auto &b : e->cconst) b.release();
     for (auto &b : e->conv_b) b.release();
-    for (auto &v : {&e->proj_w, &e->proj_b, &e->whh})
+    for (auto &v : {&e->proj_w, &e->proj_b, &e->whh, &e->whh2})
         for (auto &b : *v) b.release();
     for (auto &L : e->sa)
         for (DevBuf *b : {&L.w_in, &L.b_in, &L.w_out, &L.b_out, &L.w1, &L.b1, &L.w2, &L.b2, &L.n1w, &L.n1b, &L.n2w, &L.n2b}) b->release();
