@@ -50,6 +50,8 @@ struct LstmResidentArgs {
     const int32_t *line_T, *row_off, *slice_T;   // ragged batches, as LstmStepArgs (NULL: uniform T)
     int32_t n, npad, T;
     int32_t spin_limit;      // polls before a wait gives up
+    int32_t force_agent;     // test hook (POCR_LSTM_FORCE_AGENT=1): take the cross-XCD protocol even when the cluster shares an XCD
+    unsigned *xcc_census;    // test hook: [grid] XCC_ID + 1 of every block, or NULL
 };
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -95,7 +97,8 @@ __global__ __launch_bounds__(256) void lstm_resident_kernel(LstmResidentArgs a) 
             __builtin_amdgcn_s_sleep(2);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        int fast = 1;
+        int fast = a.force_agent ? 0 : 1;
+        if (a.xcc_census) a.xcc_census[b] = my;
         for (int m = 0; m < UG; ++m) fast &= __hip_atomic_load(gsync + 8 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my;
         if (!ok) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         if (ok && !fast && ug == 0) __hip_atomic_fetch_add(a.err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -779,6 +779,8 @@ int run_network(pocr_engine *e, Slot &s) {
             ra.sync = s.lstm_sync.as<unsigned>(); ra.err = s.lstm_sync.as<unsigned>() + s.lstm_err_off;
             ra.line_T = s.g_line_T; ra.row_off = s.g_row_off; ra.slice_T = s.g_slice_T;
             ra.n = n; ra.npad = npad; ra.T = T; ra.spin_limit = 1 << 22;
+            static const int force_agent = getenv("POCR_LSTM_FORCE_AGENT") ? atoi(getenv("POCR_LSTM_FORCE_AGENT")) : 0;
+            ra.force_agent = force_agent;
             // slices per workgroup: 1 for launches of a few slices (pages of long lines: the chain's latency is what counts),
             // 2 / 4 for many slices (the chain hides behind the next launch's convolutions: fewer resident workgroups cost
             // those less).  Measured (profiles/r03_lstm_resident.txt): c5 SL 1, c3 SL 2, c2 SL 4.

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import gpu_available
+from conftest import REPO, gpu_available
 from oracle import engine_oracle, model_oracle
 from pero_ocr_amd import _native, netspec, synth
 
@@ -1031,8 +1031,9 @@ def test_resident_recurrence_equals_the_step_kernels(monkeypatch):
         offs = np.concatenate([[0], np.cumsum([c.size for c in crops])[:-1]]).astype(np.int64)
         w_pads = [-(-max(w, 1) // 32) * 32 + 64 for w in widths]
 
-        def run(resident):
+        def run(resident, force_agent=False):
             monkeypatch.setenv("POCR_LSTM_RESIDENT", "1" if resident else "0")
+            monkeypatch.setenv("POCR_LSTM_FORCE_AGENT", "1" if force_agent else "0")
             eng = _native.NativeEngine(spec, weights, 0)
             out = []
             for rep in range(2):                  # twice: the second launch re-uses (re-zeroed) sync words and state buffers
@@ -1047,3 +1048,40 @@ def test_resident_recurrence_equals_the_step_kernels(monkeypatch):
         for ra, rb in zip(a, b):
             for k, (x, y) in enumerate(zip(ra, rb)):
                 assert x.shape == y.shape and np.array_equal(x, y), f"H {hidden}, {len(widths)} lines: output {k} differs"
+    # the fall-back protocol of a cluster that is NOT on one XCD (agent-scope release / acquire), forced: same bits
+    # (the env switch is read once per process: this only takes effect in a fresh process, see the subprocess below)
+
+
+def test_resident_recurrence_cross_xcd_protocol(tmp_path):
+    """HIP promises no workgroup -> XCD placement: a cluster of the resident recurrence whose members do not share an XCD must
+    run the agent-scope hand-off instead of the L2-local one.  POCR_LSTM_FORCE_AGENT=1 forces that protocol for every
+    cluster (fresh process: the switch is read once); the transcriptions and logits must equal the default run's bit for bit."""
+    import subprocess
+    import sys
+    script = os.path.join(str(tmp_path), "run.py")
+    with open(script, "w") as f:
+        f.write(
+            "import sys, numpy as np\n"
+            f"sys.path.insert(0, {REPO!r})\n"
+            "from pero_ocr_amd import _native, netspec, synth\n"
+            "chars = synth.make_charset(30)\n"
+            "spec = netspec.NetSpec(num_classes=len(chars) + 1)\n"
+            "w = netspec.pack_weights(spec, netspec.generate_weights(spec, 93))\n"
+            "widths = [300, 17, 641, 640, 300, 1, 96, 33, 512, 300, 64, 257, 200, 199, 31, 480, 481, 100, 7, 333]\n"
+            "crops = synth.make_crops(13, widths)\n"
+            "pool = np.concatenate([c.reshape(-1) for c in crops])\n"
+            "offs = np.concatenate([[0], np.cumsum([c.size for c in crops])[:-1]]).astype(np.int64)\n"
+            "eng = _native.NativeEngine(spec, w, 0)\n"
+            "eng.slot_stage_ragged(0, pool, offs, np.array(widths, np.int32), [-(-max(x, 1) // 32) * 32 + 64 for x in widths], 32)\n"
+            "eng.slot_launch(0, want_logits=True, want_argmax=True)\n"
+            "logits, amax, labels, lens = eng.slot_collect(0)\n"
+            "np.savez(sys.argv[1], logits=logits, amax=amax, labels=labels, lens=lens)\n")
+    outs = []
+    for force in ("0", "1"):
+        path = os.path.join(str(tmp_path), f"out{force}.npz")
+        env = dict(os.environ, POCR_LSTM_FORCE_AGENT=force, POCR_LSTM_RESIDENT="1")
+        r = subprocess.run([sys.executable, script, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    for k in ("logits", "amax", "labels", "lens"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k

@@ -220,3 +220,23 @@ def test_resize_area_sparse_equals_dense_definition():
     out = resize_area(page, 3.3)
     assert out.shape == (455, 606, 3)
     assert time.perf_counter() - t0 < 3.0          # (was 4.9 s with dense [n_out, n_in] matrices; ~0.2 s now)
+
+
+def test_lazy_crop_quacks_like_the_numpy_crop():
+    """`line.crop` of the resident cropper is a LazyCrop: shape / ndim / dtype / size like the numpy array the reference
+    stores there, and a numpy copy the moment somebody reads pixels (np.asarray, indexing, copy) - fetched ONCE."""
+    reads = []
+
+    class FakeOwner:                      # stands in for _native.ResidentCrops (no GPU here)
+        device_id = 0
+
+        def read(self, offset, nbytes):
+            reads.append((offset, nbytes))
+            return (np.arange(nbytes, dtype=np.int64) + offset).astype(np.uint8)
+    c = _native.LazyCrop(FakeOwner(), 1000, (40, 7, 3))
+    assert c.shape == (40, 7, 3) and c.ndim == 3 and c.dtype == np.uint8 and c.size == 840 and len(c) == 40 and c._host is None
+    a = np.asarray(c)
+    assert a.shape == (40, 7, 3) and a.dtype == np.uint8 and a[0, 0, 0] == 1000 % 256 and reads == [(1000, 840)]
+    assert np.array_equal(c[3], a[3]) and np.array_equal(c.copy(), a) and c.astype(np.float32).dtype == np.float32
+    assert reads == [(1000, 840)] and c._host is not None            # one fetch, then the host copy is kept
+    assert np.array_equal(np.ascontiguousarray(c, dtype=np.uint8).reshape(-1), a.reshape(-1))     # what _pack_lines does
