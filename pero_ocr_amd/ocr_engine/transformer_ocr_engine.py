@@ -195,8 +195,9 @@ class TransformerEngineLineOCR(BaseEngineLineOCR):
             rows = [len("".join(self.characters[int(c)] for c in lab)) for lab in all_labels]
             data, indices, indptr, line_off = self.net.s2s_sparse(slot, rows, SPARSE_PROB_THRESHOLD)
             C_ = indptr.shape[1] - 1
-            mats = [sparse.csc_matrix((data[int(line_off[i]):int(line_off[i + 1])], indices[int(line_off[i]):int(line_off[i + 1])],
-                                       indptr[i]), shape=(rows[i], C_)) for i in range(len(rows))]
+            from .pytorch_ocr_engine import _csc_from_device
+            mats = [_csc_from_device(data[int(line_off[i]):int(line_off[i + 1])], indices[int(line_off[i]):int(line_off[i + 1])],
+                                     indptr[i], (rows[i], C_)) for i in range(len(rows))]
             out = [(labels, mats[int(batch_first[b]):int(batch_first[b + 1])]) for b, (labels, _l) in enumerate(out)]
         return out
 
