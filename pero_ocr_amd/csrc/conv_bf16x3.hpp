@@ -24,6 +24,9 @@
 #ifndef POCR_BF16X3_SCHED
 #define POCR_BF16X3_SCHED 1            // issue-order templates (sched_group_barrier) in the main loops: -2 ... -9 % per layer, same arithmetic
 #endif
+#ifndef POCR_BDIR_SETS
+#define POCR_BDIR_SETS 3               // register sets of weight fragments in the direct-weights loop: the set of step s + SETS - 1 is requested while step s computes
+#endif
 #ifndef POCR_STA_TAP
 #define POCR_STA_TAP (NTAP / 2)        // tap after which the next chunk's halo tile (requested at tap 0) is written to the other LDS buffer
 #endif
@@ -312,22 +315,23 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     // three register sets of weight fragments, rotated with the step (statically: 9 taps = 3 x 3; other tap counts unroll
     // three chunks): the set of step s + 2 is requested while step s computes - two steps (~2000 cycles) cover an L2
     // miss, one does not
-    u32x4 bw[3][NS][SPL];
+    constexpr int NSETS = POCR_BDIR_SETS, AHEAD = NSETS - 1;
+    u32x4 bw[NSETS][NS][SPL];
     auto ldW = [&](u32x4 (&dst)[NS][SPL], const u32x4 *tile) {
 #pragma unroll
         for (int n = 0; n < NS; ++n)
 #pragma unroll
             for (int p = 0; p < SPL; ++p) dst[n][p] = tile[n * WU + p * 64];
     };
-    // step s = chunk * NTAP + tap uses set s % 3; the chunk loop is unrolled U-fold so that s % 3 is static
-    constexpr int U = NTAP % 3 == 0 ? 1 : 3;
+    // step s = chunk * NTAP + tap uses set s % NSETS; the chunk loop is unrolled U-fold so that s % NSETS is static
+    constexpr int U = NTAP % NSETS == 0 ? 1 : (2 * NTAP) % NSETS == 0 ? 2 : (3 * NTAP) % NSETS == 0 ? 3 : NSETS;
     auto wstep = [&](int s_) {                           // weights of global step s_ (clamped to the last step: re-read, never used)
         const int sc = min(s_, nchunks * NTAP - 1);
         return wq + (size_t)(sc % NTAP) * tap_stride + (size_t)(sc / NTAP) * chunk_stride;
     };
     ldA(0);
-    ldW(bw[0], wstep(0));
-    ldW(bw[1], wstep(1));
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) ldW(bw[q], wstep(q));
     stA(0);
     __syncthreads();
     for (int c0 = 0; c0 < nchunks; c0 += U) {
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             for (int tap = 0; tap < NTAP; ++tap) {
                 const int sl = u * NTAP + tap;            // step within the unrolled body: static
 #if !(POCR_BF16X3_DBG & 2)
-                ldW(bw[(sl + 2) % 3], wstep(chunk * NTAP + tap + 2));
+                ldW(bw[(sl + AHEAD) % NSETS], wstep(chunk * NTAP + tap + AHEAD));
 #endif
                 const int dy = tap / KW, dx = tap % KW;
 #if POCR_BF16X3_DBG & 1
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #else
                 const u32x4 *Ab = ldsA + abuf * A_U + dy * HW + dx + li + kq * NPPAD + wm * MWW * 16;
 #endif
-                u32x4 (&bc)[NS][SPL] = bw[sl % 3];
+                u32x4 (&bc)[NS][SPL] = bw[sl % NSETS];
 #pragma unroll
                 for (int m = 0; m < MS; ++m) {
                     const int o = (m / MWW) * HW + (m % MWW) * 16;
