@@ -217,7 +217,7 @@ def run_extra_workloads(timeout_s=170.0):
     the ONE JSON line the default run prints."""
     jobs = {"c3": ["--workload", "c3", "--steps", "2", "--warmup", "1"],
             "c4": ["--workload", "c4", "--steps", "5", "--warmup", "2"],
-            "c5": ["--workload", "c5", "--steps", "8", "--warmup", "2"]}
+            "c5": ["--workload", "c5", "--steps", "16", "--warmup", "4"]}
     only = os.environ.get("POCR_BENCH_EXTRAS")          # e.g. "c3,c5" or "" (none): which child workloads to run
     if only is not None:
         jobs = {k: v for k, v in jobs.items() if k in only.split(",")}
