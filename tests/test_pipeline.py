@@ -117,3 +117,38 @@ def test_page_stream_with_layout_network_front(tmp_path, golden):
     for img, lay in out:
         for ln in lay.lines:
             assert np.array_equal(ln.crop, crop_oracle.crop(img, ln.baseline, ln.heights, g.height, 1.0, 0))
+
+
+def test_page_stream_reproduces_the_reference_fixture(tmp_path, golden):
+    """the page stream compared with the REFERENCE, not with the engine itself.  The 'pages' are groups of
+    the ragged fixture's own crops (a cropper stand-in hands them out - resident in HBM for half of the pages, numpy for the
+    others), so whatever PageStream batches together, every line must get the transcription the reference engine produced
+    for it when the same lines went through its process_lines in one call - provided the stream hands the recogniser the same
+    list of lines in one call too (pages_per_batch = all pages): chunking is a function of the whole list."""
+    from pero_ocr_amd import _native
+    from pero_ocr_amd.document_ocr.page_ocr import PageOCR
+    from pero_ocr_amd.document_ocr.page_stream import PageStream
+    g = golden("ragged")
+    crops = g.crops()
+    ocr = PageOCR({"OCR_JSON": g.write_engine_json(tmp_path)}, Dev())
+    groups = [list(range(0, 5)), list(range(5, 6)), list(range(6, 12)), list(range(12, len(crops)))]
+    pages = [np.zeros((8, 8, 3), np.uint8) + k for k in range(len(groups))]
+    index = {id(p): k for k, p in enumerate(pages)}
+
+    class FakeCropper:
+        def process_page(self, img, layout):
+            for ln, i in zip(layout.lines, groups[index[id(img)]]):
+                ln.crop = crops[i]
+            return layout
+
+    def front(img):
+        return Layout([Line(i, [[0, 0], [1, 0]], [1, 1]) for i in groups[index[id(img)]]])
+
+    stream = PageStream(front, FakeCropper(), ocr, pages_per_batch=len(pages))
+    seen = []
+    for img, layout in stream.process(iter(pages)):
+        for ln, i in zip(layout.lines, groups[index[id(img)]]):
+            assert ln.transcription == g.transcriptions[i], f"line {i}: {ln.transcription!r} != reference {g.transcriptions[i]!r}"
+            assert ln.logit_coords == g.logit_coords[i]
+            seen.append(i)
+    assert sorted(seen) == list(range(len(crops)))
