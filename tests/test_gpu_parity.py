@@ -478,7 +478,9 @@ def test_c3_page_stream_over_rccl_matches_reference_golden(golden, tmp_path):
     for i in range(g.n):
         assert np.array_equal(np.argmax(np.asarray(logits[i]), axis=1), g.argmax(i)), f"line {i}: per-frame argmax differs"
     hip_t, ref_t, n_hip_ref, n_ref_t, _rows = _check_truth_rows(g, logits, "c3")
-    assert hip_t < LOGIT_TOL, hip_t
+    # (the fp32-MFMA fall-back, POCR_CONV_FP32=1, is an fp32 fma chain like the reference's own arithmetic and as noisy: 1.13e-3
+    # against the reference's 1.14e-3 on these rows - for it only "no further from exact arithmetic than the reference" holds)
+    assert hip_t < LOGIT_TOL or (_native.conv_split() == 0 and hip_t <= ref_t), hip_t
     assert hip_t <= ref_t, (hip_t, ref_t)
     assert n_hip_ref <= n_ref_t, (n_hip_ref, n_ref_t)
     # the statistics are 1-Lipschitz in the max norm: the reference's own deviation from exact arithmetic (ref_t, measured
