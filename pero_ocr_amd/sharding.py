@@ -228,8 +228,9 @@ class ShardedLineOCR:
         got = allgather_rows(tr, rows, max(m_of, default=0), m_of)
         _raise_together(got, failure, tr, m_of)
         texts: List[Optional[str]] = [None] * len(lines)
-        for row in got:
-            texts[int(row[0])] = "".join(self.characters[c] for c in row[2:2 + row[1]])
+        from .ocr_engine.pytorch_ocr_engine import labels_to_strings
+        for i, t in zip(got[:, 0].tolist(), labels_to_strings(got[:, 2:], got[:, 1], self.characters)):
+            texts[i] = t
         return texts
 
 

@@ -240,3 +240,21 @@ def test_lazy_crop_quacks_like_the_numpy_crop():
     assert np.array_equal(c[3], a[3]) and np.array_equal(c.copy(), a) and c.astype(np.float32).dtype == np.float32
     assert reads == [(1000, 840)] and c._host is not None            # one fetch, then the host copy is kept
     assert np.array_equal(np.ascontiguousarray(c, dtype=np.uint8).reshape(-1), a.reshape(-1))     # what _pack_lines does
+
+
+def test_labels_to_strings_vectorised_equals_per_symbol_join():
+    """The one-pass decoder must give exactly what the reference's per-symbol join gives (pytorch_ocr_engine.py:29-32),
+    for empty lines, the blank symbol, non-BMP code points and character sets holding multi-code-point entries."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import labels_to_strings
+    rng = np.random.default_rng(5)
+    chars = [chr(0x21 + i) for i in range(90)] + ["\U0001F600", "ř", "​"]
+    lab = rng.integers(0, len(chars), (64, 37)).astype(np.int32)
+    lens = rng.integers(0, 38, 64).astype(np.int32)
+    lens[:3] = (0, 37, 1)
+    want = ["".join(chars[c] for c in lab[i, :lens[i]]) for i in range(64)]
+    assert labels_to_strings(lab, lens, chars) == want
+    assert labels_to_strings(lab, lens, chars) == want          # cached table
+    multi = list(chars)
+    multi[4] = "ch"
+    assert labels_to_strings(lab, lens, multi) == ["".join(multi[c] for c in lab[i, :lens[i]]) for i in range(64)]
+    assert labels_to_strings(np.zeros((0, 4), np.int32), np.zeros(0, np.int32), chars) == []
