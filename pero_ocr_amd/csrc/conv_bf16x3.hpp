@@ -30,6 +30,12 @@
 #ifndef POCR_STA_TAP
 #define POCR_STA_TAP (NTAP / 2)        // tap after which the next chunk's halo tile (requested at tap 0) is written to the other LDS buffer
 #endif
+#ifdef POCR_BF16X3_TRACE               // tools/conv_ablate.hip: per-workgroup phase stamps (100 MHz wall clock) + where it ran
+__device__ unsigned long long g_conv_trace[1 << 18];
+#define POCR_TRACE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < (1u << 15)) g_conv_trace[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define POCR_TRACE_STAMP(k) do { } while (0)
+#endif
 #ifndef POCR_BF16X3_DBG
 #define POCR_BF16X3_DBG 0            // tools/conv_bench_bf16.hip: 1 no A reads, 2 no weight loads, 4 no A staging, 8 no barrier
 #endif
@@ -176,6 +182,15 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const int wm = wave % WM, wn = wave / WM;
 
+    POCR_TRACE_STAMP(0);
+#ifdef POCR_BF16X3_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < (1u << 15)) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_conv_trace[blockIdx.x * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     // block -> tile mapping (as conv_igemm_kernel)
     int nt, ptile;
     {
@@ -334,6 +349,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     for (int q = 0; q < AHEAD; ++q) ldW(bw[q], wstep(q));
     stA(0);
     __syncthreads();
+    POCR_TRACE_STAMP(1);
     for (int c0 = 0; c0 < nchunks; c0 += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -418,6 +434,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     stA();
     stB(0);
     __syncthreads();
+    POCR_TRACE_STAMP(1);
     int step = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool next_chunk = chunk + 1 < nchunks;
@@ -477,6 +494,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     }
 
     }
+    POCR_TRACE_STAMP(2);
 #pragma unroll
     for (int m = 0; m < MS; ++m)
 #pragma unroll
@@ -562,6 +580,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             }
         }
     }
+#ifdef POCR_BF16X3_TRACE
+    POCR_TRACE_STAMP(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    POCR_TRACE_STAMP(4);
+#endif
 }
 
 }  // namespace pocr

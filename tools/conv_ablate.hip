@@ -66,7 +66,57 @@ VG(g_pin_8x2, 8, 2, 1, 2, true, true, false)    // 128 rows x 128 cols, waves sp
 VG(g_pin_4x4, 4, 4, 1, 1, true, true, false)    // 64 rows x 256 cols (MS 4, NS 4), direct weights
 VG(g_pin_8x4m, 8, 4, 4, 2, false, true, false)  // 128 rows x 64 cols, waves split the rows (MS 2, NS 4), LDS weights
 VG(g_pin_16, 16, 4, 4, 1, false, true, false)   // 256 rows x 64 cols, waves split the rows (MS 4, NS 4), LDS weights
+#ifdef POCR_BF16X3_TRACE
+#include <map>
+#include <algorithm>
+// -DPOCR_BF16X3_TRACE: phase stamps of the LAST launch (100 MHz wall clock: 0 entry, 1 first tile staged, 2 main loop done,
+// 3 stores issued, 4 stores drained) and, per CU, how long the workgroup slots sat between two workgroups
+__global__ void trace_copy_kernel(unsigned long long *out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = g_conv_trace[i];
+}
+static void trace_report(const ConvArgs &a) {
+    (void)a;
+    const size_t nb = 1u << 15;         // every slot; blocks that never ran keep a zero stamp (the launch copies clear nothing: run one layer per process)
+    std::vector<unsigned long long> t(nb * 8);
+    unsigned long long *dp;
+    CK(hipMalloc(&dp, nb * 8 * sizeof(*dp)));
+    hipLaunchKernelGGL(trace_copy_kernel, dim3(256), dim3(256), 0, 0, dp, nb * 8);
+    CK(hipMemcpy(t.data(), dp, nb * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    { hipError_t fe = hipFree(dp); if (fe != hipSuccess) printf("    (hipFree: %d)\n", (int)fe); }
+    unsigned long long tmin = ~0ull, tmax = 0;
+    double ph[4] = {0, 0, 0, 0};
+    std::map<unsigned, std::vector<std::pair<unsigned long long, unsigned long long>>> cu;
+    for (size_t b = 0; b < nb; ++b) {
+        const unsigned long long *q = &t[b * 8];
+        if (!q[4]) continue;
+        tmin = std::min(tmin, q[0]); tmax = std::max(tmax, q[4]);
+        for (int k = 0; k < 4; ++k) ph[k] += (double)(q[k + 1] - q[k]);
+        cu[(unsigned)((q[5] >> 32) << 8) | (unsigned)((q[5] >> 8) & 0xff)].push_back({q[0], q[4]});
+    }
+    const double us = 0.01;
+    size_t ran = 0;
+    for (auto &kv : cu) ran += kv.second.size();
+    if (cu.empty()) { printf("    trace: no stamps (t0 of block 0: %llu %llu %llu %llu %llu)\n", t[0], t[1], t[2], t[3], t[4]); fflush(stdout); return; }
+    printf("    trace: span %.1f us over %zu workgroups on %zu CUs; mean per workgroup: stage-first-tile %.2f us, main loop %.2f us, epilogue issue %.2f us, store drain %.2f us\n",
+           (tmax - tmin) * us, ran, cu.size(), ph[0] / ran * us, ph[1] / ran * us, ph[2] / ran * us, ph[3] / ran * us);
+    double busy = 0, first = 0, last = 0; size_t maxwg = 0, minwg = 1 << 30;
+    for (auto &kv : cu) {
+        auto &v = kv.second;
+        std::sort(v.begin(), v.end());
+        for (auto &w : v) busy += (double)(w.second - w.first);
+        first += (double)(v.front().first - tmin); last += (double)(tmax - v.back().second);
+        maxwg = std::max(maxwg, v.size()); minwg = std::min(minwg, v.size());
+    }
+    printf("    per CU: workgroups %zu..%zu, resident workgroup-time / span = %.2f (2.0 = both slots always occupied), mean first start +%.1f us, mean last end -%.1f us\n",
+           minwg, maxwg, busy / cu.size() / (double)(tmax - tmin), first / cu.size() * us, last / cu.size() * us);
+    auto &v = cu.begin()->second;
+    printf("    CU %#x timeline (start..end us):", cu.begin()->first);
+    for (size_t i = 0; i < v.size() && i < 12; ++i) printf(" %.1f..%.1f", (v[i].first - tmin) * us, (v[i].second - tmin) * us);
+    printf("\n");
+}
+#endif
 int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     const int layer = argc > 1 ? atoi(argv[1]) : 9, wpad = argc > 3 ? atoi(argv[3]) : 576;
     int n = argc > 2 ? atoi(argv[2]) : 256;
     if (layer >= 100) n = 1;
@@ -110,6 +160,9 @@ int main(int argc, char **argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); sum += ms; best = ms < best ? ms : best;
         }
         printf("  %-28s avg %.3f ms best %.3f ms  %.1f TF(alg)\n", v.name, sum / 10, best, flops / (sum / 10 * 1e-3) / 1e12);
+#ifdef POCR_BF16X3_TRACE
+        if (&v == &vars[0]) trace_report(a);
+#endif
     }
     return 0;
 }
