@@ -27,6 +27,21 @@
 #ifndef POCR_BDIR_SETS
 #define POCR_BDIR_SETS 3               // register sets of weight fragments in the direct-weights loop: the set of step s + SETS - 1 is requested while step s computes
 #endif
+#ifndef POCR_CONV_ROWSTREAM
+#define POCR_CONV_ROWSTREAM 1          // 3x3 / f16x2 / direct-weights layers: halo-row streaming main loop (below); 0 = the tap-by-tap loop
+#endif
+#ifndef POCR_ROW_AHEAD
+#define POCR_ROW_AHEAD 2               // row streaming: A fragments requested this many (row, strip) units before the MFMAs that use them
+#endif
+#ifndef POCR_ROW_LDA_Q
+#define POCR_ROW_LDA_Q 3               // row streaming: the next chunk's halo tile is requested after this unit of the chunk's first group (after the
+#endif                                 // weight requests of units 0..2: vmcnt counts in order, so a load issued BEFORE them must land before the next group starts)
+#ifndef POCR_ROW_STA_DX
+#define POCR_ROW_STA_DX 2              // ... and written to the other LDS buffer after this group (2 = right before the chunk's barrier)
+#endif
+#ifndef POCR_GEMM_PIPE
+#define POCR_GEMM_PIPE 1               // 1x1 (GEMM mode) f16x2 layers with LDS weights: double-buffered A and B tiles, one barrier per 32-deep chunk
+#endif
 #ifndef POCR_STA_TAP
 #define POCR_STA_TAP (NTAP / 2)        // tap after which the next chunk's halo tile (requested at tap 0) is written to the other LDS buffer
 #endif
@@ -176,9 +191,13 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     constexpr int A_LD = (8 * NP8 + NTHR - 1) / NTHR;   // staging slots per thread and chunk (CQ = 8 quads or 8 pre-split units per pixel)
     constexpr int B_LD = BDIR ? 1 : (B_F4 + NTHR - 1) / NTHR;
     static_assert(POOLH == 1 || TH % 2 == 0, "H-pool needs an even tile height");
-    __shared__ u32x4 lds[BDIR ? 2 * A_U : A_U + 2 * B_F4];      // one scalar type (unsigned) for every access: no type punning
+    // GEMM mode (one tap per chunk): the tap-by-tap loop below refills its single A buffer between TWO barriers per chunk, which
+    // a 9-tap chunk amortises and a 1-tap chunk does not (the LSTM input projections ran at 95 TFLOP/s) -> own loop, A double-buffered
+    constexpr bool GEMM2 = !BDIR && NTAP == 1 && SPL == 2 && POCR_GEMM_PIPE && POCR_BF16X3_DBG == 0;
+    constexpr int A_BUFS = (BDIR || GEMM2) ? 2 : 1;
+    __shared__ u32x4 lds[BDIR ? 2 * A_U : A_BUFS * A_U + 2 * B_F4];      // one scalar type (unsigned) for every access: no type punning
     u32x4 *ldsA = lds;
-    u32x4 *ldsB = lds + A_U;
+    u32x4 *ldsB = lds + A_BUFS * A_U;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const int wm = wave % WM, wn = wave / WM;
 
@@ -325,7 +344,130 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             if (B_F4 % NTHR == 0 || f < B_F4) ldsB[buf * B_F4 + f] = __builtin_bit_cast(u32x4, rb[r]);
         }
     };
-    if constexpr (BDIR) {
+    // f16x2 3x3: the tap-by-tap loops walk the taps column by column (dx outer, dy inner) - the order in which the row-streaming
+    // loop adds them up - so that every f16x2 build of a layer gives the same bits whatever loop and tile it uses
+    auto tap_w = [](int t) { return (SPL == 2 && KH == 3 && KW == 3) ? (t % 3) * 3 + t / 3 : t; };
+    constexpr bool ROWS = BDIR && POCR_CONV_ROWSTREAM && KH == 3 && KW == 3 && SPL == 2 && POCR_BF16X3_DBG == 0;
+    if constexpr (ROWS) {
+    // ---- halo-row streaming (3x3, f16x2, weights straight from L2).  The tap-by-tap loop reads every A fragment once per
+    // tap - 9 x MS reads of (h, l) per chunk, each issued right before the MFMAs that need it, so a wave sits out the LDS
+    // latency MS times per step (profiles/r03_conv_tile_trace.txt: 0.67 us per step against 0.40 us of MFMA issue).  Here a
+    // chunk is walked column offset by column offset (dx), and inside one dx halo row by halo row: the fragment of halo row j
+    // (pixels j, dx .. dx + 15) is the A operand of output row j - dy for all three dy, so it is read ONCE and used by up to
+    // 3 x 3 NS MFMAs: 3 (TH + 2) reads per chunk instead of 9 TH (2.1x fewer for TH = 5), and each read is requested
+    // POCR_ROW_AHEAD units before its first use (a ring of register pairs).  The three taps (dy, dx) of a column offset are
+    // needed together: two sets of 3 taps of weight fragments, the set of the next (chunk, dx) group requested while the
+    // current one computes (~1400 cycles of MFMA issue ahead).  Accumulation order per output element: chunk, dx, dy.
+    const u32x4 *wq = reinterpret_cast<const u32x4 *>(wt4) + (wn * NS) * WU + lane;
+    constexpr int NROW = TH + 2, NU = NROW * MWW, AH = POCR_ROW_AHEAD, RING = AH + 1;
+    static_assert(NU >= 3 && AH >= 1 && AH <= NU, "row streaming: units per column offset");
+    u32x4 bw[2][3][NS][2], ar[RING][2];
+    auto ldW = [&](u32x4 (&dst)[NS][2], const u32x4 *tile) {
+#pragma unroll
+        for (int n = 0; n < NS; ++n) { dst[n][0] = tile[n * WU]; dst[n][1] = tile[n * WU + 64]; }
+    };
+    auto wtap = [&](int chunk, int tap) {                // (past the last chunk: the last one again - read, never used)
+        return wq + (size_t)tap * tap_stride + (size_t)min(chunk, nchunks - 1) * chunk_stride;
+    };
+    auto rdA = [&](u32x4 (&dst)[2], int abuf, int dx, int unit) {
+        const u32x4 *p = ldsA + abuf * A_U + (unit / MWW) * HW + dx + li + kq * NPPAD + (wm * MWW + unit % MWW) * 16;
+        dst[0] = p[0]; dst[1] = p[PS];
+    };
+    ldA(0);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) ldW(bw[0][dy], wtap(0, dy * 3));
+    stA(0);
+    __syncthreads();
+    POCR_TRACE_STAMP(1);
+    for (int c0 = 0; c0 < nchunks; c0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                    // two chunks = six groups: the weight-set parity is static
+            const int chunk = c0 + u;
+            if (chunk >= nchunks) break;                 // (uniform)
+            const int abuf = chunk & 1;
+#pragma unroll
+            for (int q = 0; q < AH; ++q) rdA(ar[q % RING], abuf, 0, q);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int par = (u * 3 + dx) & 1;
+                const int ndx = dx == 2 ? 0 : dx + 1, nchunk = dx == 2 ? chunk + 1 : chunk;
+#pragma unroll
+                for (int q = 0; q < NU; ++q) {
+                    const int qq = dx * NU + q, pq = qq + AH;
+                    if (pq < 3 * NU) rdA(ar[pq % RING], abuf, pq / NU, pq % NU);
+                    if (q < 3) ldW(bw[par ^ 1][q], wtap(nchunk, q * 3 + ndx));
+                    if (dx == 0 && q == (POCR_ROW_LDA_Q < NU ? POCR_ROW_LDA_Q : NU - 1)) ldA(chunk + 1 < nchunks ? chunk + 1 : chunk);
+                    const int j = q / MWW, mw = q % MWW;
+                    const u32x4 ah = ar[qq % RING][0], al = ar[qq % RING][1];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int r = j - dy;
+                        if (r < 0 || r >= TH) continue;
+                        const int m = r * MWW + mw;
+                        u32x4 (&bc)[NS][2] = bw[par][dy];
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(al, bc[n][0], acc2[m][n]);
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_F16(ah, bc[n][0], acc[m][n]);
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(ah, bc[n][1], acc2[m][n]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // units stay in source order: reads of unit q + AH, then the MFMAs of unit q
+                }
+                if (dx == POCR_ROW_STA_DX) stA(abuf ^ 1);   // the other A buffer: its last readers passed the barrier of the previous chunk
+            }
+            __syncthreads();
+        }
+    }
+    } else if constexpr (GEMM2) {
+    // ---- GEMM mode, f16x2, weights through LDS: chunk c computes from buffer c & 1 while the tiles of chunk c + 1 (in
+    // registers since the middle of chunk c - 1) are split / copied into the other buffer in the middle of chunk c and the
+    // loads of chunk c + 2 leave right after: ONE barrier per chunk, a full chunk of MFMAs between a request and its use.
+    // The A fragments of row strip m + 1 are read while strip m multiplies.
+    ldA(0);
+    ldB(wt4);
+    stA(0);
+    stB(0);
+    ldA(nchunks > 1 ? 1 : 0);
+    ldB(wt4 + (size_t)(nchunks > 1 ? 1 : 0) * chunk_stride);
+    __syncthreads();
+    POCR_TRACE_STAMP(1);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        const u32x4 *Ab = ldsA + cur * A_U + li + kq * NPPAD + wm * MWW * 16;
+        const u32x4 *Bb = ldsB + cur * B_F4 + (wn * NS) * WU + lane;
+        u32x4 bh[NS], bl[NS], af[2][2];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) { bh[n] = Bb[n * WU]; bl[n] = Bb[n * WU + 64]; }
+        af[0][0] = Ab[0]; af[0][1] = Ab[PS];
+#pragma unroll
+        for (int m = 0; m < MS; ++m) {
+            if (m + 1 < MS) {
+                const int o = ((m + 1) / MWW) * HW + ((m + 1) % MWW) * 16;
+                af[(m + 1) & 1][0] = Ab[o]; af[(m + 1) & 1][1] = Ab[o + PS];
+            }
+            const u32x4 ah = af[m & 1][0], al = af[m & 1][1];
+#pragma unroll
+            for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(al, bh[n], acc2[m][n]);
+#pragma unroll
+            for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_F16(ah, bh[n], acc[m][n]);
+#pragma unroll
+            for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(ah, bl[n], acc2[m][n]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m == (MS - 1) / 2) {
+                // (unconditional: after the last chunk the other buffer has no reader, and the clamped re-read keeps the
+                // number of loads in flight the same in every iteration - counted s_waitcnt instead of a drain)
+                stA(cur ^ 1);
+                stB(cur ^ 1);
+                const int c2 = min(chunk + 2, nchunks - 1);
+                ldA(c2);
+                ldB(wt4 + (size_t)c2 * chunk_stride);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    } else if constexpr (BDIR) {
     const u32x4 *wq = reinterpret_cast<const u32x4 *>(wt4) + (wn * NS) * WU + lane;
     // three register sets of weight fragments, rotated with the step (statically: 9 taps = 3 x 3; other tap counts unroll
     // three chunks): the set of step s + 2 is requested while step s computes - two steps (~2000 cycles) cover an L2
@@ -342,7 +484,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     constexpr int U = NTAP % NSETS == 0 ? 1 : (2 * NTAP) % NSETS == 0 ? 2 : (3 * NTAP) % NSETS == 0 ? 3 : NSETS;
     auto wstep = [&](int s_) {                           // weights of global step s_ (clamped to the last step: re-read, never used)
         const int sc = min(s_, nchunks * NTAP - 1);
-        return wq + (size_t)(sc % NTAP) * tap_stride + (size_t)(sc / NTAP) * chunk_stride;
+        return wq + (size_t)tap_w(sc % NTAP) * tap_stride + (size_t)(sc / NTAP) * chunk_stride;
     };
     ldA(0);
 #pragma unroll
@@ -369,7 +511,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #if !(POCR_BF16X3_DBG & 2)
                 ldW(bw[(sl + AHEAD) % NSETS], wstep(chunk * NTAP + tap + AHEAD));
 #endif
-                const int dy = tap / KW, dx = tap % KW;
+                const int dy = tap_w(tap) / KW, dx = tap_w(tap) % KW;
 #if POCR_BF16X3_DBG & 1
                 const u32x4 *Ab = ldsA + li + kq * NPPAD;
 #else
@@ -442,9 +584,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         for (int tap = 0; tap < NTAP; ++tap, ++step) {
             const bool last = tap == NTAP - 1, more = !last || next_chunk;
             const int bcur = step & 1;
-            if (more) ldB(wt4 + (size_t)(last ? 0 : tap + 1) * tap_stride + (size_t)(last ? chunk + 1 : chunk) * chunk_stride);
+            if (more) ldB(wt4 + (size_t)tap_w(last ? 0 : tap + 1) * tap_stride + (size_t)(last ? chunk + 1 : chunk) * chunk_stride);
             if (tap == 0 && next_chunk) ldA(chunk + 1);
-            const int dy = tap / KW, dx = tap % KW;
+            const int dy = tap_w(tap) / KW, dx = tap_w(tap) % KW;
             const u32x4 *Ab = ldsA + dy * HW + dx + li + kq * NPPAD + wm * MWW * 16;
             const u32x4 *Bb = ldsB + bcur * B_F4 + (wn * NS) * WU + lane;
             u32x4 bh[NS], bm[NS], bl[NS];

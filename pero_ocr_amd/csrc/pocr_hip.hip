@@ -214,12 +214,26 @@ POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true, 2)    // 512->
         return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW, BDIR, 3, 3, 1, 1, false, 2, true, true>, \
                            TH, 16 * MW, NS * (4 / WM) * 16, 256, a, st);                                           \
     }
-POCR_CONVP(conv2_p2,  4, 2, 2, 2, 2, 2, ACT_RELU, false, 3, false)
-POCR_CONVP(conv3_p2,  5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
-POCR_CONVP(conv4_p2,  4, 1, 2, 1, 2, 2, ACT_RELU, false, 2, true)
-POCR_CONVP(conv56_p2, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
-POCR_CONVP(conv7_p2,  2, 2, 2, 1, 2, 1, ACT_RELU, false, 2, true)
+// Tiles for the halo-row streaming main loop (conv_bf16x3.hpp ROWS; tools/conv_ablate.hip, profiles/r03_conv_rowstream.txt):
+// 10 x 16 pixels x 64 channels per workgroup (each wave 160 pixels x 16 channels: ten row fragments per weight fragment, so the
+// weight stream from L2 halves against the 80 x 32 wave tile) wherever the image is at least ten rows high - a tile then covers
+// whole columns of the 10-row layers and no halo row is staged twice; 5 x 16 x 128 stays best for the 5-row layers.
+POCR_CONVP(conv2_p2,  10, 1, 1, 1, 2, 2, ACT_RELU, false, 2, true)
+POCR_CONVP(conv3_p2,  10, 1, 1, 1, 1, 1, ACT_RELU, false, 2, true)
+POCR_CONVP(conv4_p2,  10, 1, 1, 1, 2, 2, ACT_RELU, false, 2, true)
+POCR_CONVP(conv56_p2, 10, 1, 1, 1, 1, 1, ACT_RELU, false, 2, true)
+POCR_CONVP(conv7_p2,  10, 1, 1, 1, 2, 1, ACT_RELU, false, 2, true)
 POCR_CONVP(conv8_p2,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true)
+// experiment knob (POCR_P2_ALT_TILES = bit mask over conv2 .. conv7 = bits 1 .. 6): the round-2 tiles
+POCR_CONVP(conv2_p2_alt,  4, 2, 2, 2, 2, 2, ACT_RELU, false, 3, false)
+POCR_CONVP(conv3_p2_alt,  5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
+POCR_CONVP(conv4_p2_alt,  4, 1, 2, 1, 2, 2, ACT_RELU, false, 2, true)
+POCR_CONVP(conv56_p2_alt, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
+POCR_CONVP(conv7_p2_alt,  2, 2, 2, 1, 2, 1, ACT_RELU, false, 2, true)
+int p2_alt_tiles() {
+    static const int m = getenv("POCR_P2_ALT_TILES") ? atoi(getenv("POCR_P2_ALT_TILES")) : 0;
+    return m;
+}
 POCR_CONVP(conv9_p2,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true)
 #define POCR_CONVPG(name, TH, MW, NS, WM, ACT, MINW, KH, BDIR)                                                      \
     int name(ConvArgs a, hipStream_t st) {                                                                         \
@@ -257,6 +271,10 @@ const int kConvTH[10] = {4, 4, 4, 4, 10, 10, 10, 5, 5, 1};
 const int kConvTH3[10] = {4, 4, 5, 4, 5, 5, 2, 5, 5, 1};
 const int kConvTW[10] = {32, 64, 32, 32, 16, 16, 16, 16, 16, 48};
 const int kConvTW3[10] = {32, 32, 16, 16, 16, 16, 32, 16, 16, 48};
+const int kConvTHP[10] = {4, 10, 10, 10, 10, 10, 10, 5, 5, 1};       // the P2 configurations (POCR_CONVP)
+const int kConvTWP[10] = {32, 16, 16, 16, 16, 16, 16, 16, 16, 48};
+inline int conv_tile_h(bool p2, bool b3, int k) { return p2 ? ((p2_alt_tiles() >> k) & 1 ? kConvTH3[k] : kConvTHP[k]) : b3 ? kConvTH3[k] : kConvTH[k]; }
+inline int conv_tile_w(bool p2, bool b3, int k) { return p2 ? ((p2_alt_tiles() >> k) & 1 ? kConvTW3[k] : kConvTWP[k]) : b3 ? kConvTW3[k] : kConvTW[k]; }
 // input width level of each conv (0: W_pad, 1: W_pad/2, 2: (W_pad/2)/2) and of its output
 const int kConvLvlIn[10] = {0, 0, 1, 1, 2, 2, 2, 2, 2, 2};
 const int kConvLvlOut[10] = {0, 1, 1, 2, 2, 2, 2, 2, 2, 2};
@@ -565,11 +583,11 @@ int run_network(pocr_engine *e, Slot &s) {
             if (i == 8) { a.bn_scale = e->bn_scale.as<float>(); a.bn_shift = e->bn_shift.as<float>(); }
             if (e->p2) {
                 switch (i) {
-                    case 1: rc = conv2_p2(a, st); break;
-                    case 2: rc = conv3_p2(a, st); break;
-                    case 3: rc = conv4_p2(a, st); break;
-                    case 4: case 5: rc = conv56_p2(a, st); break;
-                    case 6: rc = conv7_p2(a, st); break;
+                    case 1: rc = (p2_alt_tiles() >> 1) & 1 ? conv2_p2_alt(a, st) : conv2_p2(a, st); break;
+                    case 2: rc = (p2_alt_tiles() >> 2) & 1 ? conv3_p2_alt(a, st) : conv3_p2(a, st); break;
+                    case 3: rc = (p2_alt_tiles() >> 3) & 1 ? conv4_p2_alt(a, st) : conv4_p2(a, st); break;
+                    case 4: case 5: rc = (p2_alt_tiles() >> i) & 1 ? conv56_p2_alt(a, st) : conv56_p2(a, st); break;
+                    case 6: rc = (p2_alt_tiles() >> 6) & 1 ? conv7_p2_alt(a, st) : conv7_p2(a, st); break;
                     case 7: rc = conv8_p2(a, st); break;
                     default: rc = conv9_p2(a, st); break;
                 }
@@ -1478,7 +1496,7 @@ static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n,
             zlo[1][i] = std::max(c_hi, c_lo); zhi[1][i] = w_pads[i];
         }
     for (int k = 0; k < 10; ++k) {
-        const int th = (e->bf16x3 ? kConvTH3 : kConvTH)[k], tw = (e->bf16x3 ? kConvTW3 : kConvTW)[k];
+        const int th = conv_tile_h(e->p2, e->bf16x3, k), tw = conv_tile_w(e->p2, e->bf16x3, k);
         const int h_in = k < 9 ? hh : hh;                       // aggregation conv: one output row
         const int rows_out = k < 9 ? h_in : 1;
         const int pw = k < 9 ? kConvPlan[k].pw : 1;

@@ -47,6 +47,9 @@ VP(p3_g, 10, 1, 1, 1, 1, 1, ACT_RELU, false, 2, true)     // 10x16, NS 1 (NT 64)
 VP(p4_b, 4, 1, 2, 1, 2, 2, ACT_RELU, false, 3, true)      // conv4: shipped tile, 3 WG/CU budget
 VP(p4_c, 4, 2, 2, 1, 2, 2, ACT_RELU, false, 2, true)      // 4x32
 VP(p4_d, 2, 2, 2, 1, 2, 2, ACT_RELU, false, 3, true)      // 2x32
+VP(p4_e, 10, 1, 1, 1, 2, 2, ACT_RELU, false, 2, true)     // conv4: 10x16 NS 1
+VP(p4_f, 4, 2, 1, 1, 2, 2, ACT_RELU, false, 2, true)      // conv4: 4x32 NS 1 (MS 8)
+VP(p4_g, 20, 1, 1, 1, 2, 2, ACT_RELU, false, 2, true)     // conv4: 20x16 NS 1 (MS 20)
 VP(p7_b, 2, 2, 2, 1, 2, 1, ACT_RELU, false, 3, true)
 VP(p7_c, 2, 1, 2, 1, 2, 1, ACT_RELU, false, 3, true)      // 2x16 (MS 2)
 VP(p7_d, 10, 1, 1, 1, 2, 1, ACT_RELU, false, 2, true)     // 10x16 NS 1
@@ -131,9 +134,9 @@ int main(int argc, char **argv) {
     else if (layer == 8) { s = {256, 512, 5, wpad / 4, 1, 1}; vars = {{"P2 5x16 NT128 (shipped)", p8, 2}}; }
     else if (layer == 7) { s = {256, 256, 10, wpad / 4, 2, 1}; vars = {{"P2 2x32 NT128 (shipped)", p7, 2}, {"P2 2x32 3WG", p7_b, 2}, {"P2 2x16 3WG", p7_c, 2}, {"P2 10x16 NT64", p7_d, 2}, {"P2 2x64 NT64", p7_e, 2}}; }
     else if (layer == 6 || layer == 5) { s = {layer == 5 ? 128 : 256, 256, 10, wpad / 4, 1, 1}; vars = {{"P2 5x16 NT128 (shipped)", p6, 2}, {"P2 5x16 3WG", p3_d, 2}, {"P2 2x32 3WG", p3_e, 2}, {"P2 5x32 NT64", p3_f, 2}, {"P2 10x16 NT64", p3_g, 2}}; }
-    else if (layer == 4) { s = {128, 128, 20, wpad / 2, 2, 2}; vars = {{"P2 4x16 NT128 (shipped)", p4, 2}, {"P2 4x16 3WG", p4_b, 2}, {"P2 4x32", p4_c, 2}, {"P2 2x32 3WG", p4_d, 2}}; }
+    else if (layer == 4) { s = {128, 128, 20, wpad / 2, 2, 2}; vars = {{"P2 4x16 NT128 (shipped)", p4, 2}, {"P2 4x16 3WG", p4_b, 2}, {"P2 4x32", p4_c, 2}, {"P2 10x16 NT64", p4_e, 2}, {"P2 4x32 NT64", p4_f, 2}}; }
     else if (layer == 3) { s = {64, 128, 20, wpad / 2, 1, 1}; vars = {{"P2 5x16 NT128 (shipped)", p3, 2}, {"P2 4x16 3WG", p3_b, 2}, {"P2 4x32", p3_c, 2}, {"P2 5x16 3WG", p3_d, 2}, {"P2 2x32 3WG", p3_e, 2}, {"P2 5x32 NT64", p3_f, 2}, {"P2 10x16 NT64", p3_g, 2}}; }
-    else { s = {64, 64, 40, wpad, 2, 2}; vars = {{"P2 lds 4x32 NT64 3WG (shipped)", p2, 2}, {"P2 lds 8x32", p2_b, 2}, {"P2 direct 4x32 3WG", p2_c, 2}, {"P2 direct 8x32", p2_d, 2}, {"P2 lds 4x64 M-split NS4", p2_e, 2}, {"P2 direct 4x64 M-split NS4", p2_f, 2}, {"P2 lds 4x32 2WG", p2_g, 2}, {"P2 lds 2x64 3WG", p2_h, 2}}; }
+    else { s = {64, 64, 40, wpad, 2, 2}; vars = {{"P2 lds 4x32 NT64 3WG (shipped)", p2, 2}, {"P2 lds 8x32", p2_b, 2}, {"P2 direct 4x32 3WG", p2_c, 2}, {"P2 direct 8x32", p2_d, 2}, {"P2 lds 4x64 M-split NS4", p2_e, 2}, {"P2 direct 4x64 M-split NS4", p2_f, 2}, {"P2 lds 4x32 2WG", p2_g, 2}, {"P2 direct 10x16 NS1", p4_e, 2}, {"P2 direct 4x32 NS1", p4_f, 2}}; }
     const size_t xin = (size_t)n * s.H * s.W * s.cin, yout = (size_t)n * (s.H / s.ph) * (s.W / s.pw) * s.cout;
     std::vector<float> hx(xin);
     unsigned r = 12345;
