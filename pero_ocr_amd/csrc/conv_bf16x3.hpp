@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     constexpr int B_LD = BDIR ? 1 : (B_F4 + NTHR - 1) / NTHR;
     static_assert(POOLH == 1 || TH % 2 == 0, "H-pool needs an even tile height");
     // GEMM mode (one tap per chunk): the tap-by-tap loop below refills its single A buffer between TWO barriers per chunk, which
-    // a 9-tap chunk amortises and a 1-tap chunk does not (the LSTM input projections ran at 95 TFLOP/s) -> own loop, A double-buffered
+    // a 9-tap chunk amortises and a 1-tap chunk does not -> own loop, A double-buffered (+5 %: profiles/r03_gemm_pipe.txt; the same
+    // loop with the weights straight from L2 - one register set, reloaded channel tile by channel tile - measured the same
+    // 210 TFLOP/s on the 53248 x 512 x 2048 projection, so it is not the LDS traffic that holds this tile shape at ~37 % MFMA issue)
     constexpr bool GEMM2 = !BDIR && NTAP == 1 && SPL == 2 && POCR_GEMM_PIPE && POCR_BF16X3_DBG == 0;
     constexpr int A_BUFS = (BDIR || GEMM2) ? 2 : 1;
     __shared__ u32x4 lds[BDIR ? 2 * A_U : A_BUFS * A_U + 2 * B_F4];      // one scalar type (unsigned) for every access: no type punning

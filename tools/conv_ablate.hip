@@ -62,6 +62,7 @@ V(h9, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true, 2)
 #define VG(NAME, MW, NS, WM, MINW, BDIR, PIN, POUT) static void NAME(ConvArgs a, hipStream_t st) { \
     launch(conv3x3_bf16x3_kernel<1, MW, NS, WM, 1, 1, ACT_NONE, false, MINW, BDIR, 1, 1, 0, 0, false, 2, PIN, POUT>, 1, 16 * MW, NS * (4 / WM) * 16, a, st); }
 VG(g_ship, 8, 4, 2, 2, false, false, false)     // shipped: 128 x 128, LDS weights, split inside
+VG(g_ship_d, 8, 4, 2, 2, true, false, false)   // fp32 in, weights straight from L2
 VG(g_pin, 8, 4, 2, 2, false, true, false)       // the same with pre-split input
 VG(g_pin_d, 8, 4, 2, 2, true, true, false)      // + weights straight from L2
 VG(g_pin_out, 8, 4, 2, 2, false, true, true)    // pre-split in and out
@@ -127,7 +128,7 @@ int main(int argc, char **argv) {
     if (layer >= 100) {       // GEMM mode: 100 = 512 -> 2048 (FFN1 / LSTM projection), 101 = 2048 -> 512 (FFN2), 102 = 512 -> 512
         const int rows = 53248;
         s = {layer == 101 ? 2048 : 512, layer == 100 ? 2048 : 512, 1, rows, 1, 1};
-        vars = {{"GEMM 128x128 LDS, split inside (shipped)", g_ship, 2}, {"GEMM P2 in", g_pin, 2}, {"GEMM P2 in, direct weights", g_pin_d, 2},
+        vars = {{"GEMM 128x128 LDS, split inside (shipped)", g_ship, 2}, {"GEMM 128x128 direct weights, split inside", g_ship_d, 2}, {"GEMM P2 in", g_pin, 2}, {"GEMM P2 in, direct weights", g_pin_d, 2},
                 {"GEMM P2 in + out", g_pin_out, 2}, {"GEMM P2 128x128 N-split direct", g_pin_8x2, 2}, {"GEMM P2 64x256 direct", g_pin_4x4, 2},
                 {"GEMM P2 128x64 M-split LDS", g_pin_8x4m, 2}, {"GEMM P2 256x64 M-split LDS", g_pin_16, 2}};
     } else if (layer == 9) { s = {512, 512, 5, wpad / 4, 1, 1}; vars = {{"f16x2 in-kernel split 5x16 NT128", h9, 2}, {"P2 5x16 NT128 (shipped)", p9, 2}, {"P2 5x16 NT128 3WG", p9_b, 2}, {"P2 5x32 NT64", p9_c, 2}, {"P2 5x16 NT64 4WG", p9_d, 2}}; }
