@@ -27,10 +27,12 @@ struct Conv1Args {
     const int64_t *out_off;
     int32_t H, n_ptiles;
     int32_t src_h;               // rows the crops really have (0: = H); rows [src_h, H) are zero padding (layout network pages)
+    const void *w1x2;            // F16X2: [cout/16 = 4][plane h, l][lane] x 8 f16: k = 8 (lane >> 4) + j, cout = 16 s + (lane & 15), zero for k >= 27
 };
 
 // P2OUT: the output is written in the pre-split f16x2 layout conv2 stages by plain copies (conv_bf16x3.hpp, "P2").
-template <bool P2OUT = false>
+// F16X2: the arithmetic above (the recogniser in its default mode) instead of fp32 MFMA.
+template <bool P2OUT = false, bool F16X2 = false>
 __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
     constexpr int TH = 4, TW = 32, HH = TH + 2, HW = TW + 2, NH = HH * HW * 3;
     __shared__ float halo[NH + 4];                    // [row][col][c]; halo[NH] = 0 backs the k >= 27 padding
@@ -69,6 +71,15 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
             koff[kg][j] = k < 27 ? ((tap / 3) * HW + tap % 3) * 3 + c : -1;
         }
     }
+    u32x4 xwh = {0u, 0u, 0u, 0u}, xwl = {0u, 0u, 0u, 0u};
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    int koff8[8];
+    if constexpr (F16X2) {        // (conv_bf16x3.hpp: conv1_mma_f16x2 - weights are the A operand, a lane gets channels 16 wave + 4 kq + r of pixel li)
+        xwh = reinterpret_cast<const u32x4 *>(a.w1x2)[(wave * 2 + 0) * 64 + lane];
+        xwl = reinterpret_cast<const u32x4 *>(a.w1x2)[(wave * 2 + 1) * 64 + lane];
+        bias4 = *reinterpret_cast<const f32x4 *>(a.bias + 16 * wave + 4 * kq);
+        conv1_koff(koff8, kq, HW);
+    }
     __syncthreads();
     const float bias = a.bias[wave * 16 + li];
     float *yimg = a.y + a.out_off[img];
@@ -78,6 +89,25 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
         for (int mw = 0; mw < 2; ++mw) {
             const int base = (th * HW + mw * 16 + li) * 3;     // halo element of tap (0,0), channel 0 for this lane's pixel
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (F16X2) {
+                u32x4 xh, xl;
+                conv1_x_frag(halo, base, koff8, NH, xh, xl);
+                const f32x4 d = conv1_mma_f16x2(xh, xl, xwh, xwl);
+                const int ho = h0 + th, wc = w0 + mw * 16 + li;
+                if (ho >= a.H || wc >= Wp) continue;
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float t = d[r] + bias4[r]; v[r] = t > 0.f ? t : 0.f; }
+                if constexpr (P2OUT) {
+                    u32x2 hh, ll;
+                    split2_quad(v, hh, ll);
+                    u32x2 *dd = reinterpret_cast<u32x2 *>(reinterpret_cast<char *>(yimg + ((size_t)ho * Wp + wc) * 64) + p2_channel_bytes(wave * 16 + 4 * kq));
+                    dd[0] = hh; dd[8] = ll;
+                } else {
+                    *reinterpret_cast<f32x4 *>(yimg + ((size_t)ho * Wp + wc) * 64 + wave * 16 + 4 * kq) = v;
+                }
+                continue;
+            } else {
 #pragma unroll
             for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
@@ -85,6 +115,7 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
                     const float av = halo[koff[kg][j] >= 0 ? base + koff[kg][j] : NH];
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wb[kg][j], acc, 0, 0, 0);
                 }
+            }
             const int ho = h0 + th;
             if (ho >= a.H) continue;
             float v[4];

@@ -141,6 +141,41 @@ __device__ __forceinline__ void split2_scalar(float v, _Float16 &h, _Float16 &l)
 }
 __device__ __forceinline__ size_t p2_channel_bytes(int c) { return (size_t)(c >> 5) * 128 + (size_t)(c & 31) * 2; }   // plane h; plane l at + 64
 
+// conv1 in the f16x2 arithmetic of the rest of the stack: K = 27 fits ONE 32-deep product block, so 16 pixels x 16 channels
+// are three MFMAs (w_h x_l, w_h x_h, w_l x_h) instead of eight fp32 ones.  The WEIGHTS are the MFMA's A operand (rows =
+// channels) and the pixels its B operand, so a lane ends up with four consecutive channels 4 (lane >> 4) + r of ONE pixel
+// (lane & 15) - the shape the NHWC / P2 stores want, no transpose.  `patch` holds the normalised input (fp32, [row][col][c],
+// PW pixels per row), `base` the element of tap (0, 0) / channel 0 of this lane's pixel, koff[j] the offset of the lane's
+// k slot 8 (lane >> 4) + j (-1: k >= 27 -> the zero at zero_idx).  Shared by conv1_u8_kernel and by conv2's fused prologue
+// (conv3x3_bf16x3_kernel FUSE1), which therefore give the same bits.
+__device__ __forceinline__ void conv1_koff(int (&koff)[8], int kq, int PW) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * kq + j, tap = k / 3, c = k - 3 * tap;
+        koff[j] = k < 27 ? ((tap / 3) * PW + tap % 3) * 3 + c : -1;
+    }
+}
+__device__ __forceinline__ void conv1_x_frag(const float *patch, int base, const int (&koff)[8], int zero_idx, u32x4 &xh, u32x4 &xl) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = patch[koff[j] >= 0 ? base + koff[j] : zero_idx];
+    u32x2 h0, l0, h1, l1;
+    split2_quad((f32x4){x[0], x[1], x[2], x[3]}, h0, l0);
+    split2_quad((f32x4){x[4], x[5], x[6], x[7]}, h1, l1);
+    xh = (u32x4){h0[0], h0[1], h1[0], h1[1]};
+    xl = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+}
+__device__ __forceinline__ f32x4 conv1_mma_f16x2(u32x4 xh, u32x4 xl, u32x4 wh, u32x4 wl) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc2 = POCR_MFMA_F16(wh, xl, z);
+    const f32x4 acc = POCR_MFMA_F16(wh, xh, z);
+    acc2 = POCR_MFMA_F16(wl, xh, acc2);
+    f32x4 d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = __builtin_fmaf(acc2[r], 1.0f / kF16x2Scale, acc[r]);
+    return d;
+}
+
 // Issue-order template for the scheduler (LDS-weights loop): the G operand reads of a step spread evenly between its TOT MFMAs.
 template <int G, int TOT, int... I>
 __device__ __forceinline__ void sched_template_lds(std::integer_sequence<int, I...>) {
@@ -172,8 +207,14 @@ __device__ __forceinline__ void sched_template_dir(std::integer_sequence<int, I.
 // UPCAT: the input is the virtual tensor cat([nearest-upsample-x2(x), x2], channels) of the layout network's decoder
 // (conv_igemm.hpp STAGE_UPCAT): 32-channel chunks below cin_up come from x at half resolution, the rest from the skip tensor.
 template <int TH, int MW, int NS, int WM, int POOLH, int POOLW, int ACT, bool BN, int MINW = 1, bool BDIR = false,
-          int KH = 3, int KW = 3, int PADH = 1, int PADW = 1, bool UPCAT = false, int SPL = 3, bool PRE_IN = false, bool PRE_OUT = false>
+          int KH = 3, int KW = 3, int PADH = 1, int PADW = 1, bool UPCAT = false, int SPL = 3, bool PRE_IN = false, bool PRE_OUT = false,
+          bool FUSE1 = false>
 __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
+    // FUSE1 (conv2 of the recogniser, cin = 64): the input tensor is never read - the workgroup computes conv1 (3 -> 64, 3x3,
+    // ReLU, from the uint8 crops: conv1_u8.hpp) for the pixels of its own halo tile straight into the two A buffers in LDS.
+    // conv1's output (1.5 GB per 256-line launch, written at 2.9 TB/s and read back by conv2) then does not exist; the price
+    // is conv1 recomputed on the halo overlap, 168 extra MFMAs per workgroup against 2160.
+    static_assert(!FUSE1 || (PRE_IN && BDIR && KH == 3 && KW == 3 && SPL == 2 && POCR_CONV_ROWSTREAM), "FUSE1 rides on the row-streaming P2 loop");
     // PRE_IN: the input is in the P2 (pre-split) layout; PRE_OUT: the epilogue writes that layout (both f16x2 only)
     static_assert(!(PRE_IN || PRE_OUT) || SPL == 2, "the pre-split activation layout is the f16x2 representation");
     static_assert(!(PRE_IN && UPCAT), "the layout network keeps fp32 activations");
@@ -197,7 +238,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     // 210 TFLOP/s on the 53248 x 512 x 2048 projection, so it is not the LDS traffic that holds this tile shape at ~37 % MFMA issue)
     constexpr bool GEMM2 = !BDIR && NTAP == 1 && SPL == 2 && POCR_GEMM_PIPE && POCR_BF16X3_DBG == 0;
     constexpr int A_BUFS = (BDIR || GEMM2) ? 2 : 1;
-    __shared__ u32x4 lds[BDIR ? 2 * A_U : A_BUFS * A_U + 2 * B_F4];      // one scalar type (unsigned) for every access: no type punning
+    constexpr int F1_PW = HW + 2, F1_N = (HH + 2) * F1_PW * 3;            // FUSE1: conv1's input patch ([row][col][c] floats) behind the A buffers
+    constexpr int F1_U = FUSE1 ? (F1_N + 4 + 3) / 4 : 0;
+    __shared__ u32x4 lds[(BDIR ? 2 * A_U : A_BUFS * A_U + 2 * B_F4) + F1_U];      // one scalar type (unsigned) for every access: no type punning
     u32x4 *ldsA = lds;
     u32x4 *ldsB = lds + A_BUFS * A_U;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
@@ -375,10 +418,71 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         const u32x4 *p = ldsA + abuf * A_U + (unit / MWW) * HW + dx + li + kq * NPPAD + (wm * MWW + unit % MWW) * 16;
         dst[0] = p[0]; dst[1] = p[PS];
     };
-    ldA(0);
+    if constexpr (!FUSE1) ldA(0);
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) ldW(bw[0][dy], wtap(0, dy * 3));
-    stA(0);
+    if constexpr (FUSE1) {
+        float *patch = reinterpret_cast<float *>(lds + 2 * A_U);
+        const LineDesc ld = a.f1_lines[img];
+        const uint8_t *src = a.f1_crops + ld.offset;
+        const int src_h = a.f1_src_h > 0 ? a.f1_src_h : a.H;
+        // conv1's input patch, as conv1_u8_kernel stages it, one more ring of pixels (all byte loads first, then the table look-ups)
+        constexpr int F1_IT = (F1_N + NTHR - 1) / NTHR;
+        unsigned char pb[F1_IT];
+        bool pok[F1_IT];
+#pragma unroll
+        for (int it = 0; it < F1_IT; ++it) {
+            const int e = tid + it * NTHR, c = e % 3, p = e / 3, wc = p % F1_PW, hr = p / F1_PW;
+            const int hi = h0 - 2 + hr, wi = w0 - 2 + wc, xc = wi - ld.pad_left;
+            pok[it] = e < F1_N && hi >= 0 && hi < src_h && wi >= 0 && wi < Win && xc >= 0 && xc < ld.width;
+            pb[it] = pok[it] ? src[((size_t)hi * ld.width + xc) * 3 + c] : (unsigned char)0;
+        }
+        // conv1's weights (A operand) of all four channel tiles, its bias for this lane's channels 16 nt + 4 kq + r
+        u32x4 xwh[4], xwl[4];
+        f32x4 bias1[4];
+#pragma unroll
+        for (int nt1 = 0; nt1 < 4; ++nt1) {
+            xwh[nt1] = reinterpret_cast<const u32x4 *>(a.f1_w)[(nt1 * 2 + 0) * 64 + lane];
+            xwl[nt1] = reinterpret_cast<const u32x4 *>(a.f1_w)[(nt1 * 2 + 1) * 64 + lane];
+            bias1[nt1] = *reinterpret_cast<const f32x4 *>(a.f1_bias + 16 * nt1 + 4 * kq);
+        }
+#pragma unroll
+        for (int it = 0; it < F1_IT; ++it) {
+            const int e = tid + it * NTHR;
+            const float v = pok[it] ? a.f1_lut[pb[it]] : 0.f;
+            if (e < F1_N) patch[e] = v;
+        }
+        if (tid < 4) patch[F1_N + tid] = 0.f;
+        int koff8[8];
+        conv1_koff(koff8, kq, F1_PW);
+        __syncthreads();
+        // the waves share the pixel tiles (16 halo pixels each), every wave computes all 64 channels of its tiles
+#pragma unroll
+        for (int it = 0; it < (NPPAD / 16 + NWAVE - 1) / NWAVE; ++it) {      // (unrolled: the iterations are independent chains gather -> MFMA -> split -> LDS)
+            const int mt = wave + it * NWAVE;
+            if (mt >= NPPAD / 16) break;
+            const int px = mt * 16 + li, pa = min(px, NP - 1);
+            u32x4 xh, xl;
+            conv1_x_frag(patch, ((pa / HW) * F1_PW + pa % HW) * 3, koff8, F1_N, xh, xl);
+            const int hi = h0 - 1 + pa / HW, wi = w0 - 1 + pa % HW;
+            const bool inside = px < NP && hi >= 0 && hi < a.H && wi >= 0 && wi < Win;      // outside the image: conv2's zero padding
+#pragma unroll
+            for (int nt1 = 0; nt1 < 4; ++nt1) {
+                const f32x4 d = conv1_mma_f16x2(xh, xl, xwh[nt1], xwl[nt1]);
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float t = d[r] + bias1[nt1][r]; v[r] = (inside && t > 0.f) ? t : 0.f; }
+                u32x2 hh, ll;
+                split2_quad(v, hh, ll);
+                // channels 16 nt1 + 4 kq .. + 3: chunk nt1 >> 1, octet 2 (nt1 & 1) + (kq >> 1), half kq & 1
+                u32x2 *dst = reinterpret_cast<u32x2 *>(ldsA + (nt1 >> 1) * A_U + (2 * (nt1 & 1) + (kq >> 1)) * NPPAD + px) + (kq & 1);
+                dst[0] = hh;
+                dst[2 * PS] = ll;
+            }
+        }
+    } else {
+        stA(0);
+    }
     __syncthreads();
     POCR_TRACE_STAMP(1);
     for (int c0 = 0; c0 < nchunks; c0 += 2) {
@@ -398,7 +502,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                     const int qq = dx * NU + q, pq = qq + AH;
                     if (pq < 3 * NU) rdA(ar[pq % RING], abuf, pq / NU, pq % NU);
                     if (q < 3) ldW(bw[par ^ 1][q], wtap(nchunk, q * 3 + ndx));
-                    if (dx == 0 && q == (POCR_ROW_LDA_Q < NU ? POCR_ROW_LDA_Q : NU - 1)) ldA(chunk + 1 < nchunks ? chunk + 1 : chunk);
+                    if (!FUSE1 && dx == 0 && q == (POCR_ROW_LDA_Q < NU ? POCR_ROW_LDA_Q : NU - 1)) ldA(chunk + 1 < nchunks ? chunk + 1 : chunk);
                     const int j = q / MWW, mw = q % MWW;
                     const u32x4 ah = ar[qq % RING][0], al = ar[qq % RING][1];
 #pragma unroll
@@ -416,7 +520,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);   // units stay in source order: reads of unit q + AH, then the MFMAs of unit q
                 }
-                if (dx == POCR_ROW_STA_DX) stA(abuf ^ 1);   // the other A buffer: its last readers passed the barrier of the previous chunk
+                if (!FUSE1 && dx == POCR_ROW_STA_DX) stA(abuf ^ 1);   // the other A buffer: its last readers passed the barrier of the previous chunk
             }
             __syncthreads();
         }

@@ -114,6 +114,13 @@ struct ConvArgs {
     // (its L2 holds 1 / tiles_n of the weights; a pixel tile's halo is fetched by tiles_n XCDs), G > 1 = consecutive
     // workgroups of an XCD take G channel tiles of the SAME pixel tile (the halo is fetched once per G, the XCD's L2 holds G / tiles_n of the weights)
     int32_t xcd_g;
+    // conv3x3_bf16x3_kernel FUSE1 (conv2 computing conv1 for its own halo tile, conv_bf16x3.hpp): conv1's inputs, as Conv1Args
+    const uint8_t *f1_crops;
+    const LineDesc *f1_lines;
+    const float *f1_lut;
+    const void *f1_w;        // conv1 weights as f16x2 fragments (Conv1Args::w1x2)
+    const float *f1_bias;
+    int32_t f1_src_h;
 };
 
 // number of workgroups for a conv launch (must match the block -> tile mapping in the kernel)

@@ -224,6 +224,10 @@ POCR_CONVP(conv4_p2,  10, 1, 1, 1, 2, 2, ACT_RELU, false, 2, true)
 POCR_CONVP(conv56_p2, 10, 1, 1, 1, 1, 1, ACT_RELU, false, 2, true)
 POCR_CONVP(conv7_p2,  10, 1, 1, 1, 2, 1, ACT_RELU, false, 2, true)
 POCR_CONVP(conv8_p2,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true)
+// conv2 with conv1 computed in its prologue (conv_bf16x3.hpp FUSE1): the recogniser's default; conv1's activation is then never written
+int conv2_p2_fused(ConvArgs a, hipStream_t st) {
+    return launch_conv(conv3x3_bf16x3_kernel<10, 1, 1, 1, 2, 2, ACT_RELU, false, 2, true, 3, 3, 1, 1, false, 2, true, true, true>, 10, 16, 64, 256, a, st);
+}
 // experiment knob (POCR_P2_ALT_TILES = bit mask over conv2 .. conv7 = bits 1 .. 6): the round-2 tiles
 POCR_CONVP(conv2_p2_alt,  4, 2, 2, 2, 2, 2, ACT_RELU, false, 3, false)
 POCR_CONVP(conv3_p2_alt,  5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
@@ -444,6 +448,8 @@ struct pocr_engine {
     int dec_out_cout16 = 0;
     bool lstm_resident = true;       // one launch per BiLSTM layer with the hidden state handed over inside an XCD (lstm_resident.hpp); POCR_LSTM_RESIDENT=0: one launch per step
     bool warned_nonfinite = false, warned_placement = false;
+    bool fuse12 = false;             // conv1 inside conv2's prologue (P2 only; POCR_NO_FUSE12=1: conv1 as its own launch, its activation in HBM)
+    DevBuf conv1_w2;                 // conv1's weights as f16x2 fragments (Conv1Args::w1x2)
     bool p2 = false;                 // f16x2 with pre-split activations between conv1 and the aggregation conv (conv_bf16x3.hpp "P2"; POCR_NO_P2=1: split in every consumer)
     bool bf16x3 = true;              // conv2..conv9 on the bf16 matrix pipe with the exact 3-way operand split (POCR_CONV_FP32=1: fp32 MFMA)
     DevBuf cconst[9];                // per conv layer: the output column [H_out][cout] far inside zero padding
@@ -525,6 +531,24 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(f32x4 *p, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
+// conv1 as its own launch (every mode but the fused default; pocr_debug_read(0) runs it on demand in the fused mode)
+int launch_conv1(pocr_engine *e, Slot &s, hipStream_t st) {
+    Conv1Args c1{};
+    c1.crops = s.crops_ext ? s.crops_ext : s.crops.as<uint8_t>(); c1.lines = s.lines.as<LineDesc>(); c1.lut = e->lut.as<float>();
+    c1.wfrag = e->conv_w[0].as<float>(); c1.bias = e->conv_b[0].as<float>(); c1.y = s.act[0].as<float>();
+    c1.w1x2 = e->conv1_w2.p;
+    c1.tiles = s.g_tiles[0]; c1.line_w = s.g_lvl_w[0]; c1.out_off = s.g_act_off[0];
+    c1.H = e->cfg.height; c1.n_ptiles = s.g_ntiles[0];
+    if (c1.n_ptiles > 0) {
+        const bool x2 = conv_split() == 2;           // f16x2 builds: conv1 in the same arithmetic as the fused prologue
+        if (e->p2) hipLaunchKernelGGL((conv1_u8_kernel<true, true>), dim3(c1.n_ptiles), dim3(256), 0, st, c1);
+        else if (x2) hipLaunchKernelGGL((conv1_u8_kernel<false, true>), dim3(c1.n_ptiles), dim3(256), 0, st, c1);
+        else hipLaunchKernelGGL((conv1_u8_kernel<false, false>), dim3(c1.n_ptiles), dim3(256), 0, st, c1);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int run_network(pocr_engine *e, Slot &s) {
     const pocr_config &c = e->cfg;
     hipStream_t st = s.stream;          // switches to s.seq_stream after the backbone
@@ -568,22 +592,21 @@ int run_network(pocr_engine *e, Slot &s) {
         mark(i);
         int rc = 0;
         if (i == 0) {
-            Conv1Args c1{};
-            c1.crops = s.crops_ext ? s.crops_ext : s.crops.as<uint8_t>(); c1.lines = s.lines.as<LineDesc>(); c1.lut = e->lut.as<float>();
-            c1.wfrag = e->conv_w[0].as<float>(); c1.bias = e->conv_b[0].as<float>(); c1.y = s.act[0].as<float>();
-            c1.tiles = s.g_tiles[0]; c1.line_w = s.g_lvl_w[0]; c1.out_off = s.g_act_off[0];
-            c1.H = h; c1.n_ptiles = s.g_ntiles[0];
-            if (c1.n_ptiles > 0) {
-                if (e->p2) hipLaunchKernelGGL(conv1_u8_kernel<true>, dim3(c1.n_ptiles), dim3(256), 0, st, c1);
-                else hipLaunchKernelGGL(conv1_u8_kernel<false>, dim3(c1.n_ptiles), dim3(256), 0, st, c1);
-            }
-            HIP_TRY(hipGetLastError());
+            if (!e->fuse12) rc = launch_conv1(e, s, st);
         } else {
             a.x = s.act[i - 1].as<float>(); a.cin = L.cin;
             if (i == 8) { a.bn_scale = e->bn_scale.as<float>(); a.bn_shift = e->bn_shift.as<float>(); }
             if (e->p2) {
                 switch (i) {
-                    case 1: rc = (p2_alt_tiles() >> 1) & 1 ? conv2_p2_alt(a, st) : conv2_p2(a, st); break;
+                    case 1:
+                        if (e->fuse12) {
+                            a.f1_crops = s.crops_ext ? s.crops_ext : s.crops.as<uint8_t>(); a.f1_lines = s.lines.as<LineDesc>();
+                            a.f1_lut = e->lut.as<float>(); a.f1_w = e->conv1_w2.p; a.f1_bias = e->conv_b[0].as<float>(); a.f1_src_h = 0;
+                            rc = conv2_p2_fused(a, st);
+                        } else {
+                            rc = (p2_alt_tiles() >> 1) & 1 ? conv2_p2_alt(a, st) : conv2_p2(a, st);
+                        }
+                        break;
                     case 2: rc = (p2_alt_tiles() >> 2) & 1 ? conv3_p2_alt(a, st) : conv3_p2(a, st); break;
                     case 3: rc = (p2_alt_tiles() >> 3) & 1 ? conv4_p2_alt(a, st) : conv4_p2(a, st); break;
                     case 4: case 5: rc = (p2_alt_tiles() >> i) & 1 ? conv56_p2_alt(a, st) : conv56_p2(a, st); break;
@@ -1129,7 +1152,11 @@ static int compute_pad_constants(pocr_engine *e) {
     Slot &s = e->slot[POCR_NUM_SLOTS];
     s.want_logits = s.want_argmax = s.want_sparse = false;
     s.s2s_batches = 0; s.s2s_cap = 0;
-    if (run_network(e, s)) return 1;
+    const bool fuse12 = e->fuse12;
+    e->fuse12 = false;                           // ... and writes conv1's activation (its constant column serves pocr_debug_read)
+    const int rc_run = run_network(e, s);
+    e->fuse12 = fuse12;
+    if (rc_run) return 1;
     HIP_TRY(hipStreamSynchronize(s.stream));
     HIP_TRY(hipStreamSynchronize(s.seq_stream));
     int wl[3] = {w_pad, w_pad / 2, w_pad / 4};
@@ -1168,6 +1195,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     e->bf16x3 = conv_split() != 0;
     if (const char *env = getenv("POCR_LSTM_RESIDENT")) e->lstm_resident = atoi(env) != 0;
     e->p2 = conv_split() == 2 && !(getenv("POCR_NO_P2") && atoi(getenv("POCR_NO_P2")) != 0);
+    e->fuse12 = e->p2 && !(getenv("POCR_NO_FUSE12") && atoi(getenv("POCR_NO_FUSE12")) != 0) && !((p2_alt_tiles() >> 1) & 1);
     e->device = device_id;
     auto bail = [&](int rc) { pocr_destroy(e); return rc; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
@@ -1213,6 +1241,21 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
             continue;
         }
         std::vector<float> frag;
+        if (i == 0 && conv_split() == 2) {      // the same weights as f16x2 fragments: [cout/16][plane][lane] x 8 f16, k = 8 (lane >> 4) + j
+            std::vector<uint16_t> w2((size_t)4 * 2 * 64 * 8, 0);
+            for (int sgrp = 0; sgrp < 4; ++sgrp)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 8 * (lane >> 4) + j, co = 16 * sgrp + (lane & 15);
+                        if (k >= 27 || co >= L.cout) continue;
+                        uint16_t pl[2];
+                        split_weight(w[((size_t)co * 3 + k % 3) * 9 + k / 3], 2, pl);
+                        w2[(((size_t)sgrp * 2 + 0) * 64 + lane) * 8 + j] = pl[0];
+                        w2[(((size_t)sgrp * 2 + 1) * 64 + lane) * 8 + j] = pl[1];
+                    }
+            if (e->conv1_w2.reserve(w2.size() * 2)) return bail(1);
+            if (locked_memcpy(e->conv1_w2.p, w2.data(), w2.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return bail(fail("weight upload failed"));
+        }
         if (i == 0) {   // im2col form: one tap, "cin" k = (ky*3+kx)*3 + c, padded 27 -> 32
             frag = build_wfrag(1, 32, cout16, [&](int co, int k, int) { const int tap = k / 3, c = k % 3; return w[((size_t)co * 3 + c) * 9 + tap]; }, 27, L.cout);
         } else {
@@ -1410,7 +1453,7 @@ void pocr_destroy(pocr_engine *e) {
         for (DevBuf *b : {&L.ws_in, &L.bs_in, &L.ws_out, &L.bs_out, &L.wc_q, &L.bc_q, &L.wc_kv, &L.bc_kv, &L.wc_out, &L.bc_out,
                           &L.w1, &L.b1, &L.w2, &L.b2, &L.n1w, &L.n1b, &L.n2w, &L.n2b, &L.n3w, &L.n3b}) b->release();
     e->dec_embed.release();
-    for (DevBuf *b : {&e->sa_nw, &e->sa_nb, &e->pe, &e->bn_scale, &e->bn_shift, &e->agg_w, &e->agg_b, &e->head_w, &e->head_b, &e->lut})
+    for (DevBuf *b : {&e->sa_nw, &e->sa_nb, &e->pe, &e->bn_scale, &e->bn_shift, &e->agg_w, &e->agg_b, &e->head_w, &e->head_b, &e->lut, &e->conv1_w2})
         b->release();
     for (Slot &s : e->slot) {
         for (auto &b : s.act) b.release();
@@ -2473,6 +2516,10 @@ int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t
     const size_t k = cap < sz ? cap : sz;
     if (out && k) {
         HIP_TRY(hipStreamSynchronize(s.seq_stream));
+        if (what == 0 && e->fuse12) {       // conv1's activation does not exist in the fused mode: compute it now, from the crops still staged
+            HIP_TRY(hipStreamSynchronize(s.stream));
+            if (launch_conv1(e, s, s.stream)) return 1;
+        }
         HIP_TRY(hipMemcpyAsync(out, src, k * sizeof(float), hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(hipStreamSynchronize(s.stream));
         if (e->p2 && what >= 0 && what < 9) {
