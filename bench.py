@@ -661,7 +661,7 @@ def main():
         if w_pad is not None:
             traffic = None          # HBM bytes per launch of the dominant kernel, from the committed PMC passes
             pmc_file = {2: "r03_pmc_summary.json", 3: "r02_pmc_summary.json", 0: "pmc_summary.json"}[split]
-            dom_sig = {2: "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false, 2, true, true>",
+            dom_sig = {2: "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false, 2, true, true",
                        3: "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false>", 0: "5, 1, 4, 4, 16, 1, 1, 2, true"}[split]
             try:
                 pmc = json.load(open(os.path.join(REPO, "profiles", pmc_file)))
@@ -703,7 +703,9 @@ def main():
                                        "vs_bf16x3_ceiling_416.7": round(conv_tf / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
                                        "vs_fp32_mfma_peak_157.3": round(conv_tf / F32_MFMA_PEAK_TFLOPS, 4),
                                        "gflop_per_line": round(sum(fl.values()) / 1e9, 3), "ms_per_step": round(conv_ms, 3),
-                                       "note": "conv1 (K = 27) stays on its fused uint8 -> fp32-MFMA kernel" if split else ""}
+                                       "note": ("conv1 (uint8 crops -> 64 channels, K = 27: one f16x2 product block) is computed inside conv2's prologue for the "
+                                                "workgroup's own halo tile: its FLOPs (counted once, not per halo overlap) and its time are conv2's" if split == 2 else
+                                                "conv1 (K = 27) stays on its fused uint8 -> fp32-MFMA kernel" if split else "")}
             if spec.arch == netspec.ARCH_SA:
                 E, FF, Tn = spec.conv_out, spec.sa_ff, (w_pad // 2) // 2
                 enc_fl = spec.sa_layers * (2.0 * Tn * (4 * E * E + 2 * E * FF) + 4.0 * Tn * Tn * E) + 2.0 * Tn * E * spec.num_classes
