@@ -624,6 +624,16 @@ def main():
                                "ms_per_step": round(1e3 * e2e / args.steps, 3),
                                "what": "every step packs its crops from host memory (numpy), H2D, launch, collect, strings - "
                                        "PytorchEngineLineOCR's launch loop; no all-gather in this region"}
+        # third region (not part of any rate): the same launch ALONE - one chunk at a time, nothing else on the GPU - for the
+        # per-stage times the kernels have without the other chunk's sequence stage next to them
+        ms_alone = {}
+        eng.set_profiling(True)
+        for _ in range(3):
+            eng.slot_launch(0, want_logits=False)
+            eng.slot_collect(0)
+            for k, v in eng.slot_stage_ms(0).items():
+                ms_alone[k] = ms_alone.get(k, 0.0) + v / 3.0
+        eng.set_profiling(False)
         if args.workload == "c2" and world == 1 and not args.no_extras:
             extra["c2_sparse"] = default_contract_region(engine, eng, crops, n_lines, width, wl, spec, weights, chars, tmp, local_rank)
         lines_per_step = n_lines * world
@@ -716,6 +726,20 @@ def main():
                                              f"{SPLIT_NAME[split]} kernel in GEMM mode (attention, LayerNorm, head: fp32)" if split else
                                              "LayerNorm+PE, encoder layers (QKV / attention / out / FFN) and the head, stage events"}
             result["stage_ms"] = {k: round(v, 4) for k, v in ms.items()}
+            if ms_alone:
+                # the same kernels with the GPU to themselves (one chunk at a time): what the two-chunk overlap costs each stage
+                conv_ms_a = sum(ms_alone[k] for k in fl)
+                result["stage_ms_alone"] = {k: round(v, 4) for k, v in ms_alone.items()}
+                result["roofline"]["alone"] = {"avg_launch_ms": round(ms_alone[dom], 4),
+                                               "achieved": round(fl[dom] * n_lines / (ms_alone[dom] * 1e-3) / 1e12, 2),
+                                               "frac": round(fl[dom] * n_lines / (ms_alone[dom] * 1e-3) / 1e12 / peak, 4)}
+                result["conv_backbone"]["alone"] = {"ms_per_chunk": round(conv_ms_a, 3),
+                                                    "achieved": round(sum(fl.values()) * n_lines / (conv_ms_a * 1e-3) / 1e12, 2),
+                                                    "frac": round(sum(fl.values()) * n_lines / (conv_ms_a * 1e-3) / 1e12 / peak, 4)}
+                if "encoder" in result:
+                    enc_ms_a = ms_alone["lstm"] + ms_alone["head"]
+                    result["encoder"]["alone"] = {"ms_per_chunk": round(enc_ms_a, 3),
+                                                  "achieved": round(result["encoder"]["gflop_per_line"] * 1e9 * n_lines / (enc_ms_a * 1e-3) / 1e12, 2)}
         result.update(extra)
         if args.workload == "c2" and world == 1 and not args.no_extras:
             eng.device_synchronize()
