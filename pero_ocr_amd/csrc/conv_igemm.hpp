@@ -70,12 +70,14 @@ struct FillArgs {
     const int32_t *lvl_w[3];     // line widths at the three pooling levels
     int32_t lvl_out[9], h_out[9], cout[9];
     const FillSeg *segs;
+    int32_t only_layer;          // -1: every layer but `skip_layer` (-1: none); >= 0: that layer alone
+    int32_t skip_layer;
 };
 
 __global__ __launch_bounds__(256) void pad_fill_kernel(FillArgs a) {
     const FillSeg sg = a.segs[blockIdx.x];
     const int l = sg.layer, h = blockIdx.y;
-    if (h >= a.h_out[l]) return;
+    if (h >= a.h_out[l] || l == a.skip_layer || (a.only_layer >= 0 && l != a.only_layer)) return;
     const int W = a.lvl_w[a.lvl_out[l]][sg.line], C4 = a.cout[l] / 4;
     float *dst = a.act[l] + a.out_off[l][sg.line] + ((size_t)h * W + sg.c0) * a.cout[l];
     const float *src = a.cvec[l] + (size_t)h * a.cout[l];

@@ -531,6 +531,23 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(f32x4 *p, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
+int launch_pad_fill(pocr_engine *e, Slot &s, hipStream_t st, int only_layer, int skip_layer) {
+    if (s.g_nfill <= 0) return 0;
+    FillArgs fa{};
+    int hh = e->cfg.height;
+    for (int i = 0; i < 9; ++i) {
+        hh /= kConvPlan[i].ph;
+        fa.act[i] = s.act[i].as<float>(); fa.cvec[i] = e->cconst[i].as<float>(); fa.out_off[i] = s.g_act_off[i];
+        fa.lvl_out[i] = kConvLvlOut[i]; fa.h_out[i] = hh; fa.cout[i] = kConvPlan[i].cout;
+    }
+    for (int k = 0; k < 3; ++k) fa.lvl_w[k] = s.g_lvl_w[k];
+    fa.segs = s.g_fill;
+    fa.only_layer = only_layer; fa.skip_layer = skip_layer;
+    hipLaunchKernelGGL(pad_fill_kernel, dim3(s.g_nfill, e->cfg.height), dim3(256), 0, st, fa);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // conv1 as its own launch (every mode but the fused default; pocr_debug_read(0) runs it on demand in the fused mode)
 int launch_conv1(pocr_engine *e, Slot &s, hipStream_t st) {
     Conv1Args c1{};
@@ -565,19 +582,9 @@ int run_network(pocr_engine *e, Slot &s) {
     int h = H;
     for (int i = 0; i < 9; ++i)
         if (s.act[i].reserve((size_t)s.act_elems[i] * sizeof(float))) return 1;
-    if (s.g_nfill > 0) {        // constant padding columns of all nine layers in one launch (conv_igemm.hpp: pad_fill_kernel)
-        FillArgs fa{};
-        int hh = H;
-        for (int i = 0; i < 9; ++i) {
-            hh /= kConvPlan[i].ph;
-            fa.act[i] = s.act[i].as<float>(); fa.cvec[i] = e->cconst[i].as<float>(); fa.out_off[i] = s.g_act_off[i];
-            fa.lvl_out[i] = kConvLvlOut[i]; fa.h_out[i] = hh; fa.cout[i] = kConvPlan[i].cout;
-        }
-        for (int k = 0; k < 3; ++k) fa.lvl_w[k] = s.g_lvl_w[k];
-        fa.segs = s.g_fill;
-        hipLaunchKernelGGL(pad_fill_kernel, dim3(s.g_nfill, H), dim3(256), 0, st, fa);
-        HIP_TRY(hipGetLastError());
-    }
+    // constant padding columns of all nine layers in one launch (conv_igemm.hpp: pad_fill_kernel); conv1's activation does not
+    // exist in the fused mode (pocr_debug_read(0) fills and computes it on demand)
+    if (launch_pad_fill(e, s, st, -1, e->fuse12 ? 0 : -1)) return 1;
     for (int i = 0; i < 9; ++i) {
         const ConvLayer &L = kConvPlan[i];
         ConvArgs a{};
@@ -2518,7 +2525,7 @@ int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t
         HIP_TRY(hipStreamSynchronize(s.seq_stream));
         if (what == 0 && e->fuse12) {       // conv1's activation does not exist in the fused mode: compute it now, from the crops still staged
             HIP_TRY(hipStreamSynchronize(s.stream));
-            if (launch_conv1(e, s, s.stream)) return 1;
+            if (launch_pad_fill(e, s, s.stream, 0, -1) || launch_conv1(e, s, s.stream)) return 1;
         }
         HIP_TRY(hipMemcpyAsync(out, src, k * sizeof(float), hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(hipStreamSynchronize(s.stream));
