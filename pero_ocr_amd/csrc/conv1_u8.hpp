@@ -8,6 +8,10 @@
 // v_mfma_f32_16x16x4_f32 straight from that halo: the im2col matrix (K = 27, padded to 32) is never
 // built - MFMA operand k = (ky*3 + kx)*3 + c is just a per-lane constant offset into the halo.
 // Output-bound: 5.9 MB of fp32 NHWC per 40x576 line.
+// F16X2 (the recogniser's default arithmetic): the same contraction as ONE 32-deep f16x2 product block - three
+// v_mfma_f32_16x16x32_f16 with the weights as the A operand (conv_bf16x3.hpp: conv1_mma_f16x2) - and in the default mode this
+// kernel does not run at all: conv2 computes conv1 for its own halo tile (conv3x3_bf16x3_kernel FUSE1); it then serves
+// POCR_NO_FUSE12=1, the non-P2 builds and pocr_debug_read(0).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_igemm.hpp"

@@ -206,7 +206,7 @@ POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true, 2)    // 512->
         return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT, false, MINW, BDIR, KH, 1, 0, 0>, TH,    \
                            16 * MW, NS * (4 / WM) * 16, 256, a, st);                                               \
     }
-// f16x2 with PRE-SPLIT activations (conv_bf16x3.hpp "P2"): the recogniser's conv stack in the default mode.  conv1 writes
+// f16x2 with PRE-SPLIT activations (conv_bf16x3.hpp "P2"): the recogniser's conv stack in the default mode.  conv1 (inside conv2's prologue by default) writes
 // the two-plane layout, conv2 .. conv9 read and write it (stager = 16-byte copies), the aggregation conv reads it and
 // writes fp32 features for the sequence model.
 #define POCR_CONVP(name, TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW, BDIR)                                        \

@@ -42,10 +42,13 @@ def main():
         mode = page % 3
         kw = [dict(), dict(sparse_logits=False), dict(no_logits=True)][mode]
         t, l, c = ctc.process_lines(crops, **kw)
-        key = ("ctc", page % 5, n)
+        key = ("ctc", page % 5, tuple(widths))
         if key in first:
             assert first[key] == t, f"page {page}: CTC transcriptions changed between identical calls"
         first[key] = t
+        if page % 2 == 0:                                         # the same page again, through another output mode
+            t_again, _l, _c = ctc.process_lines(crops, **[dict(), dict(sparse_logits=False), dict(no_logits=True)][(mode + 1) % 3])
+            assert t_again == t, f"page {page}: CTC transcriptions changed between two calls on the same crops"
         if page % 4 == 0:
             few = crops[:24]
             t2, _l, _c = s2s.process_lines(few, **kw)
