@@ -228,6 +228,9 @@ POCR_CONVP(conv8_p2,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true)
 int conv2_p2_fused(ConvArgs a, hipStream_t st) {
     return launch_conv(conv3x3_bf16x3_kernel<10, 1, 1, 1, 2, 2, ACT_RELU, false, 2, true, 3, 3, 1, 1, false, 2, true, true, true>, 10, 16, 64, 256, a, st);
 }
+int conv2_p2_fused8(ConvArgs a, hipStream_t st) {      // 8 x 16 pixels, three workgroups per CU (52 KB of LDS each): POCR_P2_ALT_TILES bit 7
+    return launch_conv(conv3x3_bf16x3_kernel<8, 1, 1, 1, 2, 2, ACT_RELU, false, 3, true, 3, 3, 1, 1, false, 2, true, true, true>, 8, 16, 64, 256, a, st);
+}
 // experiment knob (POCR_P2_ALT_TILES = bit mask over conv2 .. conv7 = bits 1 .. 6): the round-2 tiles
 POCR_CONVP(conv2_p2_alt,  4, 2, 2, 2, 2, 2, ACT_RELU, false, 3, false)
 POCR_CONVP(conv3_p2_alt,  5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
@@ -277,7 +280,7 @@ const int kConvTW[10] = {32, 64, 32, 32, 16, 16, 16, 16, 16, 48};
 const int kConvTW3[10] = {32, 32, 16, 16, 16, 16, 32, 16, 16, 48};
 const int kConvTHP[10] = {4, 10, 10, 10, 10, 10, 10, 5, 5, 1};       // the P2 configurations (POCR_CONVP)
 const int kConvTWP[10] = {32, 16, 16, 16, 16, 16, 16, 16, 16, 48};
-inline int conv_tile_h(bool p2, bool b3, int k) { return p2 ? ((p2_alt_tiles() >> k) & 1 ? kConvTH3[k] : kConvTHP[k]) : b3 ? kConvTH3[k] : kConvTH[k]; }
+inline int conv_tile_h(bool p2, bool b3, int k) { return p2 ? (k == 1 && ((p2_alt_tiles() >> 7) & 1) ? 8 : (p2_alt_tiles() >> k) & 1 ? kConvTH3[k] : kConvTHP[k]) : b3 ? kConvTH3[k] : kConvTH[k]; }
 inline int conv_tile_w(bool p2, bool b3, int k) { return p2 ? ((p2_alt_tiles() >> k) & 1 ? kConvTW3[k] : kConvTWP[k]) : b3 ? kConvTW3[k] : kConvTW[k]; }
 // input width level of each conv (0: W_pad, 1: W_pad/2, 2: (W_pad/2)/2) and of its output
 const int kConvLvlIn[10] = {0, 0, 1, 1, 2, 2, 2, 2, 2, 2};
@@ -609,7 +612,7 @@ int run_network(pocr_engine *e, Slot &s) {
                         if (e->fuse12) {
                             a.f1_crops = s.crops_ext ? s.crops_ext : s.crops.as<uint8_t>(); a.f1_lines = s.lines.as<LineDesc>();
                             a.f1_lut = e->lut.as<float>(); a.f1_w = e->conv1_w2.p; a.f1_bias = e->conv_b[0].as<float>(); a.f1_src_h = 0;
-                            rc = conv2_p2_fused(a, st);
+                            rc = (p2_alt_tiles() >> 7) & 1 ? conv2_p2_fused8(a, st) : conv2_p2_fused(a, st);
                         } else {
                             rc = (p2_alt_tiles() >> 1) & 1 ? conv2_p2_alt(a, st) : conv2_p2(a, st);
                         }
