@@ -992,6 +992,49 @@ def test_presplit_activations_are_bit_identical(monkeypatch):
             assert np.all(np.abs(x - y) <= 2.0 ** -21 * np.abs(y) + 1e-9), f"conv{k + 1}: P2 read-back is not the fp32 value to 2^-21"
 
 
+@pytest.mark.parametrize("height", [40, 32, 64])
+def test_conv1_fused_into_conv2_is_bit_identical(monkeypatch, height):
+    """Default mode: conv2's workgroups compute conv1 for their own halo tile straight into LDS (conv_bf16x3.hpp FUSE1) and
+    conv1's activation never exists.  The same engine with conv1 as its own launch (POCR_NO_FUSE12=1) must give bit-identical
+    activations of every layer (conv1's is computed on demand by pocr_debug_read in the fused mode), logits and labels - on
+    ragged rows with empty / 1-pixel / maximum-width crops, with and without padding-column skipping, and for line heights
+    that are not a multiple of the 10-row tile (32: tiles of 10 + 10 + 10 + 2 rows)."""
+    if _native.conv_split() != 2:
+        pytest.skip("the fused prologue belongs to the f16x2 arithmetic")
+    chars = synth.make_charset(50)
+    spec = netspec.NetSpec(num_classes=len(chars) + 1, height=height)
+    weights = netspec.pack_weights(spec, netspec.generate_weights(spec, 81))
+    widths = [300, 0, 1, 17, 640, 96, 33, 511, 64, 1000, 200, 5, 3840]
+    crops = synth.make_crops(12, widths, height)
+    pool = np.concatenate([c.reshape(-1) for c in crops])
+    offs = np.concatenate([[0], np.cumsum([c.size for c in crops])[:-1]]).astype(np.int64)
+    cases = [([-(-max(w, 1) // 32) * 32 + 64 for w in widths], 32), ([3904] * len(widths), 32),
+             ([1100, 1088, 1090, 2047, 1088, 1153, 1088, 1088, 1301, 1088, 1088, 1088, 4000], 100)]
+
+    def run(fused, skip):
+        for name, on in (("POCR_NO_FUSE12", not fused), ("POCR_NO_PAD_SKIP", not skip)):
+            if on:
+                monkeypatch.setenv(name, "1")
+            else:
+                monkeypatch.delenv(name, raising=False)
+        eng = _native.NativeEngine(spec, weights, 0)
+        out = []
+        for w_pads, pad_left in cases:
+            eng.slot_stage_ragged(0, pool, offs, np.array(widths, np.int32), w_pads, pad_left)
+            eng.slot_launch(0, want_logits=True, want_argmax=True)
+            logits, amax, labels, lens = eng.slot_collect(0)
+            out.append([eng.debug_read(k) for k in range(10)] + [logits, amax, labels, lens])
+        eng.close()
+        return out
+
+    ref = run(False, True)
+    for fused, skip in ((True, True), (True, False)):
+        got = run(fused, skip)
+        for ca, cb in zip(got, ref):
+            for k, (x, y) in enumerate(zip(ca, cb)):
+                assert x.shape == y.shape and np.array_equal(x, y), f"output {k} differs (fused {fused}, padding skip {skip})"
+
+
 def test_layer_rescaling_leaves_the_logits_alone():
     """Size-independent property: scaling one conv layer (weights and bias) by 2^-k and the next layer's weights by 2^k
     leaves the network's function unchanged (ReLU is positively homogeneous; powers of two are exact in fp32).  With
