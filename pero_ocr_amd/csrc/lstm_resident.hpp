@@ -157,6 +157,24 @@ __global__ __launch_bounds__(256) void lstm_resident_kernel(LstmResidentArgs a) 
 #else
 #define POCR_TICK(k) do { } while (0)
 #endif
+    unsigned *pend = nullptr;                                  // sync word of the slice whose last state store is not yet published
+    auto bump = [&](unsigned *sy) {                            // (everybody's stores are acknowledged and a barrier has been passed)
+        if (tid == 0) {
+            if (fast) {
+                __hip_atomic_fetch_add(sy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // executed in this XCD's L2
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(sy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    auto publish_pending = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's state store is acknowledged by L2
+        __syncthreads();                                       // ... and everybody's
+        bump(pend);
+        pend = nullptr;
+    };
     for (int s = 0; s < Tmax; ++s) {
 #pragma unroll
         for (int j = 0; j < SL; ++j) {
@@ -170,6 +188,9 @@ __global__ __launch_bounds__(256) void lstm_resident_kernel(LstmResidentArgs a) 
             const bool live = s < Ti[j];
             const int t = dir == 0 ? s : Ti[j] - 1 - s;
             const size_t row = row0[j] + (size_t)(live ? t : 0);
+            // ---- a publication of THIS slice still pending (SL = 1, or the other slices of the group have finished): complete it now
+            if (pend == sync) { publish_pending(); }
+            if (s == 0) __syncthreads();                       // (`part`: the previous slice's gate reads)
             // ---- wait for h_{s-1} of the whole slice
             if (s > 0) {
                 if (tid == 0) {
@@ -193,14 +214,12 @@ __global__ __launch_bounds__(256) void lstm_resident_kernel(LstmResidentArgs a) 
             for (int g = 0; g < 4; ++g) xcur[g] = xg[j][g];
             if (s > 0 && f16) {
                 lstm_gemm_f16x2<KPW, true>(hc + (size_t)(s & 1) * 16 * H + (size_t)li * H, wave, kq, w2, acc);
-                load_x(j, s + 1);
             } else if (s > 0) {
                 const float *hrow = hc + (size_t)(s & 1) * 16 * H + (size_t)li * H;
                 f32x4 av[KPW];
 #pragma unroll
                 for (int q = 0; q < KPW; ++q)                 // nt loads bypass the L1 (a plain load could return what this CU read two steps ago)
                     av[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(hrow + (wave + 4 * q) * 16 + kq * 4));
-                load_x(j, s + 1);                             // behind the h loads in the (in-order) return queue
 #pragma unroll
                 for (int q = 0; q < KPW; ++q)
 #pragma unroll
@@ -208,14 +227,18 @@ __global__ __launch_bounds__(256) void lstm_resident_kernel(LstmResidentArgs a) 
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
                             acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][jj], bv[q][g][jj], acc[g], 0, 0, 0);
-            } else {
-                load_x(j, s + 1);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<f32x4 *>(&part[((wave * 4 + g) * 64 + lane) * 4]) = acc[g];
             POCR_TICK(1);                                      // h loads + MFMAs
+            // The previous slice-step's state store is published HERE, one slice-step late: its L2 acknowledgement has had this
+            // step's wait + GEMM to arrive, and the barrier that orders everybody's acknowledgement is the one the LDS reduction
+            // needs anyway (before: acknowledgement + a barrier of its own behind every store, 400-2000 cycles of a ~5 k slice-step)
+            if (pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (pend) { bump(pend); pend = nullptr; }
+            load_x(j, s + 1);                                  // x of this slice's next step: due at this slice's next turn
             POCR_TICK(2);                                      // barrier
             float gate[4];
 #pragma unroll
@@ -235,25 +258,12 @@ __global__ __launch_bounds__(256) void lstm_resident_kernel(LstmResidentArgs a) 
             POCR_TICK(3);                                      // gates
             if (s + 1 < Ts[j]) {
                 hc[(size_t)((s + 1) & 1) * 16 * H + (size_t)i * H + unit] = hn;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's state store is acknowledged by L2
-                POCR_TICK(4);                                  // store acknowledged (and the prefetched x landed)
-                __syncthreads();                                    // ... and everybody's; `part` may be overwritten again
-                POCR_TICK(5);
-                if (tid == 0) {
-                    if (fast) {
-                        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // executed in this XCD's L2
-                    } else {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            } else {
-                __syncthreads();
+                pend = sync;                                   // published behind the next slice-step's GEMM (above)
             }
             if (live) a.y[row * (2 * H) + (size_t)dir * H + unit] = hn;      // (after the hand-off: nobody waits for this store)
         }
     }
+    if (pend) publish_pending();
 #if POCR_LSTM_RES_DBG
     if (b == 0 && tid == 0)
         for (int q = 0; q < 6; ++q) reinterpret_cast<unsigned long long *>(a.err + 8)[q] = tph[q];
