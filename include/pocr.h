@@ -366,6 +366,9 @@ int pocr_set_profiling(pocr_engine *e, int32_t enabled);
  *       9 = aggregation features [n, T, E];
  *       BLSTM: 10+l = BiLSTM layer l output [n, T, 2*hidden];
  *       SA / S2S: 10 = LayerNorm + positional encoding [n, T, E], 11+l = encoder layer l output [n, T, E].
+ * In the default (f16x2) mode conv1 runs inside conv2's prologue and its activation is not kept: what = 0 computes it on
+ * demand from the crops still staged in the slot (same arithmetic, same bits); conv activations kept in the two-plane f16
+ * layout are converted to the fp32 values they stand for.
  * Writes min(cap, size) floats, stores the full size in *n_floats. */
 int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t *n_floats);
 
