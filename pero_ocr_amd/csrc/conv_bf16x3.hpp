@@ -42,6 +42,9 @@
 #ifndef POCR_GEMM_PIPE
 #define POCR_GEMM_PIPE 1               // 1x1 (GEMM mode) f16x2 layers with LDS weights: double-buffered A and B tiles, one barrier per 32-deep chunk
 #endif
+#ifndef POCR_BDIR_APRE
+#define POCR_BDIR_APRE 1               // tap-by-tap direct-weights loop, f16x2, MS <= 4: A fragments read one tap ahead
+#endif
 #ifndef POCR_STA_TAP
 #define POCR_STA_TAP (NTAP / 2)        // tap after which the next chunk's halo tile (requested at tap 0) is written to the other LDS buffer
 #endif
@@ -579,7 +582,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     // three chunks): the set of step s + 2 is requested while step s computes - two steps (~2000 cycles) cover an L2
     // miss, one does not
     constexpr int NSETS = POCR_BDIR_SETS, AHEAD = NSETS - 1;
+    constexpr bool APRE = SPL == 2 && MS <= 4 && POCR_BDIR_APRE && POCR_BF16X3_DBG == 0;
     u32x4 bw[NSETS][NS][SPL];
+    u32x4 apre[APRE ? 2 : 1][APRE ? MS : 1][2];
     auto ldW = [&](u32x4 (&dst)[NS][SPL], const u32x4 *tile) {
 #pragma unroll
         for (int n = 0; n < NS; ++n)
@@ -624,6 +629,20 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                 const u32x4 *Ab = ldsA + abuf * A_U + dy * HW + dx + li + kq * NPPAD + wm * MWW * 16;
 #endif
                 u32x4 (&bc)[NS][SPL] = bw[sl % NSETS];
+                // f16x2, few row strips (the aggregation conv: 18 MFMAs per step): the A fragments of tap t + 1 are read while tap t
+                // multiplies (within a chunk: the other A buffer is only valid behind the chunk's barrier)
+                if constexpr (APRE) {
+                    if (tap == 0) {
+#pragma unroll
+                        for (int m = 0; m < MS; ++m) { const int o = (m / MWW) * HW + (m % MWW) * 16; apre[0][m][0] = Ab[o]; apre[0][m][1] = Ab[o + PS]; }
+                    }
+                    if (tap + 1 < NTAP) {
+                        const int dy1 = tap_w(tap + 1) / KW, dx1 = tap_w(tap + 1) % KW;
+                        const u32x4 *An = ldsA + abuf * A_U + dy1 * HW + dx1 + li + kq * NPPAD + wm * MWW * 16;
+#pragma unroll
+                        for (int m = 0; m < MS; ++m) { const int o = (m / MWW) * HW + (m % MWW) * 16; apre[(tap + 1) & 1][m][0] = An[o]; apre[(tap + 1) & 1][m][1] = An[o + PS]; }
+                    }
+                }
 #pragma unroll
                 for (int m = 0; m < MS; ++m) {
                     const int o = (m / MWW) * HW + (m % MWW) * 16;
@@ -632,7 +651,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                         const u32x4 ah = bc[0][0] ^ (unsigned)m, al = bc[0][1] ^ (unsigned)m;
                         (void)o; (void)Ab;
 #else
-                        const u32x4 ah = Ab[o], al = Ab[o + PS];
+                        const u32x4 ah = APRE ? apre[tap & 1][m][0] : Ab[o], al = APRE ? apre[tap & 1][m][1] : Ab[o + PS];
 #endif
 #pragma unroll
                         for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(al, bc[n][0], acc2[m][n]);
