@@ -1,0 +1,290 @@
+// gemm_f16x2.hpp — the GEMM-shaped layers (LSTM input projections, encoder linears, the aggregation conv) on the f16 matrix
+// pipe in the f16x2 arithmetic of conv_bf16x3.hpp (fp32 operands as two f16 planes, three MFMAs per 32-deep product block),
+// as a PERSISTENT kernel whose operands are copied HBM/L2 -> LDS by the load unit itself (global_load_lds_dwordx4).
+//
+// Replaces (same arithmetic, same accumulation order, bit-identical results) conv3x3_bf16x3_kernel's GEMM mode for
+//   torch.nn.LSTM's W_ih x + b for all frames at once, nn.TransformerEncoderLayer's linears (transformer.py:366-385) and the
+//   (H/8) x 1 aggregation conv (transformer.py:351-355) - the layers whose K is one tap deep, where that kernel's main loop
+//   sat at 37 % MFMA issue (profiles/r03_gemm_pipe.txt: a barrier per 48 MFMAs, operands staged through registers by
+//   ds_write_b128, 27 % of a K = 512 tile's life in prologue and epilogue).
+//
+// Operands.  A: activations in the P2 layout ([row][K/32][32 x f16 h | 32 x f16 l], written by the producer's epilogue):
+//   a row's 32-channel chunk is one 128-byte line.  B: weights in fragment order wsplit[K/32][N/16][plane][lane][8 x f16]
+//   (build_wsplit): the (chunk, 16-column tile, plane) piece is 1 KB in exactly the order the MFMA's B operand lanes read it.
+// Tile: 256 rows x 128 columns per workgroup, 8 waves as 4 (rows) x 2 (columns): a wave owns 64 x 64 = 4 x 4 MFMA tiles x
+//   (main, cross) accumulators = 128 registers; two waves per SIMD cover each other's LDS reads and barrier waits.
+// Stage = one 32-deep chunk = 32 KB of A + 16 KB of B, three stage buffers (144 KB LDS, one workgroup per CU); every wave
+//   issues 6 LDS-DMA pieces of 1 KB per stage, two stages ahead of the MFMAs that use them; ONE raw s_barrier per stage, the
+//   DMA queue is never drained (s_waitcnt vmcnt(N) with N = pieces of the next stage [+ the epilogue's stores]).
+//   A image in LDS: row-major [256][128 B] with the 16-byte unit index XOR-ed by (row >> 1) & 7 - applied to the SOURCE address of
+//   the DMA (the LDS side of a DMA is lane-linear), so a wave instruction still reads 8 whole 128-byte lines, and the MFMA A
+//   fragment (ds_read_b128: 16 rows x one unit per 16-lane group) touches every bank once.  B image: the fragments themselves.
+// Persistent: the grid is one workgroup per CU; a workgroup walks its tiles as ONE flat stream of stages, so the DMA of the
+//   next tile's first stages is in flight while the current tile's epilogue converts and stores (302 MB of fp32 for the c2
+//   projection: the stores of one tile drain under the next tile's main loop instead of idling the matrix pipe).
+// Tile order: XCD x (blocks b % 8 == x, observed placement; a speed matter only) owns the row tiles x, x + 8, ...; its 32
+//   workgroups take consecutive (row tile, column tile) pairs, so the 16 column tiles of a row tile run at the same time on the
+//   XCD whose L2 holds that A tile, and the weights (4 MB for 512 x 2048) stay L2-resident.
+// GATHER (aggregation conv): row m of the GEMM is frame t of line i, K chunk kc = tap * cpt + c lies at
+//   in_off[i] + ((tap * W_i + t) * cin + 32 c) * 4 bytes of the conv activation: only the DMA source addresses change.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "conv_igemm.hpp"
+#include "conv_bf16x3.hpp"
+
+namespace pocr {
+
+struct GemmP2Args {
+    const void *a;            // P2 activations
+    const void *w;            // wsplit [nk][N16][2][64][8 x f16]
+    const float *bias;        // [N16 * 16]
+    void *y;                  // fp32 [M][ldy] or P2 with the same pixel pitch (ldy * 4 bytes)
+    int32_t M, nk, N16, n_valid, ldy;
+    int64_t lda;              // bytes between rows of `a` (plain GEMM; >= nk * 128)
+    int32_t mt_total, nt_total;          // 256-row / 128-column tiles
+    int32_t nb;                          // column tiles per XCD block (divides nt_total; nt_total / nb divides 8)
+    // GATHER
+    const int32_t *row_line, *row_t, *line_w;
+    const int64_t *in_off;    // element (float) offsets of the lines in `a`
+    int32_t cpt, ntap, cin;   // chunks per tap, taps, input channels: stage p = (chunk p / ntap, tap p % ntap) - the K order of conv3x3_bf16x3_kernel's tap loops
+    unsigned *range_flag;     // [2]: bit patterns of max |y| (atomicMax) - the f16x2 range guard; NULL = off
+};
+
+#ifndef POCR_GEMM_DBG
+#define POCR_GEMM_DBG 0              // tools/gemm_bench.hip ablations (results wrong, time only): 1 no DMA in the loop, 2 no fragment reads, 4 no MFMAs
+#endif
+constexpr int kGemmBM = 256, kGemmBN = 128, kGemmThreads = 512;
+constexpr int kGemmStageU = 3072;                 // 16-byte units per stage: 2048 of A, 1024 of B
+constexpr int kGemmBiasMax = 3072;                // bias columns kept in LDS (an ordinary global load inside the stream would drain the DMA queue)
+constexpr int kGemmLdsU = 3 * kGemmStageU + kGemmBiasMax / 4;
+
+#ifndef POCR_GEMM_A_AUX
+#define POCR_GEMM_A_AUX 2            // cache policy of the A pieces: 2 = nt (streamed: the weights, re-read by every row tile, keep their place in L2), 0 = default
+#endif
+#define POCR_GLDS16(gptr, lptr, aux) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), \
+                                                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, aux)
+
+template <int ACT, bool P2OUT, bool GATHER>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args a) {
+    __shared__ u32x4 lds[kGemmLdsU];                  // ONE object: a second __shared__ array makes hipcc drain the DMA queue before every ds_read
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int wm = wave & 3, wn = wave >> 2;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    // XCD x works on the column tiles of group x % NG (nb tiles: their weights stay in its L2) and on the row tiles
+    // (x / NG), (x / NG) + MG, ...; NG = 1: every XCD sees every column tile
+    const int NG = a.nt_total / a.nb, MG = 8 / NG, ngroup = xcd % NG, mgroup = xcd / NG;
+    const int cnt_m = (a.mt_total - mgroup + MG - 1) / MG;
+    const int q_total = cnt_m * a.nb;
+    const int iters = slot < q_total ? (q_total - slot + per_xcd - 1) / per_xcd : 0;
+    if (iters == 0) return;
+    const int nk = a.nk, total = iters * nk;
+
+    {   // bias -> LDS (plain loads, before any DMA is in flight)
+        float *bl = reinterpret_cast<float *>(lds + 3 * kGemmStageU);
+        for (int c = tid; c < a.N16 * 16 && c < kGemmBiasMax; c += kGemmThreads) bl[c] = a.bias[c];
+    }
+
+    // ---- DMA source addresses of this thread's pieces: A piece j covers rows (j * 8 + wave) * 8 + (lane >> 3), slot lane & 7
+    const char *abase = static_cast<const char *>(a.a);
+    const char *wbase = static_cast<const char *>(a.w);
+    const char *arow[4];
+    size_t atap[GATHER ? 4 : 1];
+    int p_it = 0, p_k = 0, p_tap = 0, p_c = 0;        // (tile iteration, stage) of the next stage to request; GATHER: its (tap, chunk)
+    const char *wcol = nullptr;
+    auto tile_of = [&](int it, int &m0, int &n16) {
+        const int q = slot + it * per_xcd;
+        m0 = ((q / a.nb) * MG + mgroup) * kGemmBM;
+        n16 = (ngroup * a.nb + q % a.nb) * (kGemmBN / 16);
+    };
+    auto tile_addr = [&](int it) {
+        int m0, n16;
+        tile_of(it, m0, n16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (j * 8 + wave) * 8 + (lane >> 3);
+            const int m = min(m0 + r, a.M - 1);       // rows past the end: a valid row again, never stored
+            const int u = (lane & 7) ^ ((r >> 1) & 7);
+            if constexpr (GATHER) {
+                const int line = a.row_line[m], t = a.row_t[m], W = a.line_w[line];
+                arow[j] = abase + ((size_t)a.in_off[line] + (size_t)t * a.cin) * 4 + u * 16;
+                atap[j] = (size_t)W * a.cin * 4;
+            } else {
+                arow[j] = abase + (size_t)m * a.lda + u * 16;
+            }
+        }
+        wcol = wbase + (size_t)n16 * 2048 + (size_t)wave * 1024 + lane * 16;
+    };
+    auto issue = [&](int buf) {                       // request stage (p_it, p_k) into buffer `buf`, advance
+        u32x4 *dst = lds + buf * kGemmStageU;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const char *src;
+            if constexpr (GATHER) src = arow[j] + p_tap * atap[j] + (size_t)p_c * 128;
+            else src = arow[j] + (size_t)p_k * 128;
+            POCR_GLDS16(src, dst + (j * 8 + wave) * 64, POCR_GEMM_A_AUX);
+        }
+        const char *wsrc = wcol + (size_t)(GATHER ? p_tap * a.cpt + p_c : p_k) * a.N16 * 2048;
+        if constexpr (GATHER) { if (++p_tap == a.ntap) { p_tap = 0; ++p_c; } }
+        POCR_GLDS16(wsrc, dst + 2048 + wave * 64, 0);                    // (tile, plane) pieces wave and wave + 8
+        POCR_GLDS16(wsrc + 8 * 1024, dst + 2048 + (8 + wave) * 64, 0);
+        if (++p_k == nk) {
+            p_k = 0; p_tap = 0; p_c = 0;
+            if (p_it + 1 < iters) { ++p_it; tile_addr(p_it); }
+            else { p_k = nk - 1; p_tap = a.ntap - 1; p_c = a.cpt - 1; }     // past the end: the last stage again (read, never used) - the DMA count per stage stays constant
+        }
+    };
+
+    f32x4 acc[4][4], acc2[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    // fragment read addresses (16-byte units inside a stage): A row wm * 64 + mt * 16 + li, unit (plane * 4 + kq) ^ swz(li)
+    const int sw = (li >> 1) & 7;
+    const int a_h = (wm * 64 + li) * 8 + (kq ^ sw), a_l = (wm * 64 + li) * 8 + ((4 + kq) ^ sw);
+    const int b_u = 2048 + (wn * 4) * 128 + lane;
+
+    tile_addr(0);
+    issue(0);
+    issue(1);
+    int c_it = 0, c_k = 0;
+    bool stores_young = false;                        // the previous stage ended with a full tile's epilogue: NST stores are younger than the pieces to wait for
+    unsigned rmax = 0u;                               // largest |output| as a bit pattern: non-negative floats order like integers, inf / NaN above every finite value
+    constexpr int NST = P2OUT ? 32 : 16;              // store instructions of one epilogue
+
+    // Two wave groups, half a stage apart (waves w and w + 4 share a SIMD): while group A multiplies stage g, group B reads the
+    // fragments of stage g from LDS and requests stage g + 2; then B multiplies and A reads stage g + 1.  Each SIMD's matrix pipe
+    // is fed by one wave at a time, and the other wave's LDS / DMA phase hides behind it (with ONE phase per stage all eight
+    // waves read, wait and multiply in lockstep: 262-296 TF; profiles/r04_gemm_persistent.txt).  A stage has two barriers -
+    // before the read phase and before the multiply phase - and group B passes one more at the start (A at the end), so that
+    // barrier instance 2 g + 1 separates A's read / multiply of stage g and B's multiply of g - 1 / read of g.
+    //   RAW: the pieces of stage g + 1 are retired by their issuers (vmcnt) before the multiply barrier of stage g, i.e. before
+    //        barrier instance 2 g + 1 (A) / 2 g + 2 (B); the first reader of stage g + 1 (A) starts behind instance 2 g + 2.
+    //   WAR: stage g + 2 goes to the buffer of stage g - 1, whose last reads (B's, retired by lgkmcnt(0) before its multiply
+    //        barrier = instance 2 g) precede every request of stage g + 2 (A: behind instance 2 g; B: behind 2 g + 1).
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // stage 0 has landed
+    if (wn == 1) __builtin_amdgcn_s_barrier();
+
+    auto stage = [&](int buf) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#if !(POCR_GEMM_DBG & 1)
+        issue(buf == 0 ? 2 : buf - 1);
+#endif
+        const u32x4 *S = lds + buf * kGemmStageU;
+        u32x4 bh[4], bl[4], ah[4], al[4];
+#if POCR_GEMM_DBG & 2
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { bh[n] = (u32x4){(unsigned)(buf + n), 1u, 2u, (unsigned)lane}; bl[n] = bh[n] ^ 5u; ah[n] = bh[n] ^ 9u; al[n] = bh[n] ^ 17u; }
+        (void)S;
+#else
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { bh[n] = S[b_u + n * 128]; bl[n] = S[b_u + n * 128 + 64]; }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { ah[m] = S[a_h + m * 128]; al[m] = S[a_l + m * 128]; }
+#endif
+        // the pieces of stage g + 1 (all but the 6 just requested - and a full epilogue's stores, which are younger than they)
+#if POCR_GEMM_DBG & 1
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+        if (stores_young) {
+            if constexpr (P2OUT) asm volatile("s_waitcnt vmcnt(38) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        }
+#endif
+        stores_young = false;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#if POCR_GEMM_DBG & 4
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { acc[m][n][0] += __builtin_bit_cast(float, ah[m][0] ^ bh[n][0]); acc2[m][n][0] += __builtin_bit_cast(float, al[m][0] ^ bl[n][0]); }
+#else
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc2[m][n] = POCR_MFMA_F16(al[m], bh[n], acc2[m][n]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = POCR_MFMA_F16(ah[m], bh[n], acc[m][n]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc2[m][n] = POCR_MFMA_F16(ah[m], bl[n], acc2[m][n]);
+        }
+#endif
+        if (++c_k == nk) {
+            // ---- epilogue of tile c_it: + bias, activation, store; the next tile's first two stages are already in flight
+            c_k = 0;
+            int m0, n16;
+            tile_of(c_it, m0, n16);
+            ++c_it;
+            const float *bl_ = reinterpret_cast<const float *>(lds + 3 * kGemmStageU);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int co = (n16 + wn * 4 + n) * 16 + li;
+                const float bias = bl_[min(co, kGemmBiasMax - 1)];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = apply_act(acc[m][n][r] + acc2[m][n][r] * (1.0f / kF16x2Scale) + bias, ACT);
+                        rmax = max(rmax, __builtin_bit_cast(unsigned, v[r]) & 0x7fffffffu);
+                    }
+                    acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    quad_transpose(v, lane);
+                    const int row = m0 + wm * 64 + m * 16 + kq * 4 + (li & 3), c4 = co - (li & 3);
+                    if (row < a.M) {
+                        if constexpr (P2OUT) {
+                            u32x2 hh, ll;
+                            split2_quad((f32x4){v[0], v[1], v[2], v[3]}, hh, ll);
+                            u32x2 *d = reinterpret_cast<u32x2 *>(static_cast<char *>(a.y) + (size_t)row * a.ldy * 4 + p2_channel_bytes(c4));
+                            d[0] = hh; d[8] = ll;
+                        } else {
+                            float *d = static_cast<float *>(a.y) + (size_t)row * a.ldy + c4;
+                            if (c4 + 3 < a.n_valid && (a.ldy & 3) == 0) {
+                                *reinterpret_cast<f32x4 *>(d) = (f32x4){v[0], v[1], v[2], v[3]};
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (c4 + k < a.n_valid) d[k] = v[k];
+                            }
+                        }
+                    }
+                }
+            }
+            // the counted wait assumes exactly NST store instructions per wave: true for tiles that lie inside the matrix and
+            // take the 16-byte path; after any other tile the plain vmcnt(6) also waits for its (older) stores
+            stores_young = m0 + kGemmBM <= a.M && (P2OUT || ((n16 + kGemmBN / 16) * 16 <= a.n_valid && (a.ldy & 3) == 0));
+        }
+    };
+
+    for (int g = 0; g < total; g += 3) {
+        stage(0);
+        if (g + 1 < total) stage(1);
+        if (g + 2 < total) stage(2);
+    }
+    if (wn == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-requested last stages: nothing may land in LDS after the workgroup has gone
+    if (a.range_flag) {
+        // f16x2 range guard (pocr_hip.hip): the largest |output| of this launch, as a bit pattern (non-negative floats order like integers; NaN / inf are largest)
+        unsigned m = rmax;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+        if (lane == 0) atomicMax(a.range_flag, m);
+    }
+    (void)NST;
+}
+
+inline int gemm_f16x2_grid(int M, int N, int n_cus) {
+    const int mt = (M + kGemmBM - 1) / kGemmBM, nt = N / kGemmBN;
+    const long tiles = (long)mt * nt;
+    int g = n_cus / 8 * 8;
+    while (g > 8 && (long)(g - 8) >= tiles) g -= 8;      // fewer tiles than workgroups: shrink in whole XCD rounds
+    return g;
+}
+
+}  // namespace pocr
