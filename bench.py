@@ -531,11 +531,11 @@ def main():
                                      transport=transport if transport is not None else sharding.LocalTransport())
         texts = None
         for _ in range(args.warmup):
-            texts = sh.process_lines(lines)
+            texts = sh.process_lines(lines, no_logits=True)[0]
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            texts = sh.process_lines(lines)
+            texts = sh.process_lines(lines, no_logits=True)[0]
         fence()
         elapsed = time.perf_counter() - t0
         assert texts == meta["transcriptions"], "c3: transcriptions differ from the reference fixture"

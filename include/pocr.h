@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define POCR_ABI_VERSION 10
+#define POCR_ABI_VERSION 11
 #define POCR_NUM_SLOTS 4
 
 typedef struct pocr_engine pocr_engine;
@@ -80,6 +80,13 @@ int pocr_abi_version(void);
  * as two f16 planes, three f16 MFMAs per 32-deep block (default); 3 = three bf16 planes, six MFMAs (POCR_CONV_SPLIT=3);
  * 0 = fp32 MFMA (POCR_CONV_FP32=1).  All three accumulate in fp32 and stay within the fp32 reference's own rounding noise. */
 int pocr_conv_split(void);
+/* f16x2 range guard (ABI 11).  The default arithmetic represents an fp32 operand as two f16 planes: fp32's precision, f16's
+ * range.  Every kernel that produces such an operand records the largest |value| it wrote; a launch in which one reached
+ * 65504 (or was not finite), or in which a whole activation tensor lay below 2^-13, is re-run - same lines, same requests,
+ * transparently, at collect time - on the bf16x3 kernels (fp32's range) of a second engine created on first use.  Replaces
+ * plain fp32 of pero_ocr/ocr_engine/pytorch_ocr_engine.py:61-69.  Returns the number of launches re-run so far.
+ * (The sequence-to-sequence engine returns an error instead; POCR_CONV_SPLIT=3 selects bf16x3 for everything.) */
+int64_t pocr_range_fallbacks(pocr_engine *e);
 /* Number of visible HIP devices (0 when none / no driver). */
 int pocr_device_count(void);
 

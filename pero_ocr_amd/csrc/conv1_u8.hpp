@@ -32,6 +32,7 @@ struct Conv1Args {
     int32_t H, n_ptiles;
     int32_t src_h;               // rows the crops really have (0: = H); rows [src_h, H) are zero padding (layout network pages)
     const void *w1x2;            // F16X2: [cout/16 = 4][plane h, l][lane] x 8 f16: k = 8 (lane >> 4) + j, cout = 16 s + (lane & 15), zero for k >= 27
+    unsigned *range_max;         // f16x2 range guard (conv_igemm.hpp: range_publish) or NULL
 };
 
 // P2OUT: the output is written in the pre-split f16x2 layout conv2 stages by plain copies (conv_bf16x3.hpp, "P2").
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
     __syncthreads();
     const float bias = a.bias[wave * 16 + li];
     float *yimg = a.y + a.out_off[img];
+    unsigned rmax = 0u;                               // f16x2 range guard (conv_igemm.hpp)
 #pragma unroll
     for (int th = 0; th < TH; ++th) {
 #pragma unroll
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
                 if (ho >= a.H || wc >= Wp) continue;
                 f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float t = d[r] + bias4[r]; v[r] = t > 0.f ? t : 0.f; }
+                for (int r = 0; r < 4; ++r) { const float t = d[r] + bias4[r]; v[r] = t > 0.f ? t : 0.f; range_note(rmax, v[r]); }
                 if constexpr (P2OUT) {
                     u32x2 hh, ll;
                     split2_quad(v, hh, ll);
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
                     (f32x4){v[0], v[1], v[2], v[3]};
         }
     }
+    if constexpr (F16X2) range_publish(a.range_max, rmax, lane);
 }
 
 }  // namespace pocr

@@ -458,6 +458,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         if (tid < 4) patch[F1_N + tid] = 0.f;
         int koff8[8];
         conv1_koff(koff8, kq, F1_PW);
+        unsigned f1max = 0u;                            // range guard of conv1's activation (never stored in this mode)
         __syncthreads();
         // the waves share the pixel tiles (16 halo pixels each), every wave computes all 64 channels of its tiles
 #pragma unroll
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                 const f32x4 d = conv1_mma_f16x2(xh, xl, xwh[nt1], xwl[nt1]);
                 f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float t = d[r] + bias1[nt1][r]; v[r] = (inside && t > 0.f) ? t : 0.f; }
+                for (int r = 0; r < 4; ++r) { const float t = d[r] + bias1[nt1][r]; v[r] = (inside && t > 0.f) ? t : 0.f; range_note(f1max, v[r]); }
                 u32x2 hh, ll;
                 split2_quad(v, hh, ll);
                 // channels 16 nt1 + 4 kq .. + 3: chunk nt1 >> 1, octet 2 (nt1 & 1) + (kq >> 1), half kq & 1
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                 dst[2 * PS] = ll;
             }
         }
+        range_publish(a.f1_range, f1max, lane);
     } else {
         stA(0);
     }
@@ -771,6 +773,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         }
     // ---- epilogue (identical to conv_igemm_kernel: same D layout)
     const int Wo = Win, Wout = Wo / POOLW;
+    unsigned rmax = 0u;                                 // f16x2 range guard (conv_igemm.hpp: range_note)
 #pragma unroll
     for (int n = 0; n < NS; ++n) {
         const int co = (nt * (NT / 16) + wn * NS + n) * 16 + li;
@@ -793,6 +796,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                         t = fmaxf(t, u);
                     }
                     v[r] = t;
+                    if constexpr (SPL == 2) range_note(rmax, t);
                 }
                 const int ho = (h0 + th) / POOLH;
                 const int wbase = w0 + (wm * MWW + mw) * 16 + kq * 4;
@@ -847,6 +851,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             }
         }
     }
+    if constexpr (SPL == 2) range_publish(a.range_max, rmax, lane);
 #ifdef POCR_BF16X3_TRACE
     POCR_TRACE_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -123,6 +123,10 @@ struct ConvArgs {
     const void *f1_w;        // conv1 weights as f16x2 fragments (Conv1Args::w1x2)
     const float *f1_bias;
     int32_t f1_src_h;
+    // f16x2 range guard (conv_bf16x3.hpp): [8] words, one per XCD-ish bucket (blockIdx & 7) - the bit pattern of the largest
+    // |output| of this launch; NULL = off.  The host decides at collect time whether the launch left f16's range.
+    unsigned *range_max;
+    unsigned *f1_range;      // the same for conv1's activation when conv2 computes it in its prologue (FUSE1)
 };
 
 // number of workgroups for a conv launch (must match the block -> tile mapping in the kernel)
@@ -152,6 +156,22 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], int lane) {
         const float r0 = __shfl_xor(s0, 2, 64), r1 = __shfl_xor(s1, 2, 64);
         if (b1) { v[0] = r0; v[1] = r1; } else { v[2] = r0; v[3] = r1; }
     }
+}
+
+// ---- f16x2 range guard.  The two-plane f16 form of a value (conv_bf16x3.hpp) has fp32's precision only while the tensor it
+// belongs to stays inside f16's range: h = f16(x) is inf from |x| >= 65520 on, and l = f16((x - h) 2^11) is a subnormal
+// (absolute resolution 2^-35) once the whole tensor lies below ~2^-13.  Every kernel that produces an activation an f16x2
+// kernel will consume records the largest |value| it wrote (bit patterns of non-negative floats order like integers; inf and
+// NaN sort above every finite value); pocr_slot_collect reads the words and re-runs a launch that left the range on the
+// bf16x3 kernels (fp32's range) - pocr_hip.hip: range_verdict / fallback.
+__device__ __forceinline__ void range_note(unsigned &m, float v) { m = max(m, __builtin_bit_cast(unsigned, v) & 0x7fffffffu); }
+__device__ __forceinline__ void range_publish(unsigned *words, unsigned m, int lane) {
+    if (!words) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    unsigned *w = words + (blockIdx.x & 7);
+    // one L2 read per wave; the atomic only while this wave still raises the maximum (a handful per launch)
+    if (lane == 0 && m > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, m);
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_igemm.hpp"
+#include "conv_bf16x3.hpp"
 
 namespace pocr {
 
@@ -23,7 +24,9 @@ namespace pocr {
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *a, const float *b, const float *gamma,
                                                         const float *beta, const float *pe, float *y, int rows,
                                                         int E, int T, float eps, const int32_t *row_t,
-                                                        const int32_t *stop) {
+                                                        const int32_t *stop, void *y_p2 = nullptr, unsigned *range_max = nullptr) {
+    // y_p2: a second copy of the output in the P2 (pre-split f16x2) layout - the input of the next projection GEMM
+    // (gemm_f16x2.hpp); the fp32 copy stays the residual of the next LayerNorm
     const int go = stop ? *stop : 1;            // decoder steps enqueued past the end of the last batch (decoder.hpp);
                                                 // tested after the row has been requested
     const int lane = threadIdx.x & 63;
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *a, const fl
     // frame index of this row inside its line: row_t[row] for ragged batches, row % T for uniform ones
     const float *ppe = pe ? pe + (size_t)(row_t ? row_t[row] : row % T) * E : nullptr;
     float *py = y + (size_t)row * E;
+    unsigned rmax = 0u;                         // f16x2 range guard of the P2 copy (conv_igemm.hpp)
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
         const int e = lane + 64 * k;
@@ -66,14 +70,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *a, const fl
             float o = (v[k] - mean) * rstd * gamma[e] + beta[e];
             if (ppe) o += ppe[e];
             py[e] = o;
+            range_note(rmax, o);
+            if (y_p2) {
+                _Float16 h, l;
+                split2_scalar(o, h, l);
+                _Float16 *d = reinterpret_cast<_Float16 *>(static_cast<char *>(y_p2) + (size_t)row * E * 4 + p2_channel_bytes(e));
+                d[0] = h; d[32] = l;
+            }
         }
     }
+    range_publish(range_max, rmax, lane);
 }
 
 // qkv [n][T][3E] (q | k | v, head h = columns h*D .. h*D+D-1 of each part) -> out [n][T][E]
-template <int D>
+// P2OUT: the output in the P2 layout (it only feeds the output projection GEMM)
+template <int D, bool P2OUT = false>
 __global__ __launch_bounds__(64) void attention_kernel(const float *qkv, float *out, int T_uniform, int E, float scale,
-                                                       const int32_t *line_T, const int32_t *row_off) {
+                                                       const int32_t *line_T, const int32_t *row_off, unsigned *range_max = nullptr) {
     static_assert(D % 16 == 0 && D <= 128, "head dim must be a multiple of 16");
     constexpr int DG = D / 16;
     const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
@@ -141,12 +154,29 @@ __global__ __launch_bounds__(64) void attention_kernel(const float *qkv, float *
         }
     }
     // ---- O^T[d = 16*dt + 4g + r][q = li] / l  ->  out[line][q0 + li][head*D + 16*dt + 4g + 0..3]
+    unsigned rmax = 0u;                     // f16x2 range guard of the P2 output (conv_igemm.hpp)
     if (q0 + li < T) {
         const float inv = 1.0f / l_run;
         float *op = out + (row0 + q0 + li) * E + head * D + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < DG; ++dt) *reinterpret_cast<f32x4 *>(op + 16 * dt) = o[dt] * inv;
+        for (int dt = 0; dt < DG; ++dt) {
+            if constexpr (P2OUT) {
+                u32x2 hh, ll;
+                const f32x4 ov = o[dt] * inv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float t = ov[r]; range_note(rmax, t); }
+                split2_quad(ov, hh, ll);
+                u32x2 *d = reinterpret_cast<u32x2 *>(reinterpret_cast<char *>(out) + (row0 + q0 + li) * (size_t)E * 4 + p2_channel_bytes(head * D + 16 * dt + 4 * g));
+                d[0] = hh; d[8] = ll;
+            } else {
+                const f32x4 ov = o[dt] * inv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float t = ov[r]; range_note(rmax, t); }
+                *reinterpret_cast<f32x4 *>(op + 16 * dt) = ov;
+            }
+        }
     }
+    range_publish(range_max, rmax, lane);
 }
 
 }  // namespace pocr

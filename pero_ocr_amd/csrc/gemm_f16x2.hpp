@@ -30,6 +30,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "conv_igemm.hpp"
 #include "conv_bf16x3.hpp"
 
@@ -48,7 +49,7 @@ struct GemmP2Args {
     const int32_t *row_line, *row_t, *line_w;
     const int64_t *in_off;    // element (float) offsets of the lines in `a`
     int32_t cpt, ntap, cin;   // chunks per tap, taps, input channels: stage p = (chunk p / ntap, tap p % ntap) - the K order of conv3x3_bf16x3_kernel's tap loops
-    unsigned *range_flag;     // [2]: bit patterns of max |y| (atomicMax) - the f16x2 range guard; NULL = off
+    unsigned *range_flag;     // [8]: the f16x2 range guard (conv_igemm.hpp: range_publish); NULL = off
 };
 
 #ifndef POCR_GEMM_DBG
@@ -68,7 +69,8 @@ constexpr int kGemmLdsU = 3 * kGemmStageU + kGemmBiasMax / 4;
 template <int ACT, bool P2OUT, bool GATHER>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args a) {
     __shared__ u32x4 lds[kGemmLdsU];                  // ONE object: a second __shared__ array makes hipcc drain the DMA queue before every ds_read
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform by construction: keeps the LDS-DMA bases (M0) and the tile bookkeeping in SGPRs
     const int wm = wave & 3, wn = wave >> 2;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     // XCD x works on the column tiles of group x % NG (nb tiles: their weights stay in its L2) and on the row tiles
@@ -92,12 +94,12 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
     size_t atap[GATHER ? 4 : 1];
     int p_it = 0, p_k = 0, p_tap = 0, p_c = 0;        // (tile iteration, stage) of the next stage to request; GATHER: its (tap, chunk)
     const char *wcol = nullptr;
-    auto tile_of = [&](int it, int &m0, int &n16) {
+    auto tile_of = [&](int it, int &m0, int &n16) __attribute__((always_inline)) {
         const int q = slot + it * per_xcd;
         m0 = ((q / a.nb) * MG + mgroup) * kGemmBM;
         n16 = (ngroup * a.nb + q % a.nb) * (kGemmBN / 16);
     };
-    auto tile_addr = [&](int it) {
+    auto tile_addr = [&](int it) __attribute__((always_inline)) {
         int m0, n16;
         tile_of(it, m0, n16);
 #pragma unroll
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
         }
         wcol = wbase + (size_t)n16 * 2048 + (size_t)wave * 1024 + lane * 16;
     };
-    auto issue = [&](int buf) {                       // request stage (p_it, p_k) into buffer `buf`, advance
+    auto issue = [&](int buf) __attribute__((always_inline)) {                       // request stage (p_it, p_k) into buffer `buf`, advance
         u32x4 *dst = lds + buf * kGemmStageU;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -167,12 +169,69 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // stage 0 has landed
     if (wn == 1) __builtin_amdgcn_s_barrier();
 
-    auto stage = [&](int buf) {
+    // The epilogue of a tile (+ bias, activation, store) runs at the START of the next stage's memory phase - while the
+    // other wave group multiplies - not behind the tile's last MFMAs, where the other group would wait at the barrier for it.
+    // The WEIGHTS are the MFMA's A operand and the activations its B operand (same products, same sums: the bits of
+    // conv3x3_bf16x3_kernel), so a lane ends up with four consecutive COLUMNS 4 kq + r of ONE row li of each 16 x 16 tile:
+    // one 16-byte store per tile and lane, no transpose (the quad transpose of the first version cost four cross-lane
+    // shuffles per tile: ~9 k cycles per wave and tile, exposed twice).
+    auto epilogue = [&]() __attribute__((always_inline)) -> bool {
+        int m0, n16;
+        tile_of(c_it, m0, n16);
+        ++c_it;
+        const float *bl_ = reinterpret_cast<const float *>(lds + 3 * kGemmStageU);
+        // a tile inside the matrix whose columns are all stored with 16-byte stores: straight-line code, exactly NST store
+        // instructions per wave (what the counted vmcnt wait of the stage assumes); any other tile: per-lane guards, and the
+        // plain vmcnt(6) of the stage also waits for its (older) stores
+        const bool full = m0 + kGemmBM <= a.M && (n16 + kGemmBN / 16) * 16 <= a.n_valid && (P2OUT || (a.ldy & 3) == 0);
+        char *yrow = static_cast<char *>(a.y) + (size_t)(m0 + wm * 64 + li) * a.ldy * 4;
+        auto body = [&](auto fullc) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(fullc)::value;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int c4 = (n16 + wn * 4 + n) * 16 + kq * 4;
+                const f32x4 bias = *reinterpret_cast<const f32x4 *>(bl_ + min(c4, kGemmBiasMax - 4));
+                char *ycol = yrow + (P2OUT ? p2_channel_bytes(c4) : (size_t)c4 * 4);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float vr = apply_act(acc[m][n][r] + acc2[m][n][r] * (1.0f / kF16x2Scale) + bias[r], ACT);
+                        v[r] = vr;
+                        rmax = max(rmax, __builtin_bit_cast(unsigned, vr) & 0x7fffffffu);
+                    }
+                    acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    char *d = ycol + (size_t)m * 16 * a.ldy * 4;
+                    if (FULL || m0 + wm * 64 + m * 16 + li < a.M) {
+                        if constexpr (P2OUT) {
+                            if (FULL || c4 < a.n_valid) {       // (n_valid % 32 == 0: a quad of columns is valid or not as a whole)
+                                u32x2 hh, ll;
+                                split2_quad(v, hh, ll);
+                                reinterpret_cast<u32x2 *>(d)[0] = hh; reinterpret_cast<u32x2 *>(d)[8] = ll;
+                            }
+                        } else if (FULL || (c4 + 3 < a.n_valid && (a.ldy & 3) == 0)) {
+                            *reinterpret_cast<f32x4 *>(d) = v;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (c4 + k < a.n_valid) reinterpret_cast<float *>(d)[k] = v[k];
+                        }
+                    }
+                }
+            }
+        };
+        if (full) body(std::true_type{});
+        else body(std::false_type{});
+        return full;
+    };
+    bool pending = false;                             // the tile whose last stage was just multiplied still has its epilogue to run
+
+    auto stage = [&](int buf) __attribute__((always_inline)) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-#if !(POCR_GEMM_DBG & 1)
-        issue(buf == 0 ? 2 : buf - 1);
-#endif
+        if (pending) { stores_young = epilogue(); pending = false; }
+        // fragment reads first, the six DMA requests behind them (in the shadow of the reads' latency)
         const u32x4 *S = lds + buf * kGemmStageU;
         u32x4 bh[4], bl[4], ah[4], al[4];
 #if POCR_GEMM_DBG & 2
@@ -185,7 +244,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
 #pragma unroll
         for (int m = 0; m < 4; ++m) { ah[m] = S[a_h + m * 128]; al[m] = S[a_l + m * 128]; }
 #endif
-        // the pieces of stage g + 1 (all but the 6 just requested - and a full epilogue's stores, which are younger than they)
+#if !(POCR_GEMM_DBG & 1)
+        issue(buf == 0 ? 2 : buf - 1);
+#endif
+        // the pieces of stage g + 1: all but the 6 just requested - and, behind a full tile's epilogue, its NST stores, which
+        // are younger than the pieces of stage g + 1 and older than those of g + 2 (so the NEXT stage's wait covers them)
 #if POCR_GEMM_DBG & 1
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #else
@@ -208,58 +271,14 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc2[m][n] = POCR_MFMA_F16(al[m], bh[n], acc2[m][n]);
+            for (int n = 0; n < 4; ++n) acc2[m][n] = POCR_MFMA_F16(bh[n], al[m], acc2[m][n]);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = POCR_MFMA_F16(ah[m], bh[n], acc[m][n]);
+            for (int n = 0; n < 4; ++n) acc[m][n] = POCR_MFMA_F16(bh[n], ah[m], acc[m][n]);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc2[m][n] = POCR_MFMA_F16(ah[m], bl[n], acc2[m][n]);
+            for (int n = 0; n < 4; ++n) acc2[m][n] = POCR_MFMA_F16(bl[n], ah[m], acc2[m][n]);
         }
 #endif
-        if (++c_k == nk) {
-            // ---- epilogue of tile c_it: + bias, activation, store; the next tile's first two stages are already in flight
-            c_k = 0;
-            int m0, n16;
-            tile_of(c_it, m0, n16);
-            ++c_it;
-            const float *bl_ = reinterpret_cast<const float *>(lds + 3 * kGemmStageU);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int co = (n16 + wn * 4 + n) * 16 + li;
-                const float bias = bl_[min(co, kGemmBiasMax - 1)];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = apply_act(acc[m][n][r] + acc2[m][n][r] * (1.0f / kF16x2Scale) + bias, ACT);
-                        rmax = max(rmax, __builtin_bit_cast(unsigned, v[r]) & 0x7fffffffu);
-                    }
-                    acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    quad_transpose(v, lane);
-                    const int row = m0 + wm * 64 + m * 16 + kq * 4 + (li & 3), c4 = co - (li & 3);
-                    if (row < a.M) {
-                        if constexpr (P2OUT) {
-                            u32x2 hh, ll;
-                            split2_quad((f32x4){v[0], v[1], v[2], v[3]}, hh, ll);
-                            u32x2 *d = reinterpret_cast<u32x2 *>(static_cast<char *>(a.y) + (size_t)row * a.ldy * 4 + p2_channel_bytes(c4));
-                            d[0] = hh; d[8] = ll;
-                        } else {
-                            float *d = static_cast<float *>(a.y) + (size_t)row * a.ldy + c4;
-                            if (c4 + 3 < a.n_valid && (a.ldy & 3) == 0) {
-                                *reinterpret_cast<f32x4 *>(d) = (f32x4){v[0], v[1], v[2], v[3]};
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k)
-                                    if (c4 + k < a.n_valid) d[k] = v[k];
-                            }
-                        }
-                    }
-                }
-            }
-            // the counted wait assumes exactly NST store instructions per wave: true for tiles that lie inside the matrix and
-            // take the 16-byte path; after any other tile the plain vmcnt(6) also waits for its (older) stores
-            stores_young = m0 + kGemmBM <= a.M && (P2OUT || ((n16 + kGemmBN / 16) * 16 <= a.n_valid && (a.ldy & 3) == 0));
-        }
+        if (++c_k == nk) { c_k = 0; pending = true; }
     };
 
     for (int g = 0; g < total; g += 3) {
@@ -268,14 +287,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
         if (g + 2 < total) stage(2);
     }
     if (wn == 0) __builtin_amdgcn_s_barrier();
+    if (pending) (void)epilogue();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-requested last stages: nothing may land in LDS after the workgroup has gone
-    if (a.range_flag) {
-        // f16x2 range guard (pocr_hip.hip): the largest |output| of this launch, as a bit pattern (non-negative floats order like integers; NaN / inf are largest)
-        unsigned m = rmax;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-        if (lane == 0) atomicMax(a.range_flag, m);
-    }
+    range_publish(a.range_flag, rmax, lane);
     (void)NST;
 }
 

@@ -40,6 +40,7 @@ struct LstmStepArgs {
     const int32_t *row_off;
     const int32_t *slice_T;
     int32_t n, npad, T, H, step;
+    int32_t y_p2;           // the layer output in the P2 (pre-split f16x2) layout: it only feeds the next layer's input projection (gemm_f16x2.hpp)
 };
 
 // Gate non-linearities on the hardware transcendentals (v_exp_f32, v_rcp_f32: ~1 ulp each): absolute error ~1e-7, the
@@ -115,6 +116,18 @@ __device__ __forceinline__ void lstm_gemm_f16x2(const float *hrow, int wave, int
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = main_[g] + cross[g] * (1.0f / kF16x2Scale);
+}
+
+// layer output y[row][2H]: fp32, or split once here into the two f16 planes the next projection's MFMAs read (P2, conv_bf16x3.hpp)
+__device__ __forceinline__ void lstm_store_y(float *y, size_t row, int H2, int col, float hn, bool p2) {
+    if (p2) {
+        _Float16 h, l;
+        split2_scalar(hn, h, l);
+        _Float16 *d = reinterpret_cast<_Float16 *>(reinterpret_cast<char *>(y) + row * (size_t)H2 * 4 + p2_channel_bytes(col));
+        d[0] = h; d[32] = l;
+    } else {
+        y[row * (size_t)H2 + col] = hn;
+    }
 }
 
 // KPW > 0: H == 64 * KPW, fully unrolled.  KPW == 0: generic H (multiple of 16).
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
         lstm_cell(gate, xg, cprev, cn, hn);
         a.c[sidx] = cn;
         a.h_out[sidx] = hn;
-        a.y[row * (2 * H) + (size_t)dir * H + unit] = hn;
+        lstm_store_y(a.y, row, 2 * H, dir * H + unit, hn, a.y_p2 != 0);
     } else {
         a.h_out[sidx] = 0.f;    // padding rows of the last slice and finished lines: value is never used
     }

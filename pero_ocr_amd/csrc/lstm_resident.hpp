@@ -52,6 +52,7 @@ struct LstmResidentArgs {
     int32_t spin_limit;      // polls before a wait gives up
     int32_t force_agent;     // test hook (POCR_LSTM_FORCE_AGENT=1): take the cross-XCD protocol even when the cluster shares an XCD
     unsigned *xcc_census;    // test hook: [grid] XCC_ID + 1 of every block, or NULL
+    int32_t y_p2;            // layer output in the P2 layout (as LstmStepArgs)
 };
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void lstm_resident_kernel(LstmResidentArgs a) 
                 hc[(size_t)((s + 1) & 1) * 16 * H + (size_t)i * H + unit] = hn;
                 pend = sync;                                   // published behind the next slice-step's GEMM (above)
             }
-            if (live) a.y[row * (2 * H) + (size_t)dir * H + unit] = hn;      // (after the hand-off: nobody waits for this store)
+            if (live) lstm_store_y(a.y, row, 2 * H, dir * H + unit, hn, a.y_p2 != 0);      // (after the hand-off: nobody waits for this store)
         }
     }
     if (pend) publish_pending();

@@ -20,6 +20,7 @@
 #include "conv_igemm.hpp"
 #include "conv1_u8.hpp"
 #include "conv_bf16x3.hpp"
+#include "gemm_f16x2.hpp"
 #include "ctc.hpp"
 #include "encoder.hpp"
 #include "decoder.hpp"
@@ -101,6 +102,9 @@ const ConvLayer kConvPlan[9] = {
     {256, 256, ACT_RELU, 2, 1}, {256, 512, ACT_LEAKY, 1, 1}, {512, 512, ACT_LEAKY, 1, 1},
 };
 const float kBnEps = 1e-5f;
+// f16x2 range guard: sets of 8 words (conv_igemm.hpp: range_publish).  Sets 0..8 = the activations of conv1..conv9, 9 = the
+// aggregated features, 10 = everything else an f16x2 GEMM consumes (LayerNorm / attention / feed-forward outputs).
+constexpr int kRangeSets = 16, kRangeWords = kRangeSets * 8, kRangeOther = 10;
 
 // fragment-order weights: wfrag[tap][cin/16][cout16][lane][j]
 //   = W(cout = 16*s + (lane & 15), cin = 16*g + 4*(lane >> 4) + j, tap), zero outside the valid range.
@@ -168,7 +172,16 @@ const int kConvNT[9] = {64, 64, 128, 128, 128, 128, 128, 256, 256};
 // Operand split of the split-precision kernels, process-wide (weights are laid out for it at creation): 2 = f16x2 (two f16
 // planes, THREE MFMAs per 32-deep product block: ceiling 2500 / 3 = 833 TFLOP/s of algorithmic fp32 FLOPs; the default),
 // 3 = bf16x3 (three bf16 planes, six MFMAs: 416.7; POCR_CONV_SPLIT=3), 0 = fp32 MFMA kernels (POCR_CONV_FP32=1: 157.3).
+// The fall-back engine of the f16x2 range guard (below: run_fallback) is a second engine of the same process that runs on
+// bf16x3: the calls made on its behalf set this thread-local override.
+thread_local int g_split_tls = -1;
+struct SplitScope {
+    int prev;
+    explicit SplitScope(int v) : prev(g_split_tls) { g_split_tls = v; }
+    ~SplitScope() { g_split_tls = prev; }
+};
 int conv_split() {
+    if (g_split_tls >= 0) return g_split_tls;
     static const int mode = [] {
         if (const char *env = getenv("POCR_CONV_FP32")) if (atoi(env) != 0) return 0;
         if (const char *env = getenv("POCR_CONV_SPLIT")) return atoi(env) == 3 ? 3 : 2;
@@ -357,6 +370,7 @@ struct Slot {
     const int32_t *g_row_off = nullptr;    // [n+1] first frame (row) of line i in the sequence tensors
     const int32_t *g_slice_T = nullptr;    // [npad/16] longest line of each 16-line slice
     const int32_t *g_row_t = nullptr;      // [rows] frame index of every row inside its line
+    const int32_t *g_row_line = nullptr;   // [rows] line of every row (the aggregation conv as a gathered GEMM, gemm_f16x2.hpp)
     const PixelTile *g_tiles[10]{};
     int g_ntiles[10]{};
     const FillSeg *g_fill = nullptr; // constant padding columns written by pad_fill_kernel instead of being convolved
@@ -367,6 +381,15 @@ struct Slot {
     DevBuf act[9], feat, xproj, hbuf, cbuf, logits, best, labels, lens;
     std::vector<DevBuf> lstm_y, sa_y;
     DevBuf sa_x, sa_x1, sa_qkv, sa_att, sa_tmp, sa_ff;
+    // f16x2 range guard: [kRangeSets][8] words, the largest |value| every producer of an f16x2 operand wrote in this launch
+    DevBuf range;
+    unsigned *range_host = nullptr;    // pinned copy, read at collect time
+    bool guard_checked = false, redirect = false;      // redirect: this launch was re-run on the fall-back engine; its results live in shadow->slot[k]
+    std::vector<int64_t> st_off;       // what was staged (per line): crop offset, width, padded width, left padding - the fall-back engine stages the same lines
+    std::vector<int32_t> st_w, st_wpad, st_padl, sp_rows_host;
+    bool feat_is_p2 = false;           // this launch's aggregated features are stored in the P2 layout (pocr_debug_read converts)
+    int lstm_p2_layers = 0;            // this launch's BiLSTM layers 0 .. lstm_p2_layers - 1 wrote their output in the P2 layout
+    DevBuf sa_xp2, sa_x1p2, feat_p2;   // P2 (pre-split) copies that feed the persistent GEMM (gemm_f16x2.hpp): LayerNorm outputs; the style-embedded features
     int act_h[9]{}, act_w[9]{}, act_c[9]{};
     // host pinned staging for the outputs
     void *pinned = nullptr;
@@ -453,6 +476,12 @@ struct pocr_engine {
     bool warned_nonfinite = false, warned_placement = false;
     bool fuse12 = false;             // conv1 inside conv2's prologue (P2 only; POCR_NO_FUSE12=1: conv1 as its own launch, its activation in HBM)
     DevBuf conv1_w2;                 // conv1's weights as f16x2 fragments (Conv1Args::w1x2)
+    pocr_engine *shadow = nullptr;   // f16x2 range guard: the same network on bf16x3 (fp32's range), created when a launch first leaves f16's range
+    std::vector<float> weights_host; // the weight blob (kept for the fall-back engine; f16x2 engines only)
+    int64_t range_fallbacks = 0;     // launches re-run on the fall-back engine
+    bool is_shadow = false;
+    int n_cus = 256;                 // compute units (grid of the persistent GEMM)
+    bool gemm2 = false;              // GEMM-shaped layers on the persistent 256 x 128 kernel with P2 inputs (gemm_f16x2.hpp; needs p2; POCR_NO_GEMM2=1: conv3x3_bf16x3_kernel's GEMM mode on fp32 activations)
     bool p2 = false;                 // f16x2 with pre-split activations between conv1 and the aggregation conv (conv_bf16x3.hpp "P2"; POCR_NO_P2=1: split in every consumer)
     bool bf16x3 = true;              // conv2..conv9 on the bf16 matrix pipe with the exact 3-way operand split (POCR_CONV_FP32=1: fp32 MFMA)
     DevBuf cconst[9];                // per conv layer: the output column [H_out][cout] far inside zero padding
@@ -552,8 +581,9 @@ int launch_pad_fill(pocr_engine *e, Slot &s, hipStream_t st, int only_layer, int
 }
 
 // conv1 as its own launch (every mode but the fused default; pocr_debug_read(0) runs it on demand in the fused mode)
-int launch_conv1(pocr_engine *e, Slot &s, hipStream_t st) {
+int launch_conv1(pocr_engine *e, Slot &s, hipStream_t st, unsigned *range = nullptr) {
     Conv1Args c1{};
+    c1.range_max = range;
     c1.crops = s.crops_ext ? s.crops_ext : s.crops.as<uint8_t>(); c1.lines = s.lines.as<LineDesc>(); c1.lut = e->lut.as<float>();
     c1.wfrag = e->conv_w[0].as<float>(); c1.bias = e->conv_b[0].as<float>(); c1.y = s.act[0].as<float>();
     c1.w1x2 = e->conv1_w2.p;
@@ -565,6 +595,28 @@ int launch_conv1(pocr_engine *e, Slot &s, hipStream_t st) {
         else if (x2) hipLaunchKernelGGL((conv1_u8_kernel<false, true>), dim3(c1.n_ptiles), dim3(256), 0, st, c1);
         else hipLaunchKernelGGL((conv1_u8_kernel<false, false>), dim3(c1.n_ptiles), dim3(256), 0, st, c1);
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The persistent P2-input GEMM (gemm_f16x2.hpp) for a [rows][cin] x [cin][cout] product whose weights are f16x2 wsplit fragments
+// with cout16 groups of 16 columns.  `can_gemm2` tells whether the shape fits (else: conv3x3_bf16x3_kernel's GEMM mode).
+inline bool can_gemm2(const pocr_engine *e, int cin, int cout16, int nk, int cout_valid, bool p2out) {
+    return e->gemm2 && cin % 32 == 0 && cout16 % (kGemmBN / 16) == 0 && cout16 * 16 <= kGemmBiasMax && nk >= 3 &&
+           (!p2out || cout_valid % 32 == 0);
+}
+inline void gemm2_shape(const pocr_engine *e, GemmP2Args &g, int rows, int cout16) {
+    g.mt_total = (rows + kGemmBM - 1) / kGemmBM;
+    g.nt_total = cout16 * 16 / kGemmBN;
+    // column tiles per XCD block: every XCD sees every column tile (measured: 2 / 4 / 8-tile groups change nothing, profiles/r04_gemm_dma_xcd_map.txt)
+    g.nb = g.nt_total;
+    (void)e;
+}
+template <int ACT, bool P2OUT, bool GATHER>
+int launch_gemm2(const pocr_engine *e, GemmP2Args g, hipStream_t st) {
+    if (g.M <= 0) return 0;
+    const int grid = gemm_f16x2_grid(g.M, g.N16 * 16, e->n_cus);
+    hipLaunchKernelGGL((gemm_f16x2_kernel<ACT, P2OUT, GATHER>), dim3(grid), dim3(kGemmThreads), 0, st, g);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -585,6 +637,17 @@ int run_network(pocr_engine *e, Slot &s) {
     int h = H;
     for (int i = 0; i < 9; ++i)
         if (s.act[i].reserve((size_t)s.act_elems[i] * sizeof(float))) return 1;
+    // f16x2 range guard: the words of this launch start at zero
+    const bool guard = conv_split() == 2;
+    if (guard) {
+        if (!s.range.p) {
+            if (s.range.reserve(kRangeWords * sizeof(unsigned))) return 1;
+            HIP_TRY(locked_host_malloc(reinterpret_cast<void **>(&s.range_host), kRangeWords * sizeof(unsigned), hipHostMallocDefault));
+        }
+        HIP_TRY(hipMemsetAsync(s.range.p, 0, kRangeWords * sizeof(unsigned), st));
+    }
+    s.guard_checked = !guard; s.redirect = false;
+    auto rset = [&](int k) -> unsigned * { return guard ? s.range.as<unsigned>() + 8 * k : nullptr; };
     // constant padding columns of all nine layers in one launch (conv_igemm.hpp: pad_fill_kernel); conv1's activation does not
     // exist in the fused mode (pocr_debug_read(0) fills and computes it on demand)
     if (launch_pad_fill(e, s, st, -1, e->fuse12 ? 0 : -1)) return 1;
@@ -599,10 +662,11 @@ int run_network(pocr_engine *e, Slot &s) {
         a.cout16 = e->conv_cout16[i]; a.cout_valid = L.cout; a.out_stride = L.cout;
         a.wfrag = e->conv_w[i].as<float>(); a.bias = e->conv_b[i].as<float>();
         a.y = s.act[i].as<float>();
+        a.range_max = rset(i); a.f1_range = rset(0);
         mark(i);
         int rc = 0;
         if (i == 0) {
-            if (!e->fuse12) rc = launch_conv1(e, s, st);
+            if (!e->fuse12) rc = launch_conv1(e, s, st, rset(0));
         } else {
             a.x = s.act[i - 1].as<float>(); a.cin = L.cin;
             if (i == 8) { a.bn_scale = e->bn_scale.as<float>(); a.bn_shift = e->bn_shift.as<float>(); }
@@ -659,9 +723,21 @@ int run_network(pocr_engine *e, Slot &s) {
         a.line_w = s.g_lvl_w[2]; a.in_off = s.g_act_off[8]; a.out_off = s.g_feat_off;
         a.cout16 = e->agg_cout16; a.cout_valid = E; a.out_stride = E;
         a.wfrag = e->agg_w.as<float>(); a.bias = e->agg_b.as<float>(); a.y = s.feat.as<float>();
+        a.range_max = rset(9);
         mark(POCR_STAGE_AGG);
         int rc;
-        if (e->p2) rc = AH == 4 ? agg4_p2(a, st) : AH == 5 ? agg5_p2(a, st) : AH == 6 ? agg6_p2(a, st) : agg8_p2(a, st);
+        // the features feed a projection GEMM directly (BiLSTM, no style embedding): written in the P2 layout, once
+        s.feat_is_p2 = false;
+        if (e->p2 && can_gemm2(e, 512, e->agg_cout16, AH * 16, E, false)) {
+            GemmP2Args g{};
+            g.a = s.act[8].p; g.w = e->agg_w.p; g.bias = e->agg_b.as<float>(); g.y = s.feat.p;
+            g.M = rows; g.nk = AH * 16; g.N16 = e->agg_cout16; g.n_valid = E; g.ldy = E;
+            gemm2_shape(e, g, rows, e->agg_cout16);
+            g.row_line = s.g_row_line; g.row_t = s.g_row_t; g.line_w = s.g_lvl_w[2]; g.in_off = s.g_act_off[8];
+            g.cpt = 16; g.ntap = AH; g.cin = 512; g.range_flag = rset(9);
+            s.feat_is_p2 = c.arch == POCR_ARCH_BLSTM && c.embed_num == 0 && E % 32 == 0 && can_gemm2(e, E, e->proj_cout16, E / 32, 8 * c.lstm_hidden, false);
+            rc = s.feat_is_p2 ? launch_gemm2<ACT_LEAKY, true, true>(e, g, st) : launch_gemm2<ACT_LEAKY, false, true>(e, g, st);
+        } else if (e->p2) rc = AH == 4 ? agg4_p2(a, st) : AH == 5 ? agg5_p2(a, st) : AH == 6 ? agg6_p2(a, st) : agg8_p2(a, st);
         else if (e->b3_weights.count(e->agg_w.p)) rc = AH == 4 ? agg4_b3(a, st) : AH == 5 ? agg5_b3(a, st) : AH == 6 ? agg6_b3(a, st) : agg8_b3(a, st);
         else rc = AH == 4 ? agg4_k(a, st) : AH == 5 ? agg5_k(a, st) : AH == 6 ? agg6_k(a, st) : agg8_k(a, st);
         if (rc) return rc;
@@ -702,36 +778,58 @@ int run_network(pocr_engine *e, Slot &s) {
         if (upload(e->pe, pe, st)) return 1;
         e->pe_rows = rows_pe;
     }
-    auto ln = [&](const float *a_, const float *b_, const DevBuf &gw, const DevBuf &gb, const float *pe_, float *y_) {
+    // The persistent GEMM (gemm_f16x2.hpp) reads P2 (pre-split) activations: LayerNorm writes a P2 copy next to the fp32
+    // residual, attention and the first feed-forward linear write P2 only (their outputs feed nothing but the next GEMM).
+    const bool g2 = e->gemm2 && E % 32 == 0 && FF % 32 == 0 &&
+                    can_gemm2(e, E, round_up(3 * E, kProjNT) / 16, E / 32, 3 * E, false) && can_gemm2(e, E, round_up(E, kProjNT) / 16, E / 32, E, false) &&
+                    can_gemm2(e, E, round_up(FF, kProjNT) / 16, E / 32, FF, true) && can_gemm2(e, FF, round_up(E, kProjNT) / 16, FF / 32, E, false) &&
+                    e->b3_weights.count(e->sa[0].w_in.p) != 0;
+    if (g2 && (s.sa_xp2.reserve(xe) || s.sa_x1p2.reserve(xe))) return 1;
+    auto ln = [&](const float *a_, const float *b_, const DevBuf &gw, const DevBuf &gb, const float *pe_, float *y_, void *y2_) {
         hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a_, b_, gw.as<float>(), gb.as<float>(),
-                           pe_, y_, rows, E, T, 1e-5f, s.g_row_t, nullptr);
+                           pe_, y_, rows, E, T, 1e-5f, s.g_row_t, (const int32_t *)nullptr, y2_, rset(kRangeOther));
     };
-    auto gemm = [&](const float *x_, int cin_, const DevBuf &w_, const DevBuf &b_, int cout_, float *y_, bool relu) {
+    // x_: fp32 activations (old kernels) or, with g2, their P2 form; p2out: the output in P2 (g2 only)
+    auto gemm = [&](const void *x_, int cin_, const DevBuf &w_, const DevBuf &b_, int cout_, void *y_, bool relu, bool p2in, bool p2out) {
+        if (p2in) {
+            GemmP2Args g{};
+            g.a = x_; g.w = w_.p; g.bias = b_.as<float>(); g.y = y_;
+            g.M = rows; g.nk = cin_ / 32; g.N16 = round_up(cout_, kProjNT) / 16; g.n_valid = cout_; g.ldy = cout_; g.lda = (int64_t)cin_ * 4;
+            gemm2_shape(e, g, rows, g.N16);
+            g.range_flag = rset(kRangeOther);     // (every output: only the feed-forward one feeds another f16x2 GEMM, the others are O(that) anyway)
+            if (p2out) return relu ? launch_gemm2<ACT_RELU, true, false>(e, g, st) : launch_gemm2<ACT_NONE, true, false>(e, g, st);
+            return relu ? launch_gemm2<ACT_RELU, false, false>(e, g, st) : launch_gemm2<ACT_NONE, false, false>(e, g, st);
+        }
         ConvArgs g{};
-        g.x = x_; g.n = 1; g.H = 1; g.W = rows; g.Ho = 1; g.Wo = rows; g.cin = cin_;
+        g.x = static_cast<const float *>(x_); g.n = 1; g.H = 1; g.W = rows; g.Ho = 1; g.Wo = rows; g.cin = cin_;
         g.cout16 = round_up(cout_, kProjNT) / 16; g.cout_valid = cout_; g.out_stride = cout_;
-        g.wfrag = w_.as<float>(); g.bias = b_.as<float>(); g.y = y_;
+        g.wfrag = w_.as<float>(); g.bias = b_.as<float>(); g.y = static_cast<float *>(y_);
+        g.range_max = rset(kRangeOther);
         if (e->b3_weights.count(w_.p)) return relu ? gemm128_relu_b3(g, st) : gemm128_b3(g, st);
         return relu ? gemm128_relu_k(g, st) : gemm128_k(g, st);
     };
-    ln(s.feat.as<float>(), nullptr, e->sa_nw, e->sa_nb, e->pe.as<float>(), s.sa_x.as<float>());
+    ln(s.feat.as<float>(), nullptr, e->sa_nw, e->sa_nb, e->pe.as<float>(), s.sa_x.as<float>(), g2 ? s.sa_xp2.p : nullptr);
+    const float *xin = s.sa_x.as<float>();             // fp32 input of the layer (residual); with g2 its P2 form is in sa_xp2
     for (int l = 0; l < c.sa_layers; ++l) {
         pocr_engine::SaLayer &L = e->sa[l];
         if (s.sa_y[l].reserve(xe)) return 1;
-        if (gemm(s.sa_x.as<float>(), E, L.w_in, L.b_in, 3 * E, s.sa_qkv.as<float>(), false)) return 1;
+        if (gemm(g2 ? s.sa_xp2.p : (const void *)xin, E, L.w_in, L.b_in, 3 * E, s.sa_qkv.p, false, g2, false)) return 1;
         const dim3 agrid((T + 15) / 16, heads, n);
         const float scale = 1.0f / sqrtf((float)D);
-        if (D == 32) hipLaunchKernelGGL(attention_kernel<32>, agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale, s.g_line_T, s.g_row_off);
-        else if (D == 64) hipLaunchKernelGGL(attention_kernel<64>, agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale, s.g_line_T, s.g_row_off);
-        else hipLaunchKernelGGL(attention_kernel<128>, agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale, s.g_line_T, s.g_row_off);
-        if (gemm(s.sa_att.as<float>(), E, L.w_out, L.b_out, E, s.sa_tmp.as<float>(), false)) return 1;
-        ln(s.sa_x.as<float>(), s.sa_tmp.as<float>(), L.n1w, L.n1b, nullptr, s.sa_x1.as<float>());
-        if (gemm(s.sa_x1.as<float>(), E, L.w1, L.b1, FF, s.sa_ff.as<float>(), true)) return 1;
-        if (gemm(s.sa_ff.as<float>(), FF, L.w2, L.b2, E, s.sa_tmp.as<float>(), false)) return 1;
-        ln(s.sa_x1.as<float>(), s.sa_tmp.as<float>(), L.n2w, L.n2b, nullptr, s.sa_y[l].as<float>());
+#define POCR_ATT(DD)                                                                                                                         \
+        do {                                                                                                                                 \
+            if (g2) hipLaunchKernelGGL((attention_kernel<DD, true>), agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale, s.g_line_T, s.g_row_off, rset(kRangeOther)); \
+            else hipLaunchKernelGGL((attention_kernel<DD, false>), agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale, s.g_line_T, s.g_row_off, rset(kRangeOther)); \
+        } while (0)
+        if (D == 32) POCR_ATT(32); else if (D == 64) POCR_ATT(64); else POCR_ATT(128);
+#undef POCR_ATT
+        if (gemm(s.sa_att.p, E, L.w_out, L.b_out, E, s.sa_tmp.p, false, g2, false)) return 1;
+        ln(xin, s.sa_tmp.as<float>(), L.n1w, L.n1b, nullptr, s.sa_x1.as<float>(), g2 ? s.sa_x1p2.p : nullptr);
+        if (gemm(g2 ? s.sa_x1p2.p : s.sa_x1.p, E, L.w1, L.b1, FF, s.sa_ff.p, true, g2, g2)) return 1;
+        if (gemm(s.sa_ff.p, FF, L.w2, L.b2, E, s.sa_tmp.p, false, g2, false)) return 1;
+        ln(s.sa_x1.as<float>(), s.sa_tmp.as<float>(), L.n2w, L.n2b, nullptr, s.sa_y[l].as<float>(), g2 ? s.sa_xp2.p : nullptr);
         HIP_TRY(hipGetLastError());
-        // the next layer reads sa_x: keep per-layer outputs for the test taps, copy is avoided by swapping roles
-        if (l + 1 < c.sa_layers) HIP_TRY(hipMemcpyAsync(s.sa_x.p, s.sa_y[l].p, xe, hipMemcpyDeviceToDevice, st));
+        xin = s.sa_y[l].as<float>();                    // the next layer's residual input (per-layer outputs stay for the test taps)
     }
     layer_in = s.sa_y[c.sa_layers - 1].as<float>();
     din = E;
@@ -740,9 +838,11 @@ int run_network(pocr_engine *e, Slot &s) {
         // (CustomMultiheadAttention.cached_forward, transformer.py:237-247): [rows][2E] = memory W[E:3E]^T + b[E:3E]
         for (int l = 0; l < c.dec_layers; ++l) {
             if (s.s2s_kv[l].reserve(2 * xe)) return 1;
-            if (gemm(layer_in, E, e->dec[l].wc_kv, e->dec[l].bc_kv, 2 * E, s.s2s_kv[l].as<float>(), false)) return 1;
+            const bool kv2 = g2 && can_gemm2(e, E, round_up(2 * E, kProjNT) / 16, E / 32, 2 * E, false) && e->b3_weights.count(e->dec[l].wc_kv.p) != 0;
+            if (gemm(kv2 ? s.sa_xp2.p : (const void *)layer_in, E, e->dec[l].wc_kv, e->dec[l].bc_kv, 2 * E, s.s2s_kv[l].p, false, kv2, false)) return 1;
         }
         mark(POCR_STAGE_HEAD); mark(POCR_STAGE_CTC); mark(POCR_NUM_STAGES);
+        if (guard) HIP_TRY(hipMemcpyAsync(s.range_host, s.range.p, kRangeWords * sizeof(unsigned), hipMemcpyDeviceToHost, st));
         return 0;
     }
     } else {
@@ -785,6 +885,7 @@ int run_network(pocr_engine *e, Slot &s) {
         la.c = s.cbuf.as<float>(); la.y = s.lstm_y[l].as<float>(); la.dims = dims;
         la.line_T = s.g_line_T; la.row_off = s.g_row_off; la.slice_T = s.g_slice_T;
         la.n = n; la.npad = npad; la.T = T; la.H = Hh; la.step = step;
+        la.y_p2 = l < s.lstm_p2_layers;
         const dim3 grid(Hh / 16, slices, 2);
         switch (Hh) {
             case 64: hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, st, la); break;
@@ -813,12 +914,28 @@ int run_network(pocr_engine *e, Slot &s) {
         }
         memset(s.lstm_err_host, 0, 8 * 4 * sizeof(uint32_t));
     }
+    // Layer outputs that only feed the next layer's input projection are written in the P2 layout (by the recurrence kernels:
+    // lstm_store_y) when that projection runs on the persistent GEMM; the last layer's output feeds the head (fp32 MFMA).
+    const bool proj2 = e->gemm2 && (2 * Hh) % 32 == 0 && can_gemm2(e, 2 * Hh, e->proj_cout16, 2 * Hh / 32, 8 * Hh, false) &&
+                       e->b3_weights.count(e->proj_w[0].p) != 0;
+    s.lstm_p2_layers = proj2 ? c.lstm_layers - 1 : 0;
+    bool in_p2 = s.feat_is_p2;
     for (int l = 0; l < c.lstm_layers; ++l) {
+        const bool y_p2 = l < s.lstm_p2_layers;
+        if (in_p2) {
+            GemmP2Args g{};
+            g.a = layer_in; g.w = e->proj_w[l].p; g.bias = e->proj_b[l].as<float>(); g.y = s.xproj.p;
+            g.M = rows; g.nk = din / 32; g.N16 = e->proj_cout16; g.n_valid = 8 * Hh; g.ldy = 8 * Hh; g.lda = (int64_t)din * 4;
+            gemm2_shape(e, g, rows, e->proj_cout16);
+            if (launch_gemm2<ACT_NONE, false, false>(e, g, st)) return 1;
+        } else {
         ConvArgs a{};
         a.x = layer_in; a.n = 1; a.H = 1; a.W = rows; a.Ho = 1; a.Wo = rows; a.cin = din;
         a.cout16 = e->proj_cout16; a.cout_valid = 8 * Hh; a.out_stride = 8 * Hh;
         a.wfrag = e->proj_w[l].as<float>(); a.bias = e->proj_b[l].as<float>(); a.y = s.xproj.as<float>();
         if (e->b3_weights.count(e->proj_w[l].p) ? gemm128_b3(a, st) : gemm128_k(a, st)) return 1;
+        }
+        in_p2 = y_p2;
         if (resident) {
             // the serial part in ONE launch: clusters of H / 16 workgroups, one per (16-line slice, direction), hand the hidden
             // state from step to step through their XCD's L2 (lstm_resident.hpp)
@@ -830,6 +947,7 @@ int run_network(pocr_engine *e, Slot &s) {
             ra.sync = s.lstm_sync.as<unsigned>(); ra.err = s.lstm_sync.as<unsigned>() + s.lstm_err_off;
             ra.line_T = s.g_line_T; ra.row_off = s.g_row_off; ra.slice_T = s.g_slice_T;
             ra.n = n; ra.npad = npad; ra.T = T; ra.spin_limit = 1 << 22;
+            ra.y_p2 = y_p2;
             static const int force_agent = getenv("POCR_LSTM_FORCE_AGENT") ? atoi(getenv("POCR_LSTM_FORCE_AGENT")) : 0;
             ra.force_agent = force_agent;
             // slices per workgroup: 1 for launches of a few slices (pages of long lines: the chain's latency is what counts),
@@ -940,6 +1058,21 @@ int run_network(pocr_engine *e, Slot &s) {
         HIP_TRY(hipGetLastError());
         mark(POCR_NUM_STAGES);
     }
+    if (guard) HIP_TRY(hipMemcpyAsync(s.range_host, s.range.p, kRangeWords * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+// ---- f16x2 range guard, host side.  0: the launch stayed inside f16's range; 1: some operand reached 65504 (or was not finite);
+// 2: a whole activation tensor lay below 2^-13, where the low plane of the split is subnormal (conv_igemm.hpp: range_note).
+int range_verdict(const Slot &s, int *which = nullptr) {
+    if (!s.range_host) return 0;
+    for (int k = 0; k < kRangeSets; ++k) {
+        unsigned m = 0;
+        for (int j = 0; j < 8; ++j) m = std::max(m, s.range_host[8 * k + j]);
+        if (which) *which = k;
+        if (m >= 0x477fe000u) return 1;                   // 65504.0f and above, inf, NaN
+        if (k <= 9 && m != 0 && m < 0x39000000u) return 2;      // 0 < max < 2^-13
+    }
     return 0;
 }
 
@@ -1029,7 +1162,7 @@ int collect_outputs(pocr_engine *e, Slot &s, float *logits_ntc, int32_t *frame_a
     if (s.nf_host && *s.nf_host && !e->warned_nonfinite) {
         e->warned_nonfinite = true;
         fprintf(stderr, "WARNING: non-finite logits (NaN / inf) in a launch of %d lines - decoded like torch.argmax would (NaN is maximal).%s\n", n,
-                conv_split() == 2 ? "  With the default f16x2 arithmetic an activation or weight beyond 65504 produces them: POCR_CONV_SPLIT=3 (bf16x3) has fp32's range." : "");
+                "");
     }
     const size_t nt_bytes = (size_t)n * T * sizeof(int32_t);
     const char *pin = static_cast<const char *>(s.pinned);
@@ -1206,6 +1339,8 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     if (const char *env = getenv("POCR_LSTM_RESIDENT")) e->lstm_resident = atoi(env) != 0;
     e->p2 = conv_split() == 2 && !(getenv("POCR_NO_P2") && atoi(getenv("POCR_NO_P2")) != 0);
     e->fuse12 = e->p2 && !(getenv("POCR_NO_FUSE12") && atoi(getenv("POCR_NO_FUSE12")) != 0) && !((p2_alt_tiles() >> 1) & 1);
+    e->gemm2 = e->p2 && !(getenv("POCR_NO_GEMM2") && atoi(getenv("POCR_NO_GEMM2")) != 0);
+    e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->device = device_id;
     auto bail = [&](int rc) { pocr_destroy(e); return rc; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
@@ -1441,6 +1576,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     if (g_f16_weight_overflow.exchange(false))
         return bail(fail("a convolution / projection weight lies outside f16's range (|w| > 65504 or not finite): the default f16x2 "
                          "arithmetic cannot represent it - set POCR_CONV_SPLIT=3 (bf16x3, fp32's range)"));
+    if (conv_split() == 2) e->weights_host.assign(weights, weights + n_floats);      // for the fall-back engine of the range guard
     *out = e;
     return 0;
 }
@@ -1451,6 +1587,7 @@ void pocr_destroy(pocr_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)locked_device_sync();
+    if (e->shadow) { pocr_destroy(e->shadow); e->shadow = nullptr; }
     if (e->comm.active()) comm_release(e);
     for (auto &b : e->conv_w) b.release();
     for (auto &b : e->cconst) b.release();
@@ -1476,7 +1613,7 @@ void pocr_destroy(pocr_engine *e) {
         for (auto &ev : s.s2s_ev)
             if (ev) (void)hipEventDestroy(ev);
         for (DevBuf *b : {&s.crops, &s.lines, &s.feat, &s.xproj, &s.hbuf, &s.cbuf, &s.logits, &s.best, &s.labels, &s.lens,
-                          &s.sa_x, &s.sa_x1, &s.sa_qkv, &s.sa_att, &s.sa_tmp, &s.sa_ff, &s.sp_rowstat, &s.sp_colcount,
+                          &s.sa_x, &s.sa_x1, &s.sa_qkv, &s.sa_att, &s.sa_tmp, &s.sa_ff, &s.sa_xp2, &s.sa_x1p2, &s.feat_p2, &s.sp_rowstat, &s.sp_colcount,
                           &s.sp_line_nnz, &s.sp_line_off, &s.sp_indptr, &s.sp_data, &s.sp_indices, &s.sp_rows, &s.sp_conf, &s.geom, &s.seqgeom})
             b->release();
         if (s.pinned) (void)locked_host_free(s.pinned);
@@ -1487,6 +1624,8 @@ void pocr_destroy(pocr_engine *e) {
         if (s.lstm_dims_host) (void)locked_host_free(s.lstm_dims_host);
         s.nf_flag.release();
         if (s.nf_host) (void)locked_host_free(s.nf_host);
+        s.range.release();
+        if (s.range_host) (void)locked_host_free(s.range_host);
         s.lstm_sync.release();
         if (s.lstm_err_host) (void)locked_host_free(s.lstm_err_host);
         if (s.host_in) (void)locked_host_free(s.host_in);
@@ -1606,7 +1745,7 @@ static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n,
         }
     }
     // sequence tensors: rows
-    std::vector<int32_t> row_off(n + 1), slice_T((n + 15) / 16, 0), row_t;
+    std::vector<int32_t> row_off(n + 1), slice_T((n + 15) / 16, 0), row_t, row_line;
     int rows = 0;
     for (int i = 0; i < n; ++i) {
         row_off[i] = rows;
@@ -1615,13 +1754,15 @@ static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n,
     }
     row_off[n] = rows;
     row_t.resize(rows > 0 ? rows : 1);
+    row_line.resize(rows > 0 ? rows : 1);
     for (int i = 0; i < n; ++i)
-        for (int t = 0; t < lvl[2][i]; ++t) row_t[row_off[i] + t] = t;
+        for (int t = 0; t < lvl[2][i]; ++t) { row_t[row_off[i] + t] = t; row_line[row_off[i] + t] = i; }
     for (int i = 0; i <= n; ++i) offs[i] = (int64_t)row_off[i] * E;
     const size_t off_feat = blob.add(offs.data(), (size_t)(n + 1) * sizeof(int64_t));
     const size_t off_row = blob.add(row_off.data(), (size_t)(n + 1) * sizeof(int32_t));
     const size_t off_slice = blob.add(slice_T.data(), slice_T.size() * sizeof(int32_t));
     const size_t off_rowt = blob.add(row_t.data(), row_t.size() * sizeof(int32_t));
+    const size_t off_rowline = blob.add(row_line.data(), row_line.size() * sizeof(int32_t));
     {
         int cap = s.sg_cap > 0 ? s.sg_cap : 64;
         while (cap < n) cap *= 2;
@@ -1649,6 +1790,7 @@ static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n,
     s.g_row_off = s.seqgeom.as<int32_t>() + s.sg_cap;
     s.g_slice_T = s.seqgeom.as<int32_t>() + 2 * s.sg_cap + 16;
     s.g_row_t = reinterpret_cast<const int32_t *>(d + off_rowt);
+    s.g_row_line = reinterpret_cast<const int32_t *>(d + off_rowline);
     s.rows = rows; s.t_max = t_max; s.w_pad = w_max;
     return 0;
 }
@@ -1704,6 +1846,12 @@ static int stage_ragged_impl(pocr_engine *e, int32_t slot, const uint8_t *crops,
     HIP_TRY(hipStreamSynchronize(s.stream));        // geom_host is pageable: finish the copy before it can change
     s.n = n; s.staged = true; s.have_ms = false;
     s.s2s_launched = s.s2s_decoded = false;
+    s.redirect = false; s.guard_checked = true;
+    if (conv_split() == 2 && !e->is_shadow && slot != POCR_NUM_SLOTS) {     // (the fall-back engine stages the same lines: run_fallback)
+        s.st_off.assign(crop_offsets, crop_offsets + n); s.st_w.assign(widths, widths + n); s.st_wpad.assign(w_pads, w_pads + n);
+        s.st_padl.resize(n);
+        for (int i = 0; i < n; ++i) s.st_padl[i] = pad_lefts ? pad_lefts[i] : pad_left;
+    }
     return 0;
 }
 
@@ -1720,6 +1868,61 @@ int pocr_slot_stage_lines(pocr_engine *e, int32_t slot, const uint8_t *crops, co
     std::vector<int32_t> wp(n, w_pad);
     return pocr_slot_stage_ragged(e, slot, crops, crop_offsets, widths, wp.data(), n, pad_left);
 }
+
+// ---- f16x2 range guard: a launch whose operands left f16's range (range_verdict) is run again on bf16x3 - the same lines, the
+// same requests - on a second engine of this process (created on first use from the retained weight blob), and the slot's
+// results are taken from there.  pero_ocr/ocr_engine/pytorch_ocr_engine.py:61-69 computes in plain fp32: no input may give
+// worse than fp32's range here either.
+static int run_fallback(pocr_engine *e, int32_t slot, int verdict, int which) {
+    Slot &s = e->slot[slot];
+    if (e->weights_host.empty()) return fail("internal error: range guard without a retained weight blob");
+    SplitScope scope(3);
+    if (!e->shadow) {
+        fprintf(stderr, "NOTE: a launch left the range of the default f16x2 arithmetic (%s in activation set %d); it and any later such launch "
+                        "are re-run on bf16x3 (fp32's range, ~0.6x the speed).  POCR_CONV_SPLIT=3 selects bf16x3 for everything.\n",
+                verdict == 1 ? "|x| >= 65504 or not finite" : "a whole tensor below 2^-13", which);
+        pocr_engine *sh = nullptr;
+        if (pocr_create(&e->cfg, e->weights_host.data(), e->weights_host.size(), e->device, &sh)) return 1;
+        sh->is_shadow = true;
+        e->shadow = sh;
+    }
+    pocr_engine *sh = e->shadow;
+    if (e->cfg.embed_num > 0 && e->embed_id >= 0 && sh->embed_id != e->embed_id && pocr_set_embed_id(sh, e->embed_id)) return 1;
+    Slot &t = sh->slot[slot];
+    if (t.in_flight && pocr_slot_reset(sh, slot)) return 1;
+    const uint8_t *base = s.crops_ext ? s.crops_ext : s.crops.as<uint8_t>();
+    if (stage_ragged_impl(sh, slot, nullptr, s.st_off.data(), s.st_w.data(), s.st_wpad.data(), s.n, 0, s.st_padl.data(), base)) return 1;
+    t.want_logits = s.want_logits; t.want_argmax = s.want_argmax; t.want_sparse = s.want_sparse;
+    t.sp_thr = s.sp_thr; t.sp_has_rows = s.sp_has_rows;
+    if (s.want_sparse && s.sp_has_rows) {
+        if (t.sp_rows.reserve(s.sp_rows_host.size() * sizeof(int32_t))) return 1;
+        HIP_TRY(locked_memcpy(t.sp_rows.p, s.sp_rows_host.data(), s.sp_rows_host.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    if (run_network(sh, t) || enqueue_outputs(sh, t)) return 1;
+    t.in_flight = true;
+    sh->last_slot = slot;
+    HIP_TRY(hipStreamSynchronize(t.seq_stream));
+    s.redirect = true;
+    ++e->range_fallbacks;
+    return 0;
+}
+
+// every read of a launch's results goes through this: wait for the launch, judge its range words once, fall back if needed
+static int sync_and_guard(pocr_engine *e, int32_t slot) {
+    Slot &s = e->slot[slot];
+    HIP_TRY(hipStreamSynchronize(s.seq_stream));
+    if (s.guard_checked) return 0;
+    s.guard_checked = true;
+    int which = 0;
+    const int verdict = e->is_shadow ? 0 : range_verdict(s, &which);
+    static const bool force = getenv("POCR_FORCE_RANGE_FALLBACK") && atoi(getenv("POCR_FORCE_RANGE_FALLBACK")) != 0;     // tests: every launch takes the fall-back
+    if (verdict == 0 && !(force && !e->is_shadow && conv_split() == 2)) return 0;
+    return run_fallback(e, slot, verdict, which);
+}
+// the slot (and engine) whose buffers hold the results of the launch on `slot`
+static inline pocr_engine *result_engine(pocr_engine *e, int32_t slot) { return e->slot[slot].redirect ? e->shadow : e; }
+
+int64_t pocr_range_fallbacks(pocr_engine *e) { return e ? e->range_fallbacks : 0; }
 
 int pocr_slot_launch(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t want_argmax) {
     if (check_slot(e, slot)) return 1;
@@ -1744,7 +1947,10 @@ int pocr_slot_collect(pocr_engine *e, int32_t slot, float *logits_ntc, int32_t *
     Slot &s = e->slot[slot];
     if (!s.in_flight) return fail("slot %d has nothing in flight", slot);
     HIP_TRY(hipSetDevice(e->device));
-    return collect_outputs(e, s, logits_ntc, frame_argmax_nt, labels_nt, label_len_n);
+    if (sync_and_guard(e, slot)) { s.in_flight = false; return 1; }
+    pocr_engine *r = result_engine(e, slot);
+    if (r != e) s.in_flight = false;
+    return collect_outputs(r, r->slot[slot], logits_ntc, frame_argmax_nt, labels_nt, label_len_n);
 }
 
 int pocr_slot_launch_sparse(pocr_engine *e, int32_t slot, const int32_t *row_begin, const int32_t *row_end,
@@ -1765,6 +1971,7 @@ int pocr_slot_launch_sparse(pocr_engine *e, int32_t slot, const int32_t *row_beg
                 return fail("line %d: row range [%d, %d) outside [0, %d]", i, row_begin[i], row_end[i], Ti);
             rows[i] = row_begin[i]; rows[s.n + i] = row_end[i];
         }
+        s.sp_rows_host = rows;
         if (s.sp_rows.reserve(rows.size() * sizeof(int32_t))) return 1;
         HIP_TRY(hipMemcpyAsync(s.sp_rows.p, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, s.stream));
         HIP_TRY(hipStreamSynchronize(s.stream));       // `rows` is a stack-lifetime pageable buffer
@@ -1786,8 +1993,9 @@ int pocr_slot_sparse_nnz(pocr_engine *e, int32_t slot, int64_t *total_nnz) {
     if (!s.in_flight || !s.want_sparse) return fail("slot %d has no sparse launch in flight", slot);
     if (!total_nnz) return fail("total_nnz is NULL");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(s.seq_stream));
-    *total_nnz = static_cast<const int64_t *>(s.sp_pinned)[s.n];
+    if (sync_and_guard(e, slot)) return 1;
+    const Slot &r = result_engine(e, slot)->slot[slot];
+    *total_nnz = static_cast<const int64_t *>(r.sp_pinned)[r.n];
     return 0;
 }
 
@@ -1798,7 +2006,11 @@ int pocr_slot_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t 
     if (!s.in_flight || !s.want_sparse) return fail("slot %d has no sparse launch in flight", slot);
     if (!data || !indices || !indptr || !line_off) return fail("NULL output pointer");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(s.seq_stream));
+    if (sync_and_guard(e, slot)) { s.in_flight = false; return 1; }
+    if (s.redirect) {                   // the launch was re-run on the fall-back engine: its slot holds the results
+        s.in_flight = false;
+        return pocr_slot_collect_sparse(e->shadow, slot, data, indices, indptr, line_off, frame_argmax_nt, labels_nt, label_len_n);
+    }
     const int n = s.n, C = e->cfg.num_classes;
     const size_t off_bytes = (size_t)(n + 1) * sizeof(int64_t), ip_bytes = (size_t)n * (C + 1) * sizeof(int32_t);
     const char *sp = static_cast<const char *>(s.sp_pinned);
@@ -1822,6 +2034,7 @@ int pocr_slot_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t 
 
 int pocr_slot_confidence(pocr_engine *e, int32_t slot, float *confidence_n) {
     if (check_slot(e, slot)) return 1;
+    if (e->slot[slot].redirect && e->shadow) return pocr_slot_confidence(e->shadow, slot, confidence_n);
     Slot &s = e->slot[slot];
     if (!s.want_sparse || !s.sp_pinned || !s.staged) return fail("slot %d: no collected sparse launch", slot);
     if (s.in_flight) return fail("slot %d: collect the launch first", slot);
@@ -2057,6 +2270,15 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
     if (s.s2s_state.reserve(((size_t)2 * n + 2 * nb + 1) * sizeof(int32_t))) return 1;
     HIP_TRY(hipMemcpyAsync(s.s2s_tables.p, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));                 // `tab` is pageable and dies with this scope; also: the encoder is done
+    if (!s.guard_checked) {
+        s.guard_checked = true;
+        int which = 0;
+        if (const int verdict = range_verdict(s, &which)) {
+            s.in_flight = false; s.s2s_launched = false;
+            return fail("the encoder left the range of the default f16x2 arithmetic (%s in activation set %d): the sequence-to-sequence engine has no "
+                        "automatic fall-back - set POCR_CONV_SPLIT=3 (bf16x3, fp32's range)", verdict == 1 ? "|x| >= 65504 or not finite" : "a whole tensor below 2^-13", which);
+        }
+    }
     const int32_t *d_batch_first = s.s2s_tables.as<int32_t>(), *d_limit = d_batch_first + nb + 1;
     int32_t *d_alive = s.s2s_state.as<int32_t>(), *d_done = d_alive + n, *d_steps = d_done + nb, *d_remaining = d_steps + nb;
     int32_t *d_line_done = d_remaining + 1;
@@ -2088,7 +2310,7 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
     };
     auto ln = [&](const float *a_, const float *b_, const DevBuf &gw, const DevBuf &gb, float *y_) {
         hipLaunchKernelGGL(layernorm_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a_, b_, gw.as<float>(), gb.as<float>(),
-                           (const float *)nullptr, y_, n, E, 1, 1e-5f, (const int32_t *)nullptr, (const int32_t *)d_remaining);
+                           (const float *)nullptr, y_, n, E, 1, 1e-5f, (const int32_t *)nullptr, (const int32_t *)d_remaining, (void *)nullptr, (unsigned *)nullptr);
     };
     auto attend = [&](DecAttnArgs a) {
         a.out = s.s2s_ctx.as<float>(); a.line_done = d_line_done; a.stop = d_remaining;
@@ -2532,10 +2754,11 @@ int pocr_debug_read(pocr_engine *e, int32_t what, float *out, size_t cap, size_t
         }
         HIP_TRY(hipMemcpyAsync(out, src, k * sizeof(float), hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(hipStreamSynchronize(s.stream));
-        if (e->p2 && what >= 0 && what < 9) {
+        const bool seq_p2 = (what == 9 && s.feat_is_p2) || (e->cfg.arch == POCR_ARCH_BLSTM && what >= 10 && what - 10 < s.lstm_p2_layers);
+        if ((e->p2 && what >= 0 && what < 9) || seq_p2) {
             // conv activations are kept pre-split (conv_bf16x3.hpp "P2": per pixel and 32-channel chunk 32 x f16 h, 32 x f16 l);
             // the caller gets the values they stand for, x = h + l / 2048, in NHWC order
-            const int C = s.act_c[what];
+            const int C = what < 9 ? s.act_c[what] : what == 9 ? e->cfg.conv_out : 2 * e->cfg.lstm_hidden;
             std::vector<float> px(C);
             for (size_t p0 = 0; p0 + C <= k; p0 += C) {
                 const _Float16 *raw = reinterpret_cast<const _Float16 *>(out + p0);

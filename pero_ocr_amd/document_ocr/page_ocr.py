@@ -55,17 +55,21 @@ class PageOCR:
         self.process_pages([page_layout])
         return page_layout
 
-    def process_pages(self, page_layouts):
+    def process_pages(self, page_layouts, sharded=None):
         """The lines of SEVERAL pages through one `process_lines` call.  The recurrent layers advance one frame per
         dependent kernel whatever the number of lines (a page of 47 long lines keeps the GPU ~20 % busy there), and lines
         are recognised independently given their chunk's padded width - which is a function of the sorted widths, so
         the chunks of a page stream differ from the per-page ones exactly as they do when the reference's
-        `process_lines` is handed more lines.  Results are written to the lines as process_page does."""
+        `process_lines` is handed more lines.  Results are written to the lines as process_page does.
+        `sharded`: a sharding.ShardedLineOCR built over this engine - the stream's chunks are dealt to the ranks."""
         lines = [line for layout in page_layouts for line in layout.lines_iterator()]
         for line in lines:
             if line.crop is None:
                 raise Exception(f"Missing crop in line {line.id}.")
-        texts, logits, coords = self.ocr_engine.process_lines([line.crop for line in lines])
+        # sharded (sharding.ShardedLineOCR over this engine, one process per GPU): every rank gets every transcription,
+        # logits / logit_coords for the lines of its own chunks and None for the others (they stay on the producing rank)
+        recogniser = sharded if sharded is not None else self.ocr_engine
+        texts, logits, coords = recogniser.process_lines([line.crop for line in lines])
         for line, text, line_logits, line_coords in zip(lines, texts, logits, coords):
             line.transcription = text
             line.logits = line_logits

@@ -173,13 +173,21 @@ class BaseEngineLineOCR:
         (scipy.sparse.csc_matrix float32 [T_i, C]; dense ndarray if sparse_logits=False;
         None if no_logits) and logit_coords ([start, end] frame span of the un-padded
         line; [None, None] with tight_crop_logits; None if no_logits)."""
+        for i, line in enumerate(lines):
+            if line.ndim != 3 or line.shape[0] != self.line_px_height or line.shape[2] != 3:
+                raise ValueError(f"line {i}: expected a [{self.line_px_height}, w, 3] crop, got {line.shape}")
+        chunks = plan_chunks([l.shape[1] for l in lines], self.max_input_horizontal_pixels, int(self.line_padding_px))
+        return self.process_chunks(lines, chunks, sparse_logits, tight_crop_logits, no_logits)
+
+    def process_chunks(self, lines, chunks, sparse_logits=True, tight_crop_logits=False, no_logits=False):
+        """The body of process_lines for a GIVEN subset of the reference's chunk plan of `lines` (all of it: process_lines;
+        one rank's share: sharding.ShardedLineOCR - a line's result depends on its chunk's padded width, so a rank must run
+        chunks of the plan over ALL lines, never a plan of its own lines).  Returns the three lists of process_lines, in
+        input order, with None for the lines of chunks that were not given."""
         n = len(lines)
         transcriptions: List[Optional[str]] = [None] * n
         logits_out: List[object] = [None] * n
         coords_out: List[Optional[list]] = [None] * n
-        for i, line in enumerate(lines):
-            if line.ndim != 3 or line.shape[0] != self.line_px_height or line.shape[2] != 3:
-                raise ValueError(f"line {i}: expected a [{self.line_px_height}, w, 3] crop, got {line.shape}")
 
         sub = int(self.net_subsampling)
         pad = int(self.line_padding_px)
@@ -222,7 +230,6 @@ class BaseEngineLineOCR:
         # before chunk k is collected, so its GPU work overlaps chunk k's read-back and the host-side
         # softmax / CSC assembly.  (The reference runs chunk after chunk, line_ocr_engine.py:80-129;
         # the chunks are independent, so the results are the same.)
-        chunks = plan_chunks([l.shape[1] for l in lines], self.max_input_horizontal_pixels, pad)
         for chunk in chunks:
             if chunk.max_width + 2 * pad > chunk.w_pad:
                 print(f"WARNING: Line too long for OCR engine. Cropping from {chunk.max_width + 2 * pad} px "

@@ -183,12 +183,17 @@ def allgather_rows(transport, rows: np.ndarray, m_max: int, m_of: Sequence[int])
 
 
 class ShardedLineOCR:
-    """process_lines over all ranks.  Every rank calls it with the SAME list of crops (the page stream); each runs the
-    chunks `assign_chunks` gives it on its own GPU and all ranks end up with every transcription.
+    """process_lines over all ranks, with the reference's return contract (line_ocr_engine.py:144-177).  Every rank calls
+    it with the SAME list of crops (the page stream); each runs the chunks `assign_chunks` gives it on its own GPU.  All
+    ranks end up with EVERY transcription (the one all-gather); logits and logit_coords stay on the rank that produced
+    them: a rank gets them for the lines of ITS chunks and None elsewhere - which is what the caller that writes them to
+    `TextLine` objects needs (page_parser.py:423-430; `PageOCR.process_pages(..., sharded=...)`).
 
-    `recognise(lines, chunk) -> (labels int32 [n, T], lens int32 [n])` is the per-chunk device call
-    (PytorchEngineLineOCR on a GPU box; a stand-in in the gloo CPU tests); `transport` carries the all-gather
-    (RcclTransport in the product, TorchDistTransport in the CPU tests)."""
+    `recognise(lines, chunk) -> (labels int32 [n, T], lens int32 [n])` is the per-chunk device call of the labels-only
+    path (`no_logits=True`); `recognise.full(lines, chunks, sparse_logits, tight_crop_logits) -> (texts, logits, coords)`
+    - lists in input order, None outside `chunks` - the one with logits (`engine_recogniser`: PytorchEngineLineOCR on a
+    GPU box; stand-ins in the gloo CPU tests).  `transport` carries the all-gather (RcclTransport in the product,
+    TorchDistTransport in the CPU tests)."""
 
     def __init__(self, recognise: Callable, characters: Sequence[str], max_input_horizontal_pixels: int,
                  line_padding_px: int = 32, transport=None):
@@ -198,7 +203,48 @@ class ShardedLineOCR:
         self.line_padding_px = line_padding_px
         self.transport = transport if transport is not None else TorchDistTransport()
 
-    def process_lines(self, lines) -> List[str]:
+    def process_lines(self, lines, sparse_logits=True, tight_crop_logits=False, no_logits=False):
+        """-> (transcriptions of ALL lines, logits, logit_coords): the latter two for this rank's lines, None elsewhere
+        (all None with no_logits).  ONE collective per call."""
+        n = len(lines)
+        if no_logits:
+            return self._texts_from_labels(lines), [None] * n, [None] * n
+        full = getattr(self.recognise, "full", None)
+        if full is None:
+            raise TypeError("this recogniser returns labels only: call process_lines(..., no_logits=True)")
+        tr = self.transport
+        chunks = plan_chunks([l.shape[1] for l in lines], self.max_input_horizontal_pixels, self.line_padding_px)
+        parts = assign_chunks(chunks, tr.world)
+        mine = [chunks[i] for i in parts[tr.rank]]
+        ids_of = [[i for ci in p for i in chunks[ci].line_ids] for p in parts]
+        m_of = [len(x) for x in ids_of]
+        # transcriptions travel as code points; a frame emits at most one symbol, so the plan bounds a row's length
+        cp_max = max([len(ch) for ch in self.characters], default=1)
+        stride = max([c.frames for c in chunks], default=0) * cp_max + 2
+        rows = np.full((m_of[tr.rank], stride), -1, dtype=np.int32)              # [line id, length, code points...]
+        logits: List[object] = [None] * n
+        coords: List[object] = [None] * n
+        failure = None
+        try:                                   # (a failing rank still takes part in the collective, with its rows flagged)
+            if mine:
+                texts_mine, logits, coords = full(lines, mine, sparse_logits, tight_crop_logits)
+                for k, i in enumerate(ids_of[tr.rank]):
+                    cps = [ord(ch) for ch in texts_mine[i]]
+                    if len(cps) > stride - 2:
+                        raise RuntimeError(f"line {i}: transcription of {len(cps)} symbols exceeds the plan's bound {stride - 2}")
+                    rows[k, 0], rows[k, 1] = i, len(cps)
+                    rows[k, 2:2 + len(cps)] = cps
+        except Exception as exc:              # noqa: BLE001 - re-raised below, after the collective
+            failure = exc
+            rows[:, 1] = ROW_FAILED
+        got = allgather_rows(tr, rows, max(m_of, default=0), m_of)
+        _raise_together(got, failure, tr, m_of)
+        texts: List[Optional[str]] = [None] * n
+        for row in got:
+            texts[int(row[0])] = "".join(chr(int(c)) for c in row[2:2 + row[1]])
+        return texts, logits, coords
+
+    def _texts_from_labels(self, lines) -> List[str]:
         tr = self.transport
         chunks = plan_chunks([l.shape[1] for l in lines], self.max_input_horizontal_pixels, self.line_padding_px)
         parts = assign_chunks(chunks, tr.world)
@@ -273,7 +319,12 @@ def engine_recogniser(engine) -> Callable:
             raise
         return [out[id(ch)] for ch in chunks]
 
+    def full(lines, chunks, sparse_logits, tight_crop_logits):
+        """This rank's chunks with the reference's logits contract: the engine's own process_lines body over them."""
+        return engine.process_chunks(lines, chunks, sparse_logits, tight_crop_logits, False)
+
     recognise.many = many
+    recognise.full = full
     return recognise
 
 

@@ -472,11 +472,21 @@ def test_c3_page_stream_over_rccl_matches_reference_golden(golden, tmp_path):
         inner = tr.allgather_i32
         tr.allgather_i32 = lambda send: (calls.append(send.size), inner(send))[1]
         sh = sharding.ShardedLineOCR(sharding.engine_recogniser(eng), eng.characters, eng.max_input_horizontal_pixels, transport=tr)
-        got = sh.process_lines(lines)
+        got, no_lg, no_co = sh.process_lines(lines, no_logits=True)
         assert len(calls) == 1, "exactly ONE collective per page stream"
+        assert no_lg == [None] * g.n and no_co == [None] * g.n
+        # the full return contract under sharding (line_ocr_engine.py:144-177): every transcription everywhere, logits and
+        # logit_coords for this rank's lines (a world of one: all of them) - again with exactly one collective
+        calls.clear()
+        sh_t, sh_l, sh_c = sh.process_lines(lines)
+        assert len(calls) == 1
     finally:
         eng.model.comm_destroy()
     assert got == g.transcriptions
+    assert sh_t == g.transcriptions and sh_c == g.logit_coords
+    from scipy import sparse as sp
+    shapes = g.arrays["shapes"]
+    assert all(sp.issparse(m) and m.shape == (int(shapes[i, 0]), int(shapes[i, 1])) for i, m in enumerate(sh_l))
     # per-frame argmax of the whole stream through the plain engine (dense logits of 330k frames stay off the fixture)
     texts, logits, coords = eng.process_lines(lines, sparse_logits=False)
     assert texts == g.transcriptions and coords == g.logit_coords
@@ -967,29 +977,34 @@ def test_presplit_activations_are_bit_identical(monkeypatch):
     offs = np.concatenate([[0], np.cumsum([c.size for c in crops])[:-1]]).astype(np.int64)
     cases = [([-(-max(w, 1) // 32) * 32 + 64 for w in widths], 32), ([1088] * len(widths), 32)]
 
-    def run(p2):
-        if p2:
-            monkeypatch.delenv("POCR_NO_P2", raising=False)
-        else:
-            monkeypatch.setenv("POCR_NO_P2", "1")
+    def run(env):
+        for k in ("POCR_NO_P2", "POCR_NO_GEMM2"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
         eng = _native.NativeEngine(spec, weights, 0)
         out = []
         for w_pads, pad_left in cases:
             eng.slot_stage_ragged(0, pool, offs, np.array(widths, np.int32), w_pads, pad_left)
             eng.slot_launch(0, want_logits=True, want_argmax=True)
             logits, amax, labels, lens = eng.slot_collect(0)
-            out.append(([eng.debug_read(k) for k in range(9)], [eng.debug_read(9), logits, amax, labels, lens]))
+            # taps 0-8 conv activations, 9 aggregated features, 10 the first BiLSTM layer's output: all pre-split in the default mode
+            out.append(([eng.debug_read(k) for k in range(11)], [eng.debug_read(11), logits, amax, labels, lens]))
+        assert eng.range_fallbacks() == 0
         eng.close()
         return out
 
-    a, b = run(True), run(False)
-    for (acts_a, outs_a), (acts_b, outs_b) in zip(a, b):
-        for k, (x, y) in enumerate(zip(outs_a, outs_b)):
-            assert x.shape == y.shape and np.array_equal(x, y), f"output {k} differs with pre-split activations"
-        for k, (x, y) in enumerate(zip(acts_a, acts_b)):
-            assert x.shape == y.shape
-            # (values below f16's normal range, 6.1e-5, keep an absolute precision of 2^-35 instead of a relative one)
-            assert np.all(np.abs(x - y) <= 2.0 ** -21 * np.abs(y) + 1e-9), f"conv{k + 1}: P2 read-back is not the fp32 value to 2^-21"
+    # default: P2 activations + the persistent P2-input GEMM (gemm_f16x2.hpp) for the aggregation conv and the LSTM projections;
+    # POCR_NO_GEMM2: P2 conv stack, conv3x3_bf16x3_kernel's GEMM mode on fp32 features; POCR_NO_P2: the split inside every consumer
+    a, g, b = run([]), run(["POCR_NO_GEMM2"]), run(["POCR_NO_P2"])
+    for other, what in ((g, "the GEMM-mode conv kernel"), (b, "the in-kernel split")):
+        for (acts_a, outs_a), (acts_b, outs_b) in zip(a, other):
+            for k, (x, y) in enumerate(zip(outs_a, outs_b)):
+                assert x.shape == y.shape and np.array_equal(x, y), f"output {k} differs from {what}"
+            for k, (x, y) in enumerate(zip(acts_a, acts_b)):
+                assert x.shape == y.shape
+                # (values below f16's normal range, 6.1e-5, keep an absolute precision of 2^-35 instead of a relative one)
+                assert np.all(np.abs(x - y) <= 2.0 ** -21 * np.abs(y) + 1e-9), f"activation {k}: P2 read-back is not the fp32 value of {what} to 2^-21"
 
 
 @pytest.mark.parametrize("height", [40, 32, 64])
@@ -1068,6 +1083,81 @@ def test_layer_rescaling_leaves_the_logits_alone():
         err = float(np.max(np.abs(logits - ref_logits)))
         print(f"[rescale {a} x 2^-{k}] max |dlogit| {err:.3e}")
         assert err < LOGIT_TOL, (a, err)
+
+
+def test_range_guard_reruns_on_bf16x3():
+    """The default f16x2 arithmetic has fp32's precision but f16's RANGE; the reference computes in plain fp32
+    (pytorch_ocr_engine.py:61-69).  Networks whose activations leave f16's range must still give fp32-class results, with
+    no action by the caller: every producer of an f16x2 operand records the largest |value| it wrote, and a launch in which
+    one reached 65504 - or a whole activation tensor lay below 2^-13, where the low plane of the split is subnormal - is
+    re-run on the bf16x3 kernels at collect time (include/pocr.h: pocr_range_fallbacks).  Rescalings by powers of two
+    leave the network's function EXACTLY unchanged (ReLU / max-pool are positively homogeneous), so the oracle on the
+    rescaled weights is the reference: logits within the tolerance, labels = its greedy CTC - dense and sparse launches."""
+    if _native.conv_split() != 2:
+        pytest.skip("the range guard belongs to the f16x2 arithmetic")
+    chars = synth.make_charset(99)
+    spec = netspec.NetSpec(num_classes=len(chars) + 1)
+    base = netspec.generate_weights(spec, 20260928)
+    crops = synth.make_crops(55, [256, 131, 300, 64, 200])
+    pool = np.concatenate([c.reshape(-1) for c in crops])
+    offs = np.concatenate([[0], np.cumsum([c.size for c in crops])[:-1]]).astype(np.int64)
+    widths = np.array([c.shape[1] for c in crops], np.int32)
+    batch = engine_oracle.assemble_batch(crops, list(range(len(crops))), spec.height, 320, 3840)      # [n, H, 384, 3]
+    assert batch.shape[2] == 384
+
+    def scaled(plan):
+        w = dict(base)
+        for name, k, with_bias in plan:
+            w[f"{name}.weight"] = base[f"{name}.weight"] * np.float32(2.0 ** k)
+            if with_bias:
+                w[f"{name}.bias"] = base[f"{name}.bias"] * np.float32(2.0 ** k)
+        return w
+
+    cases = {
+        # conv4's output ~1e5 (> 65504: its high f16 plane would be inf), conv5 takes the factor back
+        "overflow": scaled([("conv4", 17, True), ("conv5", -17, False)]),
+        # conv4's output ~6e-8 (both planes subnormal: 2^-11 relative precision without the guard), undone over two layers
+        # (conv5's pre-activation is 2^-12 times the original one: its bias is scaled to match)
+        "underflow": scaled([("conv4", -24, True), ("conv5", 12, False), ("conv6", 12, False)]),
+    }
+    cases["underflow"]["conv5.bias"] = base["conv5.bias"] * np.float32(2.0 ** -12)
+    for name, w in cases.items():
+        ref = model_oracle.forward_logits(model_oracle.OracleNet(spec, w), batch)              # [n, C, T]
+        ref_best, ref_labels = engine_oracle.greedy_ctc(ref)
+        eng = _native.NativeEngine(spec, netspec.pack_weights(spec, w), 0)
+        for rep in range(2):                                       # the second launch reuses the fall-back engine
+            eng.slot_stage_ragged(rep, pool, offs, widths, [384] * len(crops), 32)
+            eng.slot_launch(rep, want_logits=True, want_argmax=True)
+            logits, amax, labels, lens = eng.slot_collect(rep)
+            assert eng.range_fallbacks() == rep + 1, f"{name}: the launch was not re-run"
+            err = float(np.max(np.abs(logits.reshape(len(crops), -1, spec.num_classes) - ref.transpose(0, 2, 1))))
+            print(f"[range guard, {name}] max |dlogit| vs the oracle on the rescaled weights {err:.3e}")
+            assert err < LOGIT_TOL, (name, err)
+            for i in range(len(crops)):
+                assert np.array_equal(labels[i, :lens[i]], ref_labels[i]), f"{name}: line {i}"
+        # the default call's sparse launch takes the same way out
+        eng.slot_stage_ragged(0, pool, offs, widths, [384] * len(crops), 32)
+        eng.slot_launch_sparse(0, want_argmax=True)
+        data, indices, indptr, line_off, amax_s, labels_s, lens_s = eng.slot_collect_sparse(0)
+        assert eng.range_fallbacks() == 3 and np.array_equal(labels_s, labels) and np.array_equal(amax_s, amax)
+        conf = eng.slot_confidence(0)
+        assert conf.shape == (len(crops),) and np.all(np.isfinite(conf))
+        dense = logits.reshape(len(crops), -1, spec.num_classes)
+        for i in range(len(crops)):                                # kept entries are the dense logits of the same (re-run) arithmetic
+            T_i, Cn = dense.shape[1], spec.num_classes
+            for c in range(0, Cn, 17):
+                lo, hi = int(line_off[i] + indptr[i, c]), int(line_off[i] + indptr[i, c + 1])
+                rows = indices[lo:hi]
+                assert np.all(rows < T_i)
+                assert np.allclose(data[lo:hi], dense[i, rows, c], atol=1e-6)
+        eng.close()
+    # a network that stays in range never takes the fall-back
+    eng = _native.NativeEngine(spec, netspec.pack_weights(spec, base), 0)
+    eng.slot_stage_ragged(0, pool, offs, widths, [384] * len(crops), 32)
+    eng.slot_launch(0, want_logits=True)
+    eng.slot_collect(0)
+    assert eng.range_fallbacks() == 0
+    eng.close()
 
 
 def test_resident_recurrence_equals_the_step_kernels(monkeypatch):

@@ -39,6 +39,25 @@ def _fake_recognise(lines, chunk):
     return labs, lens
 
 
+def _fake_full(lines, chunks, sparse_logits, tight_crop_logits):
+    """Stand-in for engine.process_chunks: texts from the labels of _fake_recognise, "logits" = a small array that
+    encodes (line, chunk width, flags), coords as process_lines computes them.  None outside `chunks`."""
+    chars = synth.make_charset(50)
+    n = len(lines)
+    texts, logits, coords = [None] * n, [None] * n, [None] * n
+    for ch in chunks:
+        labs, lens = _fake_recognise(lines, ch)
+        for k, i in enumerate(ch.line_ids):
+            texts[i] = "".join(chars[c] for c in labs[k, :lens[k]])
+            logits[i] = np.array([i, ch.w_pad, int(sparse_logits), int(tight_crop_logits)], np.float32)
+            coords[i] = [None, None] if tight_crop_logits else [8, (32 + lines[i].shape[1]) // 4]
+    return texts, logits, coords
+
+
+_fake_recognise_full = lambda lines, chunk: _fake_recognise(lines, chunk)      # noqa: E731 - a callable that can carry attributes
+_fake_recognise_full.full = _fake_full
+
+
 def _fake_s2s(lines, batches):
     """Stand-in for the GPU call of the seq2seq engine: text = f(crop bytes, batch geometry, number of parts)."""
     out = {}
@@ -59,9 +78,9 @@ def _worker(rank, world, port, out_dir):
         lines = synth.make_crops(4, widths)
         chars = synth.make_charset(50)
         eng = sharding.ShardedLineOCR(_fake_recognise, chars, 480 * 8)
-        texts = eng.process_lines(lines)
+        texts = eng.process_lines(lines, no_logits=True)[0]
         # a rank with no chunks at all (more ranks than chunks) must still take part
-        few = sharding.ShardedLineOCR(_fake_recognise, chars, 480 * 64).process_lines(lines[:3])
+        few = sharding.ShardedLineOCR(_fake_recognise, chars, 480 * 64).process_lines(lines[:3], no_logits=True)[0]
         # sequence-to-sequence engine: whole reference batches per rank, transcriptions gathered as code points
         s2s = sharding.ShardedSeq2SeqOCR(_fake_s2s, 480 * 4, 1024).process_lines(lines)
         # one rank fails inside its share: it must still take part in the collective and BOTH ranks must raise
@@ -70,7 +89,7 @@ def _worker(rank, world, port, out_dir):
                 raise ValueError("device lost (simulated)")
             return _fake_recognise(lines_, chunk)
         try:
-            sharding.ShardedLineOCR(failing, chars, 480 * 8).process_lines(lines)
+            sharding.ShardedLineOCR(failing, chars, 480 * 8).process_lines(lines, no_logits=True)
             outcome = "returned"
         except ValueError as exc:
             outcome = f"own:{exc}"
@@ -78,6 +97,16 @@ def _worker(rank, world, port, out_dir):
             outcome = f"peer:{exc}"
         with open(os.path.join(out_dir, f"fail{rank}.txt"), "w") as f:
             f.write(outcome)
+        # the full return contract: every transcription on every rank, logits / coords for this rank's lines only
+        f_t, f_l, f_c = sharding.ShardedLineOCR(_fake_recognise_full, chars, 480 * 8).process_lines(lines, sparse_logits=False)
+        import pickle
+        with open(os.path.join(out_dir, f"full{rank}.pkl"), "wb") as f:
+            pickle.dump((f_t, [None if x is None else x.tolist() for x in f_l], f_c), f)
+        try:
+            sharding.ShardedLineOCR(_fake_recognise, chars, 480 * 8).process_lines(lines)       # labels-only recogniser, logits asked for
+            raise AssertionError("expected a TypeError")
+        except TypeError:
+            pass
         np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array(texts + few, dtype=object), allow_pickle=True)
         np.save(os.path.join(out_dir, f"s{rank}.npy"), np.array(s2s, dtype=object), allow_pickle=True)
     finally:
@@ -108,6 +137,20 @@ def test_gloo_world2_allgather_labels(tmp_path):
         for k, i in enumerate(ch.line_ids):
             expect[i] = "".join(chars[c] for c in labs[k, :lens[k]])
     assert r0[:len(lines)] == expect
+    # full contract: the transcriptions are everywhere; the union of the ranks' logits / coords is the single-process
+    # result of the same stand-in over the whole plan, and the ranks' shares are disjoint
+    import pickle
+    f0 = pickle.load(open(tmp_path / "full0.pkl", "rb"))
+    f1 = pickle.load(open(tmp_path / "full1.pkl", "rb"))
+    s_t, s_l, s_c = _fake_full(lines, plan_chunks(widths, 480 * 8), False, False)
+    assert f0[0] == f1[0] == s_t == expect
+    for i in range(len(lines)):
+        have = [f for f in (f0, f1) if f[1][i] is not None]
+        assert len(have) == 1, f"line {i}: logits on {len(have)} ranks"
+        assert have[0][1][i] == s_l[i].tolist() and have[0][2][i] == s_c[i]
+        other = f1 if have[0] is f0 else f0
+        assert other[2][i] is None
+    assert any(x is not None for x in f0[1]) and any(x is not None for x in f1[1])
     # seq2seq sharding: both ranks hold every transcription, equal to the single-process result
     from pero_ocr_amd.ocr_engine.transformer_ocr_engine import plan_batches
     s0 = np.load(tmp_path / "s0.npy", allow_pickle=True).tolist()

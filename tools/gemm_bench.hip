@@ -97,7 +97,7 @@ int main(int argc, char **argv) {
         g.range_flag = dflag;
         const int grid = gemm_f16x2_grid(M, N, cus);
         const double flops = 2.0 * M * (double)N * K;
-        printf("GEMM %d x %d x %d (M K N), %d CUs, grid %d, nb %d, A aux %d, row pad %d B\n", M, K, N, cus, grid, g.nb, POCR_GEMM_A_AUX, pad);
+        printf("GEMM %d x %d x %d (M K N), %d CUs, grid %d, nb %d, row pad %d B\n", M, K, N, cus, grid, g.nb, pad);
         float best;
         const bool run_old = pad == 0;
         auto old_f32 = [&] { if (!run_old) return; ConvArgs a = c; a.y = dY0; launch_old(conv3x3_bf16x3_kernel<1, 8, 4, 2, 1, 1, ACT_NONE, false, 2, false, 1, 1, 0, 0, false, 2, true, false>, 128, 128, a, st); };
