@@ -509,6 +509,25 @@ def main():
             fence()
             elapsed = time.perf_counter() - t0
         assert all(isinstance(t, str) for t in texts)
+        # the stream's result is CHECKED: the last batch of `ppb` pages again, sequentially (same lines in one process_lines call ->
+        # same reference chunk plan -> the deterministic GPU path must reproduce every string and coordinate); and against one
+        # page at a time (another chunk plan: a line's padded width, hence its last bits, may differ - reported, bounded)
+        with contextlib.redirect_stdout(sys.stderr):
+            first = ((args.steps - 1) // ppb) * ppb
+            idx = [i % n_pages for i in range(first, args.steps)]
+            streamed = [lay for _img, lay in stream.process(pages[k] for k in idx)]
+            again = []
+            for k in idx:
+                lay = layout_front(pages[k]); cropper.process_page(pages[k], lay); again.append(lay)
+            page_ocr.process_pages(again)
+            for a_, b_ in zip(streamed, again):
+                assert [l.transcription for l in a_.lines] == [l.transcription for l in b_.lines], "c5: the stream and the sequential batch disagree"
+                assert [l.logit_coords for l in a_.lines] == [l.logit_coords for l in b_.lines]
+            assert texts == [l.transcription for l in streamed[-1].lines]
+            single = one_page(idx[-1])
+            differing = sum(x != y for x, y in zip(single, texts))
+        assert differing <= max(1, len(texts) // 20), f"c5: {differing} of {len(texts)} lines differ between the stream and one page at a time"
+        extra["checked"] = {"stream_equals_sequential_batch": True, "lines_differing_from_page_at_a_time": differing, "lines": len(texts)}
         lines_per_step = 1 * world                  # unit of this workload: pages
         scaling = "weak"
         extra["unit_note"] = "value is PAGES/s for this workload"
@@ -543,7 +562,10 @@ def main():
         scaling = "strong"
         workload_txt = (f"c3: {n_total}-line page stream, widths 128..1024 (seeded), reference plan at default batch_size 8 "
                         f"({len(meta['plan'])} chunks), whole chunks dealt to {world} rank(s) (LPT), inputs: host->device every "
-                        "step, one RCCL all-gather of the labels per pass; transcriptions checked against the reference fixture")
+                        "step, " + ("one RCCL all-gather of the labels per pass" if rccl_fields["rccl_ranks"] >= 1 else
+                                    ("one all-gather of the labels per pass over the gloo carrier (NOT RCCL)" if transport is not None else
+                                     "LocalTransport: a world of one, NO collective")) +
+                        "; transcriptions checked against the reference fixture")
         w_pad = None
     else:
         # ------------------------------------------------------------------ c2 / c4: one reference chunk per step
