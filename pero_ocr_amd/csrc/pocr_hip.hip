@@ -472,6 +472,7 @@ struct pocr_engine {
     std::vector<DecLayer> dec;
     DevBuf dec_embed, dec_out_w, dec_out_b;
     int dec_out_cout16 = 0;
+    int lstm_capacity = -1;          // workgroups of the resident recurrence the chip holds at once (occupancy query, first launch)
     bool lstm_resident = true;       // one launch per BiLSTM layer with the hidden state handed over inside an XCD (lstm_resident.hpp); POCR_LSTM_RESIDENT=0: one launch per step
     bool warned_nonfinite = false, warned_placement = false;
     bool fuse12 = false;             // conv1 inside conv2's prologue (P2 only; POCR_NO_FUSE12=1: conv1 as its own launch, its activation in HBM)
@@ -902,8 +903,28 @@ int run_network(pocr_engine *e, Slot &s) {
     // resident recurrence: hidden sizes whose W_hh fragments fit a workgroup's registers, launches whose clusters the chip can
     // hold (1024 workgroups = 512 lines at H = 256); otherwise one launch per step as before
     const int n_clusters = 2 * (npad / 16);
+    // slices per workgroup: 1 for launches of a few slices (pages of long lines: the chain's latency is what counts),
+    // 2 / 4 for many slices (the chain hides behind the next launch's convolutions: fewer resident workgroups cost
+    // those less).  Measured (profiles/r03_lstm_resident.txt): c5 SL 1, c3 SL 2, c2 SL 4.
+    static const int sl_env = getenv("POCR_LSTM_SL") ? atoi(getenv("POCR_LSTM_SL")) : 0;
+    const int n_sl = npad / 16, ug_n = Hh / 16;
+    int SLn = sl_env ? sl_env : (n_sl <= 4 ? 1 : (n_sl >= 16 && T <= 160) ? 4 : 2);
+    if (SLn != 1 && SLn != 2 && SLn != 4) SLn = 2;
+    // The clusters of a launch wait for one another's members inside ONE ordinary launch: every workgroup of the grid must be
+    // able to be resident at the same time, or a cluster whose tail was not dispatched spins until its timeout.  The capacity
+    // is what the runtime reports for this kernel (workgroups per CU x CUs, one taken off per CU as the margin the guide asks
+    // for where the query is known to be optimistic); a launch that does not fit takes more slices per workgroup, then the
+    // step kernels.
+    auto resident_grid = [&](int sl) { return ((2 * ((n_sl + sl - 1) / sl) + 7) / 8) * ug_n * 8; };
+    if (e->lstm_capacity < 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_resident_kernel<4, 4>, 256, 0) != hipSuccess) per_cu = 1;
+        e->lstm_capacity = std::max(1, std::min(per_cu, 4)) * e->n_cus;
+        if (per_cu > 1) e->lstm_capacity -= e->n_cus;
+    }
+    while (SLn < 4 && resident_grid(SLn) > e->lstm_capacity) SLn *= 2;
     const bool resident = e->lstm_resident && (Hh == 64 || Hh == 128 || Hh == 256) && c.lstm_layers <= 8 &&
-                          (size_t)n_clusters * (Hh / 16) <= 1024;
+                          resident_grid(SLn) <= e->lstm_capacity;
     const size_t sync_words = (size_t)n_clusters * 32 + 32;     // + error / diagnostic words
     s.lstm_resident_used = resident;
     if (resident) {
@@ -950,15 +971,7 @@ int run_network(pocr_engine *e, Slot &s) {
             ra.y_p2 = y_p2;
             static const int force_agent = getenv("POCR_LSTM_FORCE_AGENT") ? atoi(getenv("POCR_LSTM_FORCE_AGENT")) : 0;
             ra.force_agent = force_agent;
-            // slices per workgroup: 1 for launches of a few slices (pages of long lines: the chain's latency is what counts),
-            // 2 / 4 for many slices (the chain hides behind the next launch's convolutions: fewer resident workgroups cost
-            // those less).  Measured (profiles/r03_lstm_resident.txt): c5 SL 1, c3 SL 2, c2 SL 4.
-            static const int sl_env = getenv("POCR_LSTM_SL") ? atoi(getenv("POCR_LSTM_SL")) : 0;
-            const int n_sl = npad / 16, ug_n = Hh / 16;
-            int SLn = sl_env ? sl_env : (n_sl <= 4 ? 1 : (n_sl >= 16 && T <= 160) ? 4 : 2);
-            if (SLn != 1 && SLn != 2 && SLn != 4) SLn = 2;
-            const int groups = 2 * ((n_sl + SLn - 1) / SLn);
-            const unsigned grid = (unsigned)((groups + 7) / 8 * ug_n * 8);
+            const unsigned grid = (unsigned)resident_grid(SLn);
 #define POCR_RES(KPW_)                                                                                                             \
             do {                                                                                                                   \
                 if (SLn == 1) hipLaunchKernelGGL((lstm_resident_kernel<KPW_, 1>), dim3(grid), dim3(256), 0, st, ra);                 \
@@ -1151,8 +1164,7 @@ int collect_outputs(pocr_engine *e, Slot &s, float *logits_ntc, int32_t *frame_a
     if (s.lstm_resident_used && s.lstm_err_host) {
         for (int l = 0; l < e->cfg.lstm_layers && l < 8; ++l)
             if (s.lstm_err_host[4 * l])
-                return fail("BiLSTM layer %d: a hand-off of the resident recurrence timed out (a cluster's workgroups did not all become resident) - "
-                            "set POCR_LSTM_RESIDENT=0 for one launch per step", l);
+                return fail("BiLSTM layer %d: a hand-off of the resident recurrence timed out (internal error: sync_and_guard repeats such launches)", l);
         for (int l = 0; l < e->cfg.lstm_layers && l < 8; ++l)
             if (s.lstm_err_host[4 * l + 1] && !e->warned_placement) {
                 e->warned_placement = true;
@@ -1812,9 +1824,10 @@ static int stage_ragged_impl(pocr_engine *e, int32_t slot, const uint8_t *crops,
     size_t total = 0;
     for (int i = 0; i < n; ++i) {
         if (widths[i] < 0) return fail("line %d has negative width", i);
+        if (w_pads[i] < 4) return fail("line %d: w_pad must be >= 4 (got %d)", i, w_pads[i]);
+        if ((pad_lefts ? pad_lefts[i] : pad_left) < 0) return fail("line %d: pad_left must be >= 0", i);
         if (dev_base) continue;
         if (crop_offsets[i] < 0) return fail("line %d has negative offset", i);
-        if (w_pads[i] < 4) return fail("line %d: w_pad must be >= 4 (got %d)", i, w_pads[i]);
         const size_t end = (size_t)crop_offsets[i] + (size_t)H * widths[i] * 3;
         if (end > total) total = end;
     }
@@ -1911,6 +1924,24 @@ static int run_fallback(pocr_engine *e, int32_t slot, int verdict, int which) {
 static int sync_and_guard(pocr_engine *e, int32_t slot) {
     Slot &s = e->slot[slot];
     HIP_TRY(hipStreamSynchronize(s.seq_stream));
+    if (s.lstm_resident_used && s.lstm_err_host) {
+        bool timed_out = false;
+        for (int l = 0; l < e->cfg.lstm_layers && l < 8; ++l) timed_out = timed_out || s.lstm_err_host[4 * l] != 0;
+        if (timed_out) {
+            // A cluster's workgroups did not all become resident in time (CU masking, a partitioned device, several processes
+            // on the GPU ...): this engine goes back to one launch per step, and THIS launch is run again - same slot, same
+            // requests - before anything of it is read.
+            if (e->lstm_resident)
+                fprintf(stderr, "NOTE: a hand-off of the resident BiLSTM recurrence timed out; this engine now runs one launch per step "
+                                "(POCR_LSTM_RESIDENT=0) and the launch is repeated.\n");
+            e->lstm_resident = false;
+            memset(s.lstm_err_host, 0, 8 * 4 * sizeof(uint32_t));
+            const bool checked = s.guard_checked;
+            if (run_network(e, s) || enqueue_outputs(e, s)) return 1;
+            HIP_TRY(hipStreamSynchronize(s.seq_stream));
+            s.guard_checked = checked;
+        }
+    }
     if (s.guard_checked) return 0;
     s.guard_checked = true;
     int which = 0;

@@ -119,34 +119,64 @@ class _EmbeddingView:
         return iter([self.weight])
 
 
-_FAST_CSC = None          # None: not probed yet; True / False: the attribute-level construction below reproduces the constructor
+_FAST_CSC = None          # None: not probed yet; dict / False: the attribute-level construction below is / is not in use
+_FAST_CSC_SCIPY = ((1, 8), (1, 17))      # scipy versions [lo, hi) on which the attribute-level construction has been run against the constructor (1.15.3 here)
+_FAST_CSC_CHECKED = 0     # matrices of this process whose GPU triplets were verified to be canonical (the first few of every process)
+
+
+def _canonical_triplets(indices, indptr, shape) -> bool:
+    """What csc_matrix calls canonical format: int32 index arrays, indptr non-decreasing from 0 to nnz, row indices strictly
+    increasing inside every column (sorted, no duplicates) and inside [0, rows)."""
+    if indices.dtype != np.int32 or indptr.dtype != np.int32 or len(indptr) != shape[1] + 1:
+        return False
+    if indptr[0] != 0 or indptr[-1] != len(indices) or np.any(np.diff(indptr) < 0):
+        return False
+    if len(indices) and (indices.min() < 0 or indices.max() >= shape[0]):
+        return False
+    inner = np.ones(len(indices), bool)
+    inner[indptr[:-1][indptr[:-1] < len(indices)]] = False          # first entry of every non-empty column
+    return bool(np.all(np.diff(indices, prepend=-1)[inner] > 0)) if len(indices) else True
 
 
 def _csc_from_device(data, indices, indptr, shape):
-    """scipy.sparse.csc_matrix((data, indices, indptr), shape) for triplets that are already canonical (built by the GPU's
-    compaction: sorted row indices, no duplicates, int32 index arrays).  The public constructor spends ~16 us per matrix on
-    validation - 4 ms per 256-line launch, a third of the launch's GPU time; the object is therefore assembled attribute by
-    attribute, after ONE probe per process that this yields exactly the object the constructor builds (same attributes, same
-    content) on the installed scipy - otherwise the constructor is used."""
-    global _FAST_CSC
+    """scipy.sparse.csc_matrix((data, indices, indptr), shape) for the triplets the GPU's compaction builds (sorted row
+    indices, no duplicates, int32 index arrays).  The public constructor spends ~16 us per matrix on validation - 4 ms per
+    256-line launch, a third of the launch's GPU time - so the object is assembled attribute by attribute instead: on the
+    scipy versions this was run against (_FAST_CSC_SCIPY; POCR_FAST_CSC=0 turns it off, =1 forces it), with the per-instance
+    state taken from a matrix the CONSTRUCTOR built, and only the flags the contract of the GPU compaction implies -
+    sorted indices, canonical format - are asserted, after that contract has been verified on the first matrices of the
+    process (_canonical_triplets).  Everything else goes through the constructor."""
+    global _FAST_CSC, _FAST_CSC_CHECKED
     if _FAST_CSC is None:
-        try:
-            ref = sparse.csc_matrix((data, indices, indptr), shape=shape)
-            probe = sparse.csc_matrix.__new__(sparse.csc_matrix)
-            probe.__dict__.update({k: v for k, v in ref.__dict__.items() if k not in ("data", "indices", "indptr", "_shape")})
-            probe.data, probe.indices, probe.indptr, probe._shape = data, indices, indptr, tuple(int(v) for v in shape)
-            same = (set(vars(probe)) == set(vars(ref)) and probe.shape == ref.shape and probe.nnz == ref.nnz and
-                    probe.has_sorted_indices == ref.has_sorted_indices and (probe != ref).nnz == 0 and
-                    np.array_equal(probe.toarray(), ref.toarray()))
-            _FAST_CSC = dict(ref.__dict__) if same else False
-            for k in ("data", "indices", "indptr", "_shape"):
-                if _FAST_CSC:
-                    _FAST_CSC.pop(k, None)
-            return ref
-        except Exception:
-            _FAST_CSC = False
+        env = os.environ.get("POCR_FAST_CSC", "")
+        import scipy
+        ver = tuple(int(x) for x in scipy.__version__.split(".")[:2] if x.isdigit())
+        allowed = env == "1" or (env != "0" and _FAST_CSC_SCIPY[0] <= ver < _FAST_CSC_SCIPY[1])
+        _FAST_CSC = False
+        if allowed:
+            try:
+                ref = sparse.csc_matrix((data, indices, indptr), shape=shape)
+                ref.sort_indices(); ref.sum_duplicates()                   # what the constructor leaves to be found out lazily
+                state = {k: v for k, v in ref.__dict__.items() if k not in ("data", "indices", "indptr", "_shape")}
+                probe = sparse.csc_matrix.__new__(sparse.csc_matrix)
+                probe.__dict__.update(state)
+                probe.data, probe.indices, probe.indptr, probe._shape = data, indices, indptr, tuple(int(v) for v in shape)
+                fresh = sparse.csc_matrix((data, indices, indptr), shape=shape)      # an independent constructor-built object to compare with
+                extra = set(vars(probe)) - set(vars(fresh))             # only the two lazily cached flags may be new
+                if (set(vars(fresh)) <= set(vars(probe)) and extra <= {"_has_sorted_indices", "_has_canonical_format"} and
+                        probe.shape == fresh.shape and probe.nnz == fresh.nnz and
+                        (probe != fresh).nnz == 0 and np.array_equal(probe.toarray(), fresh.toarray()) and
+                        np.array_equal((probe.T @ probe).toarray(), (fresh.T @ fresh).toarray())):
+                    _FAST_CSC = state
+            except Exception:
+                _FAST_CSC = False
     if not _FAST_CSC:
         return sparse.csc_matrix((data, indices, indptr), shape=shape)
+    if _FAST_CSC_CHECKED < 64:               # the GPU compaction's contract, verified where it is cheap: the first matrices of the process
+        _FAST_CSC_CHECKED += 1
+        if not _canonical_triplets(indices, indptr, shape):
+            _FAST_CSC = False
+            return sparse.csc_matrix((data, indices, indptr), shape=shape)
     m = sparse.csc_matrix.__new__(sparse.csc_matrix)
     m.__dict__.update(_FAST_CSC)
     m.data, m.indices, m.indptr, m._shape = data, indices, indptr, (int(shape[0]), int(shape[1]))

@@ -504,7 +504,9 @@ def test_c3_page_stream_over_rccl_matches_reference_golden(golden, tmp_path):
         assert np.array_equal(np.argmax(np.asarray(logits[i]), axis=1), g.argmax(i)), f"line {i}: per-frame argmax differs"
     hip_t, ref_t, n_hip_ref, n_ref_t, _rows = _check_truth_rows(g, logits, "c3")
     st = _TRUTH_STATS["c3"]
-    assert hip_t <= ref_t, (hip_t, ref_t)
+    # (the worst of 3.8 M sampled logits is an outlier statistic that moves with the summation order: a fixed margin, not a strict
+    # comparison of two outliers - ADVICE r03; the RMS and count criteria below are the gate)
+    assert hip_t <= ref_t + 1e-4, (hip_t, ref_t)
     assert hip_t < 1.25 * LOGIT_TOL, hip_t
     # (the fp32-MFMA fall-back, POCR_CONV_FP32=1, is an fp32 fma chain like the reference's own arithmetic and as noisy: RMS 2.2e-5)
     assert st["rms_hip"] <= st["rms_ref"] * (1.1 if _native.conv_split() == 0 else 1.0) and st["rows_hip_off"] <= n_ref_t, st

@@ -121,8 +121,8 @@ def test_page_stream_with_layout_network_front(tmp_path, golden):
 
 def test_page_stream_reproduces_the_reference_fixture(tmp_path, golden):
     """the page stream compared with the REFERENCE, not with the engine itself.  The 'pages' are groups of
-    the ragged fixture's own crops (a cropper stand-in hands them out - resident in HBM for half of the pages, numpy for the
-    others), so whatever PageStream batches together, every line must get the transcription the reference engine produced
+    the ragged fixture's own crops (a cropper stand-in hands them out as numpy arrays; HBM-resident crops are covered by
+    tests/test_crop.py::test_crops_stay_in_hbm_between_cropper_and_recogniser and test_full_size_config5_page), so whatever PageStream batches together, every line must get the transcription the reference engine produced
     for it when the same lines went through its process_lines in one call - provided the stream hands the recogniser the same
     list of lines in one call too (pages_per_batch = all pages): chunking is a function of the whole list."""
     from pero_ocr_amd import _native
