@@ -60,6 +60,9 @@ constexpr int kGemmStageU = 3072;                 // 16-byte units per stage: 20
 constexpr int kGemmBiasMax = 3072;                // bias columns kept in LDS (an ordinary global load inside the stream would drain the DMA queue)
 constexpr int kGemmLdsU = 3 * kGemmStageU + kGemmBiasMax / 4;
 
+#ifndef POCR_GEMM_SPLIT
+#define POCR_GEMM_SPLIT 0            // where a stage's six DMA requests are issued: 0 all in the memory phase, 1 the B pieces there and the A pieces between the MFMA groups, 2 all between the MFMA groups
+#endif
 #ifndef POCR_GEMM_A_AUX
 #define POCR_GEMM_A_AUX 2            // cache policy of the A pieces: 2 = nt (streamed: the weights, re-read by every row tile, keep their place in L2), 0 = default
 #endif
@@ -117,24 +120,34 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
         }
         wcol = wbase + (size_t)n16 * 2048 + (size_t)wave * 1024 + lane * 16;
     };
-    auto issue = [&](int buf) __attribute__((always_inline)) {                       // request stage (p_it, p_k) into buffer `buf`, advance
+    // one stage = 4 A pieces + 2 B pieces per wave; issue_a(buf, j) requests A piece j, issue_b the two B pieces, advance()
+    // moves on to the next stage of the flat stream
+    auto issue_a = [&](int buf, int j) __attribute__((always_inline)) {
         u32x4 *dst = lds + buf * kGemmStageU;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const char *src;
-            if constexpr (GATHER) src = arow[j] + p_tap * atap[j] + (size_t)p_c * 128;
-            else src = arow[j] + (size_t)p_k * 128;
-            POCR_GLDS16(src, dst + (j * 8 + wave) * 64, POCR_GEMM_A_AUX);
-        }
+        const char *src;
+        if constexpr (GATHER) src = arow[j] + p_tap * atap[j] + (size_t)p_c * 128;
+        else src = arow[j] + (size_t)p_k * 128;
+        POCR_GLDS16(src, dst + (j * 8 + wave) * 64, POCR_GEMM_A_AUX);
+    };
+    auto issue_b = [&](int buf) __attribute__((always_inline)) {
+        u32x4 *dst = lds + buf * kGemmStageU;
         const char *wsrc = wcol + (size_t)(GATHER ? p_tap * a.cpt + p_c : p_k) * a.N16 * 2048;
-        if constexpr (GATHER) { if (++p_tap == a.ntap) { p_tap = 0; ++p_c; } }
         POCR_GLDS16(wsrc, dst + 2048 + wave * 64, 0);                    // (tile, plane) pieces wave and wave + 8
         POCR_GLDS16(wsrc + 8 * 1024, dst + 2048 + (8 + wave) * 64, 0);
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        if constexpr (GATHER) { if (++p_tap == a.ntap) { p_tap = 0; ++p_c; } }
         if (++p_k == nk) {
             p_k = 0; p_tap = 0; p_c = 0;
             if (p_it + 1 < iters) { ++p_it; tile_addr(p_it); }
             else { p_k = nk - 1; p_tap = a.ntap - 1; p_c = a.cpt - 1; }     // past the end: the last stage again (read, never used) - the DMA count per stage stays constant
         }
+    };
+    auto issue = [&](int buf) __attribute__((always_inline)) {                       // a whole stage at once (prologue)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue_a(buf, j);
+        issue_b(buf);
+        advance();
     };
 
     f32x4 acc[4][4], acc2[4][4];
@@ -245,18 +258,33 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
         for (int m = 0; m < 4; ++m) { ah[m] = S[a_h + m * 128]; al[m] = S[a_l + m * 128]; }
 #endif
 #if !(POCR_GEMM_DBG & 1)
-        issue(buf == 0 ? 2 : buf - 1);
+        {
+            const int nb_ = buf == 0 ? 2 : buf - 1;
+            if constexpr (POCR_GEMM_SPLIT == 0) issue(nb_);
+            else if constexpr (POCR_GEMM_SPLIT == 1) issue_b(nb_);
+        }
 #endif
         // the pieces of stage g + 1: all but the 6 just requested - and, behind a full tile's epilogue, its NST stores, which
         // are younger than the pieces of stage g + 1 and older than those of g + 2 (so the NEXT stage's wait covers them)
 #if POCR_GEMM_DBG & 1
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #else
+        // (POCR_GEMM_SPLIT: the pieces requested in THIS memory phase are the only ones younger than the stage waited for:
+        //  6 / 2 / 0, plus a full epilogue's NST stores)
         if (stores_young) {
-            if constexpr (P2OUT) asm volatile("s_waitcnt vmcnt(38) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)" ::: "memory");
+            if constexpr (P2OUT) {
+                if constexpr (POCR_GEMM_SPLIT == 0) asm volatile("s_waitcnt vmcnt(38) lgkmcnt(0)" ::: "memory");
+                else if constexpr (POCR_GEMM_SPLIT == 1) asm volatile("s_waitcnt vmcnt(34) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+            } else {
+                if constexpr (POCR_GEMM_SPLIT == 0) asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)" ::: "memory");
+                else if constexpr (POCR_GEMM_SPLIT == 1) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+            }
         } else {
-            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            if constexpr (POCR_GEMM_SPLIT == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else if constexpr (POCR_GEMM_SPLIT == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
 #endif
         stores_young = false;
@@ -270,6 +298,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
 #else
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
+#if !(POCR_GEMM_DBG & 1)
+            if constexpr (POCR_GEMM_SPLIT >= 1) issue_a(buf == 0 ? 2 : buf - 1, m);       // one A piece per 12 MFMAs
+            if constexpr (POCR_GEMM_SPLIT == 2) { if (m == 1) issue_b(buf == 0 ? 2 : buf - 1); }
+#endif
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc2[m][n] = POCR_MFMA_F16(bh[n], al[m], acc2[m][n]);
 #pragma unroll
@@ -277,6 +309,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc2[m][n] = POCR_MFMA_F16(bl[n], ah[m], acc2[m][n]);
         }
+#if !(POCR_GEMM_DBG & 1)
+        if constexpr (POCR_GEMM_SPLIT >= 1) advance();
+#endif
 #endif
         if (++c_k == nk) { c_k = 0; pending = true; }
     };

@@ -64,7 +64,7 @@ constexpr int kXccIdGetreg = (3 << 11) | (0 << 6) | 20;      // s_getreg_b32 HW_
 // workgroup computes the next slice - the hand-off latency disappears from the chain, and the launch needs 1 / SL of the
 // workgroups (c2: 256 instead of 512, one per CU, which leaves the convolutions of the next launch two workgroups per CU).
 template <int KPW, int SL>
-__global__ __launch_bounds__(256) void lstm_resident_kernel(LstmResidentArgs a) {
+__global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs a) {
     constexpr int H = 64 * KPW, KGT = H / 16, UG = KGT;
     __shared__ float part[4 * 4 * 64 * 4];      // [wave][gate][lane][reg]
     __shared__ int s_fast, s_abort;

@@ -202,7 +202,7 @@ int conv_split() {
 // wins wherever each wave owns its channels (WM 1) and the accumulators leave room for three weight sets
 // the low-K layers (2-4 chunks of K) want SMALL tiles: two or three workgroups per CU cover each other's prologue / epilogue
 // (MFMA busy 44-52 % with one 4x64 / 4x32 workgroup per CU; -10 ... -16 % with these)
-POCR_CONV3(conv2_b3,  4, 2, 2, 2, 2, 2, ACT_RELU, false, 2, false, 3)   // 64->64 + pool 2x2: 4x32 px, NT 64, waves 2 (pixels) x 2 (channels)
+POCR_CONV3(conv2_b3,  4, 2, 2, 2, 2, 2, ACT_RELU, false, 2, false, 2)   // 64->64 + pool 2x2: 4x32 px, NT 64, waves 2 (pixels) x 2 (channels)
 POCR_CONV3(conv3_b3,  5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true, 2)    // 64->128: 5x16 px, NT 128
 POCR_CONV3(conv4_b3,  4, 1, 2, 1, 2, 2, ACT_RELU, false, 2, true, 2)    // 128->128 + pool 2x2: 4x16 px
 POCR_CONV3(conv56_b3, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true, 2)    // ->256: 5x16 px, NT 128, two workgroups per CU
@@ -245,7 +245,7 @@ int conv2_p2_fused8(ConvArgs a, hipStream_t st) {      // 8 x 16 pixels, three w
     return launch_conv(conv3x3_bf16x3_kernel<8, 1, 1, 1, 2, 2, ACT_RELU, false, 3, true, 3, 3, 1, 1, false, 2, true, true, true>, 8, 16, 64, 256, a, st);
 }
 // experiment knob (POCR_P2_ALT_TILES = bit mask over conv2 .. conv7 = bits 1 .. 6): the round-2 tiles
-POCR_CONVP(conv2_p2_alt,  4, 2, 2, 2, 2, 2, ACT_RELU, false, 3, false)
+POCR_CONVP(conv2_p2_alt,  4, 2, 2, 2, 2, 2, ACT_RELU, false, 2, false)
 POCR_CONVP(conv3_p2_alt,  5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
 POCR_CONVP(conv4_p2_alt,  4, 1, 2, 1, 2, 2, ACT_RELU, false, 2, true)
 POCR_CONVP(conv56_p2_alt, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
@@ -275,8 +275,22 @@ POCR_CONVPG(agg8_p2, 1, 3, 2, 1, ACT_LEAKY, 2, 8, true)
         return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT_RELU, false, MINW, BDIR, 3, 3, 1, 1, true>, \
                            TH, 16 * MW, NS * (4 / WM) * 16, 256, a, st);                                           \
     }
-POCR_CONV3U(pn_up128_b3, 5, 1, 2, 1, 2, true)       // NT 128
-POCR_CONV3U(pn_up64_b3, 4, 4, 4, 4, 2, false)       // NT 64 (d1, d0: 64 output channels), waves split the pixels
+// decoder layers with 256 / 128 output channels: 5 x 16 pixels x 64 channels, weights straight from L2 (f16x2: halo-row streaming);
+// the 128-channel tile of round 3 kept 8 B of scratch per lane in its f16x2 build and is 3 % slower (profiles/r04_parsenet_up64.txt)
+#define POCR_CONV3U2(name, TH, MW, NS, WM, MINW, BDIR, NS3)                                                         \
+    int name(ConvArgs a, hipStream_t st) {                                                                         \
+        if (conv_split() == 2)                                                                                     \
+            return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, 1, 1, ACT_RELU, false, MINW, BDIR, 3, 3, 1, 1, true, 2>, \
+                               TH, 16 * MW, NS * (4 / WM) * 16, 256, a, st);                                       \
+        return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS3, WM, 1, 1, ACT_RELU, false, MINW, BDIR, 3, 3, 1, 1, true>, \
+                           TH, 16 * MW, NS3 * (4 / WM) * 16, 256, a, st);                                          \
+    }
+POCR_CONV3U2(pn_up128_b3, 5, 1, 1, 1, 2, true, 2)   // f16x2: NT 64; bf16x3: NT 128 as before
+// d1 / d0 (64 output channels): 10 x 16 pixels, weights straight from L2, halo-row streaming - 230 registers, no scratch; 1.86 ms per
+// 4k x 3k page against 2.62 with the 4 x 64-pixel tile of round 3, which spilled 456 B per lane (profiles/r04_parsenet_up64.txt)
+POCR_CONV3U(pn_up64_b_b3, 10, 1, 1, 1, 2, true)
+POCR_CONV3U(pn_up64_a_b3, 4, 2, 2, 2, 2, false)     // 4 x 32 pixels, waves 2 (pixels) x 2 (channels), LDS weights (the bf16x3 build: row streaming is f16x2 only): 198 registers
+int pn_up64_b3(ConvArgs a, hipStream_t st) { return conv_split() == 2 ? pn_up64_b_b3(a, st) : pn_up64_a_b3(a, st); }
 POCR_CONV3G(agg4_b3, 1, 3, 4, 1, ACT_LEAKY, 1, 4, false)
 POCR_CONV3G(agg5_b3, 1, 3, 4, 1, ACT_LEAKY, 1, 5, false)
 POCR_CONV3G(agg6_b3, 1, 3, 2, 1, ACT_LEAKY, 1, 6, false)

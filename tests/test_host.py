@@ -258,3 +258,41 @@ def test_labels_to_strings_vectorised_equals_per_symbol_join():
     multi[4] = "ch"
     assert labels_to_strings(lab, lens, multi) == ["".join(multi[c] for c in lab[i, :lens[i]]) for i in range(64)]
     assert labels_to_strings(np.zeros((0, 4), np.int32), np.zeros(0, np.int32), chars) == []
+
+
+def test_no_kernel_of_the_library_spills():
+    """Every kernel of the shipped library fits its register budget: `.private_segment_fixed_size` (scratch bytes per lane)
+    is 0 for all of them (one layout-network tile spilled 484 B per lane).  Read from the gfx950 code
+    object embedded in libpocr_hip.so (clang offload bundle) with llvm-readelf; skipped where the ROCm tool is absent."""
+    import re
+    import struct
+    import subprocess
+    import tempfile
+    from pero_ocr_amd import _native
+    tool = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    so = os.path.join(os.path.dirname(_native.__file__), _native.LIB_NAME)
+    if not os.path.exists(tool) or not os.path.exists(so):
+        pytest.skip("llvm-readelf or the built library is not here")
+    data = open(so, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    at = data.find(magic)
+    assert at >= 0
+    n = struct.unpack_from("<Q", data, at + len(magic))[0]
+    p, elf = at + len(magic) + 8, None
+    for _ in range(n):
+        off, size, tlen = struct.unpack_from("<QQQ", data, p)
+        p += 24
+        triple = data[p:p + tlen].decode()
+        p += tlen
+        if "gfx950" in triple:
+            elf = data[at + off:at + off + size]
+    assert elf, "no gfx950 code object in the library"
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(elf)
+        f.flush()
+        notes = subprocess.run([tool, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+    names = re.findall(r"\.name:\s*(\S+)", notes)
+    scratch = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", notes)]
+    assert len(scratch) >= 100, len(scratch)
+    bad = [(nm, s) for nm, s in zip([x for x in names if x.startswith("_Z")], scratch) if s]
+    assert max(scratch) == 0, bad[:5]
