@@ -692,11 +692,15 @@ def main():
         result.update(shape_rccl_fields(result, rccl_fields, collective))
         if w_pad is not None:
             traffic = None          # HBM bytes per launch of the dominant kernel, from the committed PMC passes
-            pmc_file = {2: "r03_pmc_summary.json", 3: "r02_pmc_summary.json", 0: "pmc_summary.json"}[split]
+            pmc_meta = {}
+            pmc_file = {2: "r04_pmc_summary.json", 3: "r02_pmc_summary.json", 0: "pmc_summary.json"}[split]
+            if not os.path.exists(os.path.join(REPO, "profiles", pmc_file)):
+                pmc_file = "r03_pmc_summary.json"
             dom_sig = {2: "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false, 2, true, true",
                        3: "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false>", 0: "5, 1, 4, 4, 16, 1, 1, 2, true"}[split]
             try:
                 pmc = json.load(open(os.path.join(REPO, "profiles", pmc_file)))
+                pmc_meta = pmc.pop("_meta", {})
                 for kname, ctr in pmc.items():
                     if dom_sig in kname and "hbm_bytes_per_launch" in ctr and args.workload == "c2":
                         traffic = ctr["hbm_bytes_per_launch"]
@@ -715,6 +719,8 @@ def main():
                 "frac": round(dom_tf / peak, 4), "traffic": traffic,
                 "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (KiB -> B; gfx950 FETCH_SIZE x2 correction) from "
                                 f"separate rocprofv3 --pmc passes of this bench, profiles/{pmc_file}",
+                "traffic_source_head": pmc_meta.get("head", "") if traffic is not None else None,
+                "traffic_library_source_hash": pmc_meta.get("library_source_hash", "") if traffic is not None else None,
                 "flops_per_launch": fl[dom] * n_lines, "avg_launch_ms": round(ms[dom], 4),
                 "peak_dtype": {2: "algorithmic fp32 FLOPs on the f16 MFMA pipe: operands as two f16 planes, 3 v_mfma_f32_16x16x32_f16 per 32-deep "
                                   "block -> ceiling = 2500 TFLOP/s dense f16 / 3; executed MFMA rate = 3 x achieved",

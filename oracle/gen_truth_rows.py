@@ -30,13 +30,19 @@ def main(name):
     net = model_oracle.OracleNet(spec, weights).double()
     torch.set_num_threads(os.cpu_count() or 1)
     out = [None] * g.n
+    st_colmax, st_colmean, st_rowlse = [None] * g.n, [None] * g.n, [None] * g.n
     for k, (ids, mw) in enumerate(g.plan):
         batch = engine_oracle.assemble_batch(crops, ids, spec.height, mw, 480 * g.batch_size)
         with torch.no_grad():
             x = (torch.from_numpy(np.ascontiguousarray(batch)).double() / 255.0).permute(0, 3, 1, 2)
             nct = net(x).numpy()
         for j, i in enumerate(ids):
-            out[i] = nct[j].T[g.sample_rows[i]]
+            tc = nct[j].T                                   # [T, C] float64
+            out[i] = tc[g.sample_rows[i]]
+            # full-tensor statistics in exact arithmetic (1-Lipschitz in the max norm: tests/test_gpu_parity.py
+            # _check_full_tensor_stats): per class max / mean over the frames, per frame logsumexp
+            st_colmax[i], st_colmean[i] = tc.max(axis=0), tc.mean(axis=0)
+            st_rowlse[i] = np.logaddexp.reduce(tc, axis=1)
         if k % 20 == 0:
             print(f"chunk {k}/{len(g.plan)}", flush=True)
     rows64 = np.concatenate(out)
@@ -47,6 +53,12 @@ def main(name):
     arrays = dict(np.load(path))
     arrays.pop("rows64_all", None)
     arrays["rows64_delta16"] = (ref.astype(np.float64) - rows64.astype(np.float64)).astype(np.float16)
+    if "colmax" in arrays:      # the float64 statistics as float16(reference statistic - float64 statistic), like the rows
+        arrays["colmax64_delta16"] = (arrays["colmax"].astype(np.float64) - np.stack(st_colmax)).astype(np.float16)
+        arrays["colmean64_delta16"] = (arrays["colmean"].astype(np.float64) - np.stack(st_colmean)).astype(np.float16)
+        arrays["rowlse64_delta16"] = (arrays["rowlse"].astype(np.float64) - np.concatenate(st_rowlse)).astype(np.float16)
+        print("reference vs float64 statistics: colmax %.3e colmean %.3e rowlse %.3e" % tuple(
+            float(np.abs(arrays[k].astype(np.float64)).max()) for k in ("colmax64_delta16", "colmean64_delta16", "rowlse64_delta16")))
     np.savez_compressed(path, **arrays)
 
 

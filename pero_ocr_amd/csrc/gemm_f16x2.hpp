@@ -328,12 +328,17 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
     (void)NST;
 }
 
+// Workgroups of a launch: one per CU, less where that changes nothing - every XCD walks ceil(row tiles / 8) x column tiles in
+// rounds of its workgroups, and the smallest number of workgroups per XCD that needs no more ROUNDS finishes at the same time
+// while leaving CUs to whatever else runs on the GPU (the other launch's convolutions): the aggregation conv of config 2 has
+// 576 tiles = 2.25 rounds of 256 workgroups -> 192 workgroups x 3 tiles.
 inline int gemm_f16x2_grid(int M, int N, int n_cus) {
     const int mt = (M + kGemmBM - 1) / kGemmBM, nt = N / kGemmBN;
-    const long tiles = (long)mt * nt;
-    int g = n_cus / 8 * 8;
-    while (g > 8 && (long)(g - 8) >= tiles) g -= 8;      // fewer tiles than workgroups: shrink in whole XCD rounds
-    return g;
+    const int per_xcd_max = n_cus / 8 > 0 ? n_cus / 8 : 1;
+    const long q = (long)((mt + 7) / 8) * nt;                         // tiles of the busiest XCD
+    const long rounds = (q + per_xcd_max - 1) / per_xcd_max;
+    const long per_xcd = rounds > 0 ? (q + rounds - 1) / rounds : 1;
+    return (int)(8 * (per_xcd > 0 ? per_xcd : 1));
 }
 
 }  // namespace pocr

@@ -37,6 +37,17 @@ def main(paths):
             c["lds_bank_conflict_share"] = c["SQ_LDS_BANK_CONFLICT"] / max(1.0, c["SQ_LDS_IDX_ACTIVE"])
             if "GRBM_GUI_ACTIVE_LDS" in c:
                 c["lds_util"] = c["SQ_LDS_IDX_ACTIVE"] / (256.0 * c["GRBM_GUI_ACTIVE_LDS"] / 8.0)
+    # which sources the passes ran on: POCR_SOURCE_HEAD (the evidence script exports `git rev-parse HEAD` of the build container;
+    # the GPU box has no .git) and the source hash of the library that ran (__graft_entry__.built_hash)
+    import os
+    meta = {"head": os.environ.get("POCR_SOURCE_HEAD", ""), "library_source_hash": ""}
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import __graft_entry__ as ge
+        meta["library_source_hash"] = ge.built_hash()
+    except Exception:
+        pass
+    out["_meta"] = meta
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
 
 
