@@ -63,6 +63,9 @@ constexpr int kGemmLdsU = 3 * kGemmStageU + kGemmBiasMax / 4;
 #ifndef POCR_GEMM_SPLIT
 #define POCR_GEMM_SPLIT 0            // where a stage's six DMA requests are issued: 0 all in the memory phase, 1 the B pieces there and the A pieces between the MFMA groups, 2 all between the MFMA groups
 #endif
+#ifndef POCR_GEMM_PRIO
+#define POCR_GEMM_PRIO 0             // 1: s_setprio(1) around a stage's MFMAs (the multiplying wave ahead of its partner's memory phase)
+#endif
 #ifndef POCR_GEMM_A_AUX
 #define POCR_GEMM_A_AUX 2            // cache policy of the A pieces: 2 = nt (streamed: the weights, re-read by every row tile, keep their place in L2), 0 = default
 #endif
@@ -296,6 +299,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
 #pragma unroll
             for (int n = 0; n < 4; ++n) { acc[m][n][0] += __builtin_bit_cast(float, ah[m][0] ^ bh[n][0]); acc2[m][n][0] += __builtin_bit_cast(float, al[m][0] ^ bl[n][0]); }
 #else
+#if POCR_GEMM_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #if !(POCR_GEMM_DBG & 1)
@@ -309,6 +315,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc2[m][n] = POCR_MFMA_F16(bl[n], ah[m], acc2[m][n]);
         }
+#if POCR_GEMM_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #if !(POCR_GEMM_DBG & 1)
         if constexpr (POCR_GEMM_SPLIT >= 1) advance();
 #endif

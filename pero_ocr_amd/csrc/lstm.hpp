@@ -85,18 +85,11 @@ __device__ __forceinline__ void lstm_load_w_f16x2(const void *whh2, int dir, int
     }
 }
 
-// hrow: the lane's line of h_{s-1} (H floats); NT: read with L1-bypassing loads (resident kernel).  acc = this wave's partial gates.
-template <int KPW, bool NT>
-__device__ __forceinline__ void lstm_gemm_f16x2(const float *hrow, int wave, int kq, const LstmW2<KPW> &w, f32x4 (&acc)[4]) {
+// The MFMA part: x0 / x1 = the lane's 8 values of h_{s-1} per K block (wave w: blocks w, w + 4, ...), split here.  acc = this wave's partial gates.
+template <int KPW>
+__device__ __forceinline__ void lstm_mfma_f16x2(const f32x4 (&x0)[(2 * KPW + 3) / 4], const f32x4 (&x1)[(2 * KPW + 3) / 4], int wave,
+                                                const LstmW2<KPW> &w, f32x4 (&acc)[4]) {
     constexpr int NB = 2 * KPW, QB = (NB + 3) / 4;
-    f32x4 x0[QB], x1[QB];
-#pragma unroll
-    for (int q = 0; q < QB; ++q) {
-        const int blk = min(wave + 4 * q, NB - 1);
-        const f32x4 *p = reinterpret_cast<const f32x4 *>(hrow + blk * 32 + kq * 8);
-        if constexpr (NT) { x0[q] = __builtin_nontemporal_load(p); x1[q] = __builtin_nontemporal_load(p + 1); }
-        else { x0[q] = p[0]; x1[q] = p[1]; }
-    }
     f32x4 main_[4], cross[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) { main_[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; cross[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -116,6 +109,21 @@ __device__ __forceinline__ void lstm_gemm_f16x2(const float *hrow, int wave, int
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = main_[g] + cross[g] * (1.0f / kF16x2Scale);
+}
+
+// hrow: the lane's line of h_{s-1} (H floats) in global memory; NT: read with L1-bypassing loads (resident kernel).
+template <int KPW, bool NT>
+__device__ __forceinline__ void lstm_gemm_f16x2(const float *hrow, int wave, int kq, const LstmW2<KPW> &w, f32x4 (&acc)[4]) {
+    constexpr int NB = 2 * KPW, QB = (NB + 3) / 4;
+    f32x4 x0[QB], x1[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int blk = min(wave + 4 * q, NB - 1);
+        const f32x4 *p = reinterpret_cast<const f32x4 *>(hrow + blk * 32 + kq * 8);
+        if constexpr (NT) { x0[q] = __builtin_nontemporal_load(p); x1[q] = __builtin_nontemporal_load(p + 1); }
+        else { x0[q] = p[0]; x1[q] = p[1]; }
+    }
+    lstm_mfma_f16x2<KPW>(x0, x1, wave, w, acc);
 }
 
 // layer output y[row][2H]: fp32, or split once here into the two f16 planes the next projection's MFMAs read (P2, conv_bf16x3.hpp)

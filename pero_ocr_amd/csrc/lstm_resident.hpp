@@ -34,6 +34,9 @@
 #include "conv_igemm.hpp"
 #include "lstm.hpp"
 
+#ifndef POCR_LSTM_PREFETCH
+#define POCR_LSTM_PREFETCH 1         // the NEXT slice-step's hidden state is copied into LDS (global_load_lds) while the current one computes (f16x2, SL >= 2)
+#endif
 #ifndef POCR_LSTM_RES_DBG
 #define POCR_LSTM_RES_DBG 0          // 1: workgroup 0 accumulates cycles per phase into err[8..] (timing experiments only)
 #endif
@@ -66,8 +69,15 @@ constexpr int kXccIdGetreg = (3 << 11) | (0 << 6) | 20;      // s_getreg_b32 HW_
 template <int KPW, int SL>
 __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs a) {
     constexpr int H = 64 * KPW, KGT = H / 16, UG = KGT;
-    __shared__ float part[4 * 4 * 64 * 4];      // [wave][gate][lane][reg]
-    __shared__ int s_fast, s_abort;
+    // ONE shared object (a second one makes hipcc drain the LDS-DMA queue before every ds_read, gemm_f16x2.hpp):
+    // [part: wave x gate x lane x reg partial sums | hpre: the NEXT slice-step's h_{s-1}, 16 rows of H floats + 4 pad, landed by LDS-DMA | xl | flags]
+    constexpr int HP = H + 4;                   // row pitch of the landing zone in floats: +16 bytes, so the 16 rows of an MFMA A fragment hit 16 different bank groups
+    constexpr int PART_F = 4 * 4 * 64 * 4, HPRE_F = (POCR_LSTM_PREFETCH && SL >= 2 && H == 256) ? 16 * HP : 0;
+    constexpr int XL_F = SL * 1024;             // xl: the gate pre-activations x of each slice's next step ([slice][wave][lane][4]: every wave lands and reads its own 1 KB)
+    __shared__ float smem[PART_F + HPRE_F + XL_F + 4];
+    float *part = smem, *hpre = smem + PART_F, *xl = smem + PART_F + HPRE_F;
+    int &s_fast = *reinterpret_cast<int *>(smem + PART_F + HPRE_F + XL_F), &s_abort = *reinterpret_cast<int *>(smem + PART_F + HPRE_F + XL_F + 1);
+    int &s_pref = *reinterpret_cast<int *>(smem + PART_F + HPRE_F + XL_F + 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int b = blockIdx.x, xcd = b & 7, k = b >> 3;
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
     const int unit = ug * 16 + u;
     int Ti[SL], Ts[SL];
     size_t row0[SL];
-    float cprev[SL], xg[SL][4];
+    float cprev[SL];
 #pragma unroll
     for (int j = 0; j < SL; ++j) {
         const int slice = sg * SL + j, line = slice * 16 + i;
@@ -123,17 +133,24 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
         Ti[j] = have && line < a.n ? (a.line_T ? a.line_T[line] : a.T) : 0;
         row0[j] = a.row_off ? (size_t)a.row_off[min(line, a.n - 1)] : (size_t)line * a.T;
         cprev[j] = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xg[j][g] = 0.f;
     }
     // gate pre-activations of (slice j, step s): requested a full round ahead, so they are in registers when the gates need them
+    // gate pre-activations x of (slice j, step s): copied into LDS by the load unit ONE ROUND AHEAD (global_load_lds: no result
+    // registers - the compiler would put a drain of the whole load queue in front of their first use, and with it the latency
+    // of the request just made: xproj is 302 MB, served by MALL / HBM).  One piece per wave: lane (line 4 wave + (lane >> 4),
+    // gate (lane >> 2) & 3, quarter lane & 3) fetches four consecutive units, so thread (line i, unit u) later reads what its OWN
+    // wave landed - no barrier, only that wave's counted vmcnt.  Finished / padding lines fetch a clamped row (never used):
+    // every wave issues exactly one piece per call, which the counted waits rely on.
     auto load_x = [&](int j, int s) {
-        if (s < Ti[j]) {
-            const int t = dir == 0 ? s : Ti[j] - 1 - s;
-            const float *xp = a.xproj + (row0[j] + (size_t)t) * (8 * H) + (size_t)dir * 4 * H + unit;
+        const int tl = max(Ti[j], 1);
+        const int t = min(max(dir == 0 ? s : Ti[j] - 1 - s, 0), tl - 1);
+        const float *xp = a.xproj + (row0[j] + (size_t)t) * (8 * H) + (size_t)dir * 4 * H + (size_t)((lane >> 2) & 3) * H + ug * 16 + (lane & 3) * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)xp,
+                                         (__attribute__((address_space(3))) void *)(xl + (j * 4 + wave) * 256), 16, 0, 0);
+    };
+    auto read_x = [&](int j, float (&x)[4]) {              // thread (i, u): gate g of unit u of line i
 #pragma unroll
-            for (int g = 0; g < 4; ++g) xg[j][g] = xp[(size_t)g * H];
-        }
+        for (int g = 0; g < 4; ++g) x[g] = xl[(j * 4 + wave) * 256 + ((((lane >> 4) * 4 + g) * 4 + ((lane & 15) >> 2)) * 4) + (lane & 3)];
     };
     // W_hh fragments of this unit group, resident for the whole layer (the step kernel re-reads them every step)
     const bool f16 = a.whh2 != nullptr;
@@ -170,16 +187,49 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
             }
         }
     };
+    // A slice-step's stores (its piece of h_s, the layer output y) are ISSUED at the start of the next slice-step, behind that
+    // step's wait: in front of a prefetched slice-step only the four x loads are then younger than the LDS-DMA pieces, and the
+    // wait can be counted (vmcnt(4)) instead of a drain that would also sit out the x loads' HBM latency and the stores' acknowledgement.
+    float d_hn = 0.f;
+    float *d_hdst = nullptr;
+    size_t d_row = 0;
+    bool d_y = false;
+    auto flush_stores = [&]() {
+        if (d_hdst) { *d_hdst = d_hn; d_hdst = nullptr; }
+        if (d_y) { lstm_store_y(a.y, d_row, 2 * H, dir * H + unit, d_hn, a.y_p2 != 0); d_y = false; }
+    };
     auto publish_pending = [&]() {
+        flush_stores();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's state store is acknowledged by L2
         __syncthreads();                                       // ... and everybody's
         bump(pend);
         pend = nullptr;
     };
+    // Look-ahead (SL >= 2, f16x2): while slice-step (j, s) computes, the state h_{s'-1} of the NEXT slice-step (j', s') of this
+    // workgroup - published two or more slice-steps ago when several slices take turns - is copied into LDS by the load unit:
+    // thread 0 requests that slice's counter at the start of the step (one L2 read, consumed behind the MFMAs), and if every
+    // member has published, the four waves each issue 4 LDS-DMA pieces (one 1 KB row of h per piece) behind the step's barrier.
+    // The next slice-step then starts with its operand in LDS: no counter poll, no L2 round trip for h (profiles/r03_lstm_resident.txt
+    // section 8: wait 580 + h loads ~1500 of a slice-step's ~5000 cycles).  Not ready (a single slice left, the first step): the
+    // blocking path below, as before.  Same values, same MFMAs: bit-identical.
+    constexpr bool PREF = POCR_LSTM_PREFETCH && SL >= 2 && H == 256;       // (one 1 KB LDS-DMA piece = one row of h)
+    bool have_pre = false;                                     // hpre holds h_{s-1} of the slice-step that starts now
     for (int s = 0; s < Tmax; ++s) {
 #pragma unroll
         for (int j = 0; j < SL; ++j) {
             if (s >= Ts[j]) continue;                          // (uniform over the group: slice_T)
+            // the slice-step after this one (iteration order), if any
+            int ns = -1, nj = 0;
+            if constexpr (PREF) {
+#pragma unroll
+                for (int q = SL - 1; q >= 0; --q) if (q > j && s < Ts[q]) { ns = s; nj = q; }
+                if (ns < 0) {
+#pragma unroll
+                    for (int q = SL - 1; q >= 0; --q) if (s + 1 < Ts[q]) { ns = s + 1; nj = q; }
+                }
+            }
+            const bool use_pre = have_pre;
+            have_pre = false;
 #if POCR_LSTM_RES_DBG
             if (b == 0 && tid == 0) t0 = __builtin_readcyclecounter();
 #endif
@@ -193,7 +243,15 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
             if (pend == sync) { publish_pending(); }
             if (s == 0) __syncthreads();                       // (`part`: the previous slice's gate reads)
             // ---- wait for h_{s-1} of the whole slice
-            if (s > 0) {
+            if (use_pre) {
+                // this wave's four LDS-DMA pieces of h have landed (and every older x piece): everything but the ONE x piece requested behind them ...
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                __syncthreads();                                       // ... and everybody's
+                flush_stores();
+            } else {
+                flush_stores();
+            }
+            if (!use_pre && s > 0) {
                 if (tid == 0) {
                     const unsigned want = (unsigned)UG * (unsigned)s;
                     int spins = 0;
@@ -206,14 +264,29 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
                 __syncthreads();
                 if (s_abort) return;
             }
+            if (!use_pre) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this slice-step's x piece (requested at the slice's previous turn) and the stores just issued
+            float xcur[4];
+            read_x(j, xcur);                                   // (before this slice's NEXT piece is requested, behind the barrier below, into the same 1 KB)
             POCR_TICK(0);                                      // wait for the hand-off
+            // look-ahead poll of the next slice-step's counter: requested now, looked at behind the MFMAs
+            unsigned look = 0u;
+            const bool look_ok = PREF && f16 && ns > 0 && !(ns == s + 1 && nj == j);
+            unsigned *nsync = a.sync + (size_t)((sg * SL + nj) * 2 + dir) * 32;
+            if (look_ok && tid == 0) look = __hip_atomic_load(nsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             f32x4 acc[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            float xcur[4];
+            if (s > 0 && f16 && use_pre) {
+                constexpr int NB = 2 * KPW, QB = (NB + 3) / 4;
+                f32x4 x0[QB], x1[QB];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) xcur[g] = xg[j][g];
-            if (s > 0 && f16) {
+                for (int q = 0; q < QB; ++q) {
+                    const int blk = min(wave + 4 * q, NB - 1);
+                    const f32x4 *pp = reinterpret_cast<const f32x4 *>(hpre + li * HP + blk * 32 + kq * 8);
+                    x0[q] = pp[0]; x1[q] = pp[1];
+                }
+                lstm_mfma_f16x2<KPW>(x0, x1, wave, w2, acc);
+            } else if (s > 0 && f16) {
                 lstm_gemm_f16x2<KPW, true>(hc + (size_t)(s & 1) * 16 * H + (size_t)li * H, wave, kq, w2, acc);
             } else if (s > 0) {
                 const float *hrow = hc + (size_t)(s & 1) * 16 * H + (size_t)li * H;
@@ -236,9 +309,30 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
             // The previous slice-step's state store is published HERE, one slice-step late: its L2 acknowledgement has had this
             // step's wait + GEMM to arrive, and the barrier that orders everybody's acknowledgement is the one the LDS reduction
             // needs anyway (before: acknowledgement + a barrier of its own behind every store, 400-2000 cycles of a ~5 k slice-step)
+            if constexpr (PREF) {
+                if (tid == 0) {
+                    const bool ready = look_ok && look >= (unsigned)UG * (unsigned)ns;
+                    if (ready && !fast) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    s_pref = ready ? 1 : 0;
+                }
+            }
             if (pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            __syncthreads();                                   // (also: every wave has read its fragments of hpre - it may be overwritten)
             if (pend) { bump(pend); pend = nullptr; }
+            if constexpr (PREF) {
+                if (s_pref) {
+                    // h_{ns-1} of slice nj: 16 rows of H floats = KPW * 4 pieces of 1 KB (KPW = 4: one row per piece), four per wave
+                    const float *src = a.hbuf + (size_t)((sg * SL + nj) * 2 + dir) * 2 * 16 * H + (size_t)(ns & 1) * 16 * H;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int piece = wave * 4 + q;                    // = the row of h (H = 256: 1 KB)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)piece * H + lane * 4),
+                                                         (__attribute__((address_space(3))) void *)(hpre + piece * HP), 16, 0, 2 /* nt: served by L2, like the direct loads */);
+                    }
+                    have_pre = true;
+                }
+            }
+            asm volatile("" ::: "memory");                     // the x piece below stays BEHIND the h pieces (the counted wait assumes that order)
             load_x(j, s + 1);                                  // x of this slice's next step: due at this slice's next turn
             POCR_TICK(2);                                      // barrier
             float gate[4];
@@ -257,13 +351,15 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
                 cprev[j] = cn;
             }
             POCR_TICK(3);                                      // gates
+            d_hn = hn;
             if (s + 1 < Ts[j]) {
-                hc[(size_t)((s + 1) & 1) * 16 * H + (size_t)i * H + unit] = hn;
-                pend = sync;                                   // published behind the next slice-step's GEMM (above)
+                d_hdst = hc + (size_t)((s + 1) & 1) * 16 * H + (size_t)i * H + unit;
+                pend = sync;                                   // issued at the start of the next slice-step, published behind its GEMM (above)
             }
-            if (live) lstm_store_y(a.y, row, 2 * H, dir * H + unit, hn, a.y_p2 != 0);      // (after the hand-off: nobody waits for this store)
+            d_y = live; d_row = row;
         }
     }
+    flush_stores();
     if (pend) publish_pending();
 #if POCR_LSTM_RES_DBG
     if (b == 0 && tid == 0)

@@ -29,6 +29,8 @@ struct pocr_parsenet {
     size_t pin_in_cap = 0, pin_out_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
+    DevBuf range;                          // f16x2 range guard (conv_igemm.hpp): one set of 8 words per conv layer, 1 .. 18 (e1 .. d0)
+    unsigned *range_host = nullptr;
 };
 
 namespace {
@@ -67,6 +69,8 @@ void pocr_parsenet_destroy(pocr_parsenet *p) {
     for (auto &b : p->y) b.release();
     if (p->pin_in) (void)locked_host_free(p->pin_in);
     if (p->pin_out) (void)locked_host_free(p->pin_out);
+    if (p->range_host) (void)locked_host_free(p->range_host);
+    p->range.release();
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -262,8 +266,21 @@ static int parsenet_get_maps_impl(pocr_parsenet *p, const uint8_t *img_hwc, int3
         hipLaunchKernelGGL(conv1_u8_kernel<false>, dim3(c1.n_ptiles), dim3(256), 0, st, c1);
         HIP_TRY(hipGetLastError());
     }
+    // f16x2 range guard: the activations of this network stay fp32 in HBM and are split inside every consumer, so what a layer
+    // writes must stay inside f16's range like the recogniser's (pocr_hip.hip: range_verdict) - here an excursion is an ERROR
+    // (no automatic re-run: POCR_CONV_SPLIT=3 runs the network on bf16x3)
+    const bool guard = conv_split() == 2;
+    int n_guarded = 0;
+    if (guard) {
+        if (!p->range.p) {
+            if (p->range.reserve(24 * 8 * sizeof(unsigned))) return 1;
+            HIP_TRY(locked_host_malloc(reinterpret_cast<void **>(&p->range_host), 24 * 8 * sizeof(unsigned), hipHostMallocDefault));
+        }
+        HIP_TRY(hipMemsetAsync(p->range.p, 0, 24 * 8 * sizeof(unsigned), st));
+    }
     auto conv = [&](int (*fn)(ConvArgs, hipStream_t), const PnLayer &L, const float *x, const float *x2, int cin_up, float *y, int Hc, int Wc) {
         ConvArgs a{};
+        if (guard && n_guarded < 24) a.range_max = p->range.as<unsigned>() + 8 * n_guarded++;
         a.x = x; a.x2 = x2; a.cin_up = cin_up; a.n = 1; a.H = Hc; a.W = Wc; a.Ho = Hc; a.Wo = Wc; a.cin = L.cin;
         a.cout16 = L.cout16; a.cout_valid = L.cout; a.out_stride = L.cout;
         a.wfrag = L.w.as<float>(); a.bias = L.b.as<float>(); a.y = y;
@@ -306,7 +323,16 @@ static int parsenet_get_maps_impl(pocr_parsenet *p, const uint8_t *img_hwc, int3
         p->pin_out_cap = out_bytes;
     }
     HIP_TRY(hipMemcpyAsync(p->pin_out, p->out.p, out_bytes, hipMemcpyDeviceToHost, st));
+    if (guard) HIP_TRY(hipMemcpyAsync(p->range_host, p->range.p, 24 * 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (guard)
+        for (int k = 0; k < n_guarded; ++k) {
+            unsigned m = 0;
+            for (int j = 0; j < 8; ++j) m = std::max(m, p->range_host[8 * k + j]);
+            if (m >= 0x477fe000u || (m != 0 && m < 0x39000000u))
+                return fail("layout network: conv layer %d left the range of the default f16x2 arithmetic (%s) - set POCR_CONV_SPLIT=3 (bf16x3, fp32's range)",
+                            k + 1, m >= 0x477fe000u ? "|x| >= 65504 or not finite" : "its whole activation lies below 2^-13");
+        }
     memcpy(out_hw5, p->pin_out, out_bytes);
     HIP_TRY(hipEventElapsedTime(&p->last_ms, p->ev0, p->ev1));
     return 0;

@@ -764,14 +764,38 @@ int run_network(pocr_engine *e, Slot &s) {
             HIP_TRY(hipGetLastError());
         }
     }
-    HIP_TRY(hipEventRecord(s.conv_done, st));
-    s.conv_done_valid = true;
-    HIP_TRY(hipStreamWaitEvent(s.seq_stream, s.conv_done, 0));
     if (prof) (void)hipEventRecord(s.ev_conv_end, st);
-    st = s.seq_stream;
+    mark(POCR_STAGE_LSTM);                // (on the conv stream: the sequence stage begins with the first projection, below)
+    // The FIRST BiLSTM layer's input projection depends on the features only: it runs HERE, on the conv stream, behind the
+    // aggregation conv and before the next launch's backbone may start - alone on the chip, 0.27 ms for a c2 chunk - instead
+    // of on the sequence stream, where its 256 persistent workgroups (147 KB of LDS each: a CU must drain both of its conv
+    // workgroups before one fits) took 0.55 ms next to the other slot's convolutions and held the recurrence back
+    // (profiles/r04_bench_c2_kernel_stats.txt).  POCR_PROJ0_ON_SEQ=1: as before.
+    static const bool proj0_early_env = !(getenv("POCR_PROJ0_ON_SEQ") && atoi(getenv("POCR_PROJ0_ON_SEQ")) != 0);
+    bool proj0_done = false, xproj_moved = false;
+    if (c.arch == POCR_ARCH_BLSTM && proj0_early_env && s.feat_is_p2) {
+        const int Hh0 = c.lstm_hidden;
+        const void *xp0 = s.xproj.p;
+        if (s.xproj.reserve((size_t)rows * 8 * Hh0 * sizeof(float))) return 1;
+        xproj_moved = xp0 != s.xproj.p;
+        GemmP2Args g{};
+        g.a = s.feat.p; g.w = e->proj_w[0].p; g.bias = e->proj_b[0].as<float>(); g.y = s.xproj.p;
+        g.M = rows; g.nk = E / 32; g.N16 = e->proj_cout16; g.n_valid = 8 * Hh0; g.ldy = 8 * Hh0; g.lda = (int64_t)E * 4;
+        gemm2_shape(e, g, rows, e->proj_cout16);
+        if (launch_gemm2<ACT_NONE, false, false>(e, g, st)) return 1;
+        proj0_done = true;
+    }
+    // POCR_SEQ_SAME_STREAM=1 (experiments; config 4, where both halves of a launch are MFMA-bound): the sequence stage stays
+    // on the conv stream and the next launch's backbone starts behind the WHOLE network - no two launches share the chip
+    static const bool seq_same_stream = getenv("POCR_SEQ_SAME_STREAM") && atoi(getenv("POCR_SEQ_SAME_STREAM")) != 0;
+    if (!seq_same_stream) {
+        HIP_TRY(hipEventRecord(s.conv_done, st));
+        s.conv_done_valid = true;
+        HIP_TRY(hipStreamWaitEvent(s.seq_stream, s.conv_done, 0));
+        st = s.seq_stream;
+    }
     const float *layer_in = s.feat.as<float>();
     int din = E;
-    mark(POCR_STAGE_LSTM);
     if (c.arch == POCR_ARCH_SA || c.arch == POCR_ARCH_S2S) {
     // ---- self-attention encoder (transformer.py:366-385)
     const int FF = c.sa_ff, heads = c.sa_heads, D = E / heads;
@@ -858,6 +882,11 @@ int run_network(pocr_engine *e, Slot &s) {
         }
         mark(POCR_STAGE_HEAD); mark(POCR_STAGE_CTC); mark(POCR_NUM_STAGES);
         if (guard) HIP_TRY(hipMemcpyAsync(s.range_host, s.range.p, kRangeWords * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        if (seq_same_stream) {
+            HIP_TRY(hipEventRecord(s.conv_done, st));
+            s.conv_done_valid = true;
+            HIP_TRY(hipStreamWaitEvent(s.seq_stream, s.conv_done, 0));
+        }
         return 0;
     }
     } else {
@@ -875,7 +904,7 @@ int run_network(pocr_engine *e, Slot &s) {
         }
         // (h_stride is baked into the captured launches too - as the ping-pong offset and the memset size - and can change
         // while the over-allocated buffer stays where it is)
-        bool moved = before[0] != s.xproj.p || before[1] != s.hbuf.p || before[2] != s.cbuf.p || stride_before != s.h_stride;
+        bool moved = xproj_moved || before[0] != s.xproj.p || before[1] != s.hbuf.p || before[2] != s.cbuf.p || stride_before != s.h_stride;
         for (int l = 0; l < c.lstm_layers; ++l) {
             const void *yb = s.lstm_y[l].p;
             if (s.lstm_y[l].reserve((size_t)rows * 2 * Hh * sizeof(float))) return 1;
@@ -957,7 +986,9 @@ int run_network(pocr_engine *e, Slot &s) {
     bool in_p2 = s.feat_is_p2;
     for (int l = 0; l < c.lstm_layers; ++l) {
         const bool y_p2 = l < s.lstm_p2_layers;
-        if (in_p2) {
+        if (l == 0 && proj0_done) {
+            // (already computed on the conv stream)
+        } else if (in_p2) {
             GemmP2Args g{};
             g.a = layer_in; g.w = e->proj_w[l].p; g.bias = e->proj_b[l].as<float>(); g.y = s.xproj.p;
             g.M = rows; g.nk = din / 32; g.N16 = e->proj_cout16; g.n_valid = 8 * Hh; g.ldy = 8 * Hh; g.lda = (int64_t)din * 4;
@@ -1086,6 +1117,11 @@ int run_network(pocr_engine *e, Slot &s) {
         mark(POCR_NUM_STAGES);
     }
     if (guard) HIP_TRY(hipMemcpyAsync(s.range_host, s.range.p, kRangeWords * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    if (seq_same_stream) {
+        HIP_TRY(hipEventRecord(s.conv_done, st));
+        s.conv_done_valid = true;
+        HIP_TRY(hipStreamWaitEvent(s.seq_stream, s.conv_done, 0));
+    }
     return 0;
 }
 

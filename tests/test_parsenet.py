@@ -140,3 +140,28 @@ def test_gpu_area_downsampling_and_engine_surface(tmp_path):
     assert out2.ndim == 3 and out2.shape[2] == 5 and 1 <= used2 <= 8
     with pytest.raises(RuntimeError, match="no CPU path"):
         tp.TorchParseNet(path, type("C", (), {"type": "cpu", "index": None})())
+
+
+@pytest.mark.gpu
+def test_gpu_layout_network_range_guard():
+    """The layout network's convolutions run in the f16x2 arithmetic too (fp32 activations, split inside every consumer): a
+    layer whose output leaves f16's range must not pass silently - get_maps raises and names POCR_CONV_SPLIT=3; the same
+    rescaled network (x 2^18 on one layer, 2^-18 on the next: the function is unchanged) is fine on bf16x3."""
+    from pero_ocr_amd import _native
+    if _native.conv_split() != 2:
+        pytest.skip("the range guard belongs to the f16x2 arithmetic")
+    meta, arrays = fixture()
+    w = dict(fixture_weights(meta, arrays))
+    names = [n for n, _ in ps.tensor_table() if n.endswith(".weight") and not n.startswith("head.")]
+    a, b = names[3], names[4]
+    w[a] = w[a] * np.float32(2.0 ** 18)
+    w[a.replace(".weight", ".bias")] = w[a.replace(".weight", ".bias")] * np.float32(2.0 ** 18)
+    w[b] = w[b] * np.float32(2.0 ** -18)
+    page = synth.make_page(11, 200, 300)
+    net = _native.NativeParseNet(ps.pack_weights(w), 0)
+    with pytest.raises(RuntimeError, match="POCR_CONV_SPLIT=3"):
+        net.get_maps(page, 1)
+    net.close()
+    ok = _native.NativeParseNet(ps.pack_weights(fixture_weights(meta, arrays)), 0)
+    assert check_page("small", meta, arrays, ok.get_maps(page, 1)) < MAP_TOL
+    ok.close()
