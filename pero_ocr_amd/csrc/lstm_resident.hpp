@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
     const int u = tid & 15, i = tid >> 4;
     const int unit = ug * 16 + u;
     int Ti[SL], Ts[SL];
-    size_t row0[SL];
+    int row0[SL];                                 // (first row of the thread's line: rows < 2^31)
     float cprev[SL];
 #pragma unroll
     for (int j = 0; j < SL; ++j) {
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
         const bool have = slice < n_slices;
         Ts[j] = have ? (a.slice_T ? a.slice_T[slice] : a.T) : 0;
         Ti[j] = have && line < a.n ? (a.line_T ? a.line_T[line] : a.T) : 0;
-        row0[j] = a.row_off ? (size_t)a.row_off[min(line, a.n - 1)] : (size_t)line * a.T;
+        row0[j] = a.row_off ? a.row_off[min(line, a.n - 1)] : line * a.T;
         cprev[j] = 0.f;
     }
     // gate pre-activations of (slice j, step s): requested a full round ahead, so they are in registers when the gates need them
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
     auto load_x = [&](int j, int s) {
         const int tl = max(Ti[j], 1);
         const int t = min(max(dir == 0 ? s : Ti[j] - 1 - s, 0), tl - 1);
-        const float *xp = a.xproj + (row0[j] + (size_t)t) * (8 * H) + (size_t)dir * 4 * H + (size_t)((lane >> 2) & 3) * H + ug * 16 + (lane & 3) * 4;
+        const float *xp = a.xproj + (size_t)(row0[j] + t) * (8 * H) + (size_t)dir * 4 * H + (size_t)((lane >> 2) & 3) * H + ug * 16 + (lane & 3) * 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)xp,
                                          (__attribute__((address_space(3))) void *)(xl + (j * 4 + wave) * 256), 16, 0, 0);
     };
@@ -192,11 +192,11 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
     // wait can be counted (vmcnt(4)) instead of a drain that would also sit out the x loads' HBM latency and the stores' acknowledgement.
     float d_hn = 0.f;
     float *d_hdst = nullptr;
-    size_t d_row = 0;
+    int d_row = 0;
     bool d_y = false;
     auto flush_stores = [&]() {
         if (d_hdst) { *d_hdst = d_hn; d_hdst = nullptr; }
-        if (d_y) { lstm_store_y(a.y, d_row, 2 * H, dir * H + unit, d_hn, a.y_p2 != 0); d_y = false; }
+        if (d_y) { lstm_store_y(a.y, (size_t)d_row, 2 * H, dir * H + unit, d_hn, a.y_p2 != 0); d_y = false; }
     };
     auto publish_pending = [&]() {
         flush_stores();
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
             float *hc = a.hbuf + (size_t)cl * 2 * 16 * H;     // [2][16][H]
             const bool live = s < Ti[j];
             const int t = dir == 0 ? s : Ti[j] - 1 - s;
-            const size_t row = row0[j] + (size_t)(live ? t : 0);
+            const int row = row0[j] + (live ? t : 0);
             // ---- a publication of THIS slice still pending (SL = 1, or the other slices of the group have finished): complete it now
             if (pend == sync) { publish_pending(); }
             if (s == 0) __syncthreads();                       // (`part`: the previous slice's gate reads)
