@@ -4,7 +4,8 @@
 // nb_layers x nn.TransformerEncoderLayer (post-norm, ReLU FFN, dropout 0, no attention mask).
 // The four projections of a layer run on conv_igemm_kernel in GEMM mode; this file has the rest:
 //   layernorm_kernel   y = LN(a [+ b]) * gamma + beta [+ pe[t]]      one wavefront per row
-//   attention_kernel   softmax(Q K^T / sqrt(d)) V per (line, head)    one wavefront per 16 queries
+//   attention_kernel   softmax(Q K^T / sqrt(d)) V per (line, head)    one wavefront per 16 queries (fp32 MFMA, fp32 q | k | v)
+//   attention_f16x2_kernel  the same on f16x2 MFMAs from P2 q | k | v      four wavefronts per 128 queries, K / V through LDS
 //
 // attention on v_mfma_f32_16x16x4_f32, no LDS, flash-style online softmax over 16-key blocks.
 // It computes TRANSPOSED tiles so that no cross-lane data movement is needed between the two GEMMs:
@@ -173,6 +174,206 @@ __global__ __launch_bounds__(64) void attention_kernel(const float *qkv, float *
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float t = ov[r]; range_note(rmax, t); }
                 *reinterpret_cast<f32x4 *>(op + 16 * dt) = ov;
+            }
+        }
+    }
+    range_publish(range_max, rmax, lane);
+}
+
+// ---- attention in the f16x2 arithmetic of the rest of the stack (conv_bf16x3.hpp): q | k | v arrive in the P2 layout (the
+// projection GEMM's P2 output), both products run on v_mfma_f32_16x16x32_f16 - three MFMAs per 32-deep block instead of
+// eight fp32 ones - and the probabilities are split in registers.  One workgroup = 128 queries of one (line, head): four
+// waves, two 16-query tiles each, so every K / V fragment read from LDS feeds six MFMAs.  Keys go by blocks of 32:
+//   S^T = K Q^T      A = K rows from the LDS image [chunk][plane][key][4 units], B = Q fragments held in registers
+//   O^T += V^T P^T   A = V^T from the LDS image [plane][d][32 keys], B = P^T = the S^T accumulators themselves
+// The reduction index of the second product is free, so position 8 kq + j of a V^T row holds key 16 (j >> 2) + 4 kq + (j & 3):
+// then registers {S^T tile 0: r = 0..3, S^T tile 1: r = 0..3} of a lane ARE its eight B-operand values, no data movement.
+// V is transposed on its way into LDS: a lane takes the same 8 channels of two consecutive keys (two 16-byte loads) and
+// stores eight (key, key + 1) f16 pairs.  The 16-byte units of a 64-byte image row are XORed with 3 on rows 8..15 of a
+// tile, which spreads the four non-contiguous 16-lane groups of ds_read_b128 over all banks.  Next block's K / V pieces
+// are requested before the current block's products (register staging), one barrier per block.
+// exp runs as v_exp_f32 on log2(e)-scaled scores; the running maximum only rescales the accumulators when it moved.
+template <int D, int QT>
+__global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(const void *qkv, void *out, int T_uniform, int E, float scale2,
+                                                                 const int32_t *line_T, const int32_t *row_off, unsigned *range_max) {
+    static_assert(D % 32 == 0 && D <= 128, "head dim must be a multiple of 32");
+    constexpr int DC = D / 32, DT = D / 16, KB = 32;        // QT: 16-query tiles per wave (2; 1 for D = 128, registers)
+    constexpr int K_IMG = KB * 64 + 64;          // one (chunk, plane) image; + 64 B: the planes' 16-byte stores on different banks
+    constexpr int K_BYTES = DC * 2 * K_IMG;
+    constexpr int V_IMG = D * 64 + 64;
+    constexpr int BUF = K_BYTES + 2 * V_IMG;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int head = blockIdx.y, line = blockIdx.z;
+    const int T = line_T ? line_T[line] : T_uniform;
+    const int qw = blockIdx.x * (4 * QT * 16);
+    if (qw >= T) return;                         // the grid is sized for the longest line (uniform for the workgroup)
+    const size_t row0 = row_off ? (size_t)row_off[line] : (size_t)line * T_uniform;
+    const size_t pitch = (size_t)E * 12;          // bytes of a q | k | v row
+    const char *base = static_cast<const char *>(qkv) + row0 * pitch;
+    const size_t q_off = (size_t)(head * D / 32) * 128, k_off = q_off + (size_t)E * 4, v_off = q_off + (size_t)E * 8;
+    const int q0 = qw + wave * (QT * 16);
+    const bool active = q0 < T;
+
+    u32x4 qh[QT][DC], ql[QT][DC];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const char *qp = base + (size_t)min(q0 + 16 * t + li, T - 1) * pitch + q_off + kq * 16;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            qh[t][c] = *reinterpret_cast<const u32x4 *>(qp + c * 128);
+            ql[t][c] = *reinterpret_cast<const u32x4 *>(qp + c * 128 + 64);
+        }
+    }
+    // staging assignment: K - DC 16-byte pieces per thread; V - key pairs, (128 DC) items over 256 threads
+    constexpr int VI = (128 * DC + 255) / 256;
+    u32x4 kreg[DC], vreg[VI][2];
+    auto request = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < DC; ++i) {
+            const int p = tid + 256 * i, key = p / (DC * 8), w = p % (DC * 8);
+            kreg[i] = *reinterpret_cast<const u32x4 *>(base + (size_t)min(k0 + key, T - 1) * pitch + k_off + (w >> 3) * 128 + (w & 7) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < VI; ++i) {
+            const int it = tid + 256 * i;
+            if (128 * DC >= 256 || it < 128 * DC) {
+                const int m = it & 15, cb = it >> 4;
+                const size_t o = v_off + (size_t)(cb >> 3) * 128 + (size_t)(cb & 7) * 16;
+                vreg[i][0] = *reinterpret_cast<const u32x4 *>(base + (size_t)min(k0 + 2 * m, T - 1) * pitch + o);
+                vreg[i][1] = *reinterpret_cast<const u32x4 *>(base + (size_t)min(k0 + 2 * m + 1, T - 1) * pitch + o);
+            }
+        }
+    };
+    auto deposit = [&](char *buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < DC; ++i) {
+            const int p = tid + 256 * i, key = p / (DC * 8), w = p % (DC * 8), u = w & 3;
+            *reinterpret_cast<u32x4 *>(buf + (w >> 2) * K_IMG + key * 64 + ((u ^ ((key & 8) ? 3 : 0)) * 16)) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VI; ++i) {
+            const int it = tid + 256 * i;
+            if (128 * DC >= 256 || it < 128 * DC) {
+                const int m = it & 15, cb = it >> 4, kq8 = cb & 3, plane = (cb >> 2) & 1, c = cb >> 3;
+                const int unit = ((m >> 1) & 3) ^ ((kq8 & 1) ? 3 : 0);
+                char *d = buf + K_BYTES + plane * V_IMG + (c * 32 + kq8 * 8) * 64 + unit * 16 + (m >> 3) * 8 + (m & 1) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {     // dword j of the two pieces = channels 2 j, 2 j + 1 of keys 2 m, 2 m + 1
+                    const unsigned a = vreg[i][0][j], b = vreg[i][1][j];
+                    *reinterpret_cast<unsigned *>(d + (2 * j) * 64) = (a & 0xffffu) | (b << 16);
+                    *reinterpret_cast<unsigned *>(d + (2 * j + 1) * 64) = (a >> 16) | (b & 0xffff0000u);
+                }
+            }
+        }
+    };
+
+    f32x4 o1[QT][DT], o2[QT][DT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { o1[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; o2[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) { m_run[t] = -INFINITY; l_run[t] = 0.f; }
+    const int swz = (li & 8) ? 3 : 0;
+    const int frag = li * 64 + ((kq ^ swz) * 16);         // this lane's 16 bytes inside a 16-row tile of either image
+
+    request(0);
+    deposit(smem);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < T; k0 += KB) {
+        const bool more = k0 + KB < T;
+        if (more) request(k0 + KB);
+        const char *buf = smem + cur * BUF;
+        if (active) {
+            // ---- S^T, two key tiles x QT query tiles
+            f32x4 s1[QT][2], s2[QT][2];
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) { s1[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; s2[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int c = 0; c < DC; ++c) {
+                    const u32x4 kh = *reinterpret_cast<const u32x4 *>(buf + (2 * c) * K_IMG + kt * 1024 + frag);
+                    const u32x4 kl = *reinterpret_cast<const u32x4 *>(buf + (2 * c + 1) * K_IMG + kt * 1024 + frag);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        s1[t][kt] = POCR_MFMA_F16(kh, qh[t][c], s1[t][kt]);
+                        s2[t][kt] = POCR_MFMA_F16(kh, ql[t][c], s2[t][kt]);
+                        s2[t][kt] = POCR_MFMA_F16(kl, qh[t][c], s2[t][kt]);
+                    }
+                }
+            // ---- online softmax: this lane holds keys k0 + 16 kt + 4 kq + r of query li
+            u32x4 ph[QT], pl[QT];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                float p[8], tmax = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = (s1[t][j >> 2][j & 3] + s2[t][j >> 2][j & 3] * (1.0f / kF16x2Scale)) * scale2;
+                    p[j] = (more || k0 + 16 * (j >> 2) + 4 * kq + (j & 3) < T) ? v : -INFINITY;
+                    tmax = fmaxf(tmax, p[j]);
+                }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run[t], tmax);         // finite: every block holds at least one valid key
+                const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);     // 0 on the first block
+                float psum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(p[j] - m_new); psum += p[j]; }
+                psum += __shfl_xor(psum, 16, 64);
+                psum += __shfl_xor(psum, 32, 64);
+                l_run[t] = l_run[t] * alpha + psum;
+                m_run[t] = m_new;
+                if (__any(alpha != 1.0f)) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) { o1[t][dt] *= alpha; o2[t][dt] *= alpha; }
+                }
+                u32x2 h0, l0, h1, l1;
+                split2_quad((f32x4){p[0], p[1], p[2], p[3]}, h0, l0);
+                split2_quad((f32x4){p[4], p[5], p[6], p[7]}, h1, l1);
+                ph[t] = (u32x4){h0[0], h0[1], h1[0], h1[1]};
+                pl[t] = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+            }
+            // ---- O^T += V^T P^T
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const u32x4 vh = *reinterpret_cast<const u32x4 *>(buf + K_BYTES + dt * 1024 + frag);
+                const u32x4 vl = *reinterpret_cast<const u32x4 *>(buf + K_BYTES + V_IMG + dt * 1024 + frag);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    o1[t][dt] = POCR_MFMA_F16(vh, ph[t], o1[t][dt]);
+                    o2[t][dt] = POCR_MFMA_F16(vh, pl[t], o2[t][dt]);
+                    o2[t][dt] = POCR_MFMA_F16(vl, ph[t], o2[t][dt]);
+                }
+            }
+        }
+        if (more) deposit(smem + (cur ^ 1) * BUF);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- O^T[d = 16 dt + 4 kq + r][q = li] / l  ->  out (P2) [row q][head * D + 16 dt + 4 kq + 0..3]
+    unsigned rmax = 0u;
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const int q = q0 + 16 * t + li;
+            if (q < T) {
+                const float inv = 1.0f / l_run[t];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const f32x4 ov = (o1[t][dt] + o2[t][dt] * (1.0f / kF16x2Scale)) * inv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float x = ov[r]; range_note(rmax, x); }
+                    u32x2 hh, ll;
+                    split2_quad(ov, hh, ll);
+                    u32x2 *d = reinterpret_cast<u32x2 *>(static_cast<char *>(out) + (row0 + q) * (size_t)E * 4 + p2_channel_bytes(head * D + 16 * dt + 4 * kq));
+                    d[0] = hh; d[8] = ll;
+                }
             }
         }
     }

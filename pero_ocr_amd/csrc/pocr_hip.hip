@@ -852,9 +852,19 @@ int run_network(pocr_engine *e, Slot &s) {
     for (int l = 0; l < c.sa_layers; ++l) {
         pocr_engine::SaLayer &L = e->sa[l];
         if (s.sa_y[l].reserve(xe)) return 1;
-        if (gemm(g2 ? s.sa_xp2.p : (const void *)xin, E, L.w_in, L.b_in, 3 * E, s.sa_qkv.p, false, g2, false)) return 1;
+        // att2: q | k | v leave the projection in P2 and attention runs on f16x2 MFMAs (encoder.hpp); POCR_ATT_FP32=1 keeps
+        // the fp32-MFMA kernel on fp32 q | k | v
+        static const bool att_fp32 = getenv("POCR_ATT_FP32") && atoi(getenv("POCR_ATT_FP32")) != 0;
+        const bool att2 = g2 && !att_fp32 && conv_split() == 2 && (D == 32 || D == 64 || D == 128);
+        if (gemm(g2 ? s.sa_xp2.p : (const void *)xin, E, L.w_in, L.b_in, 3 * E, s.sa_qkv.p, false, g2, att2)) return 1;
         const dim3 agrid((T + 15) / 16, heads, n);
         const float scale = 1.0f / sqrtf((float)D);
+        if (att2) {
+            const float scale2 = scale * 1.44269504088896340736f;
+#define POCR_ATT2(DD, QQ) hipLaunchKernelGGL((attention_f16x2_kernel<DD, QQ>), dim3((T + 64 * QQ - 1) / (64 * QQ), heads, n), dim3(256), 0, st, s.sa_qkv.p, s.sa_att.p, T, E, scale2, s.g_line_T, s.g_row_off, rset(kRangeOther))
+            if (D == 32) POCR_ATT2(32, 2); else if (D == 64) POCR_ATT2(64, 2); else POCR_ATT2(128, 1);
+#undef POCR_ATT2
+        } else {
 #define POCR_ATT(DD)                                                                                                                         \
         do {                                                                                                                                 \
             if (g2) hipLaunchKernelGGL((attention_kernel<DD, true>), agrid, dim3(64), 0, st, s.sa_qkv.as<float>(), s.sa_att.as<float>(), T, E, scale, s.g_line_T, s.g_row_off, rset(kRangeOther)); \
@@ -862,6 +872,7 @@ int run_network(pocr_engine *e, Slot &s) {
         } while (0)
         if (D == 32) POCR_ATT(32); else if (D == 64) POCR_ATT(64); else POCR_ATT(128);
 #undef POCR_ATT
+        }
         if (gemm(s.sa_att.p, E, L.w_out, L.b_out, E, s.sa_tmp.p, false, g2, false)) return 1;
         ln(xin, s.sa_tmp.as<float>(), L.n1w, L.n1b, nullptr, s.sa_x1.as<float>(), g2 ? s.sa_x1p2.p : nullptr);
         if (gemm(g2 ? s.sa_x1p2.p : s.sa_x1.p, E, L.w1, L.b1, FF, s.sa_ff.p, true, g2, g2)) return 1;
