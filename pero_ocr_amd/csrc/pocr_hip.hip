@@ -498,6 +498,9 @@ struct pocr_engine {
     int n_cus = 256;                 // compute units (grid of the persistent GEMM)
     bool gemm2 = false;              // GEMM-shaped layers on the persistent 256 x 128 kernel with P2 inputs (gemm_f16x2.hpp; needs p2; POCR_NO_GEMM2=1: conv3x3_bf16x3_kernel's GEMM mode on fp32 activations)
     bool p2 = false;                 // f16x2 with pre-split activations between conv1 and the aggregation conv (conv_bf16x3.hpp "P2"; POCR_NO_P2=1: split in every consumer)
+    DevBuf head_w2, head_b2;         // the output layer's weights in the wsplit layout + its bias padded to 128 columns: the head on the persistent GEMM
+    int head2_cout16 = 0;
+    bool head_fp32 = false, att_fp32 = false;      // POCR_HEAD_FP32 / POCR_ATT_FP32 at creation: the fp32-MFMA head / attention kernels
     bool bf16x3 = true;              // conv2..conv9 on the bf16 matrix pipe with the exact 3-way operand split (POCR_CONV_FP32=1: fp32 MFMA)
     DevBuf cconst[9];                // per conv layer: the output column [H_out][cout] far inside zero padding
     bool pad_skip = false;           // skip + fill constant padding tiles (POCR_NO_PAD_SKIP=1 turns it off)
@@ -796,6 +799,12 @@ int run_network(pocr_engine *e, Slot &s) {
     }
     const float *layer_in = s.feat.as<float>();
     int din = E;
+    // head2: the output layer on the persistent f16x2 GEMM, reading the last sequence layer's output in P2 (POCR_HEAD_FP32=1:
+    // the fp32-MFMA GEMM on the fp32 output)
+    const void *layer_in_p2 = nullptr;
+    auto head2_ok = [&](int din_) {
+        return e->gemm2 && !e->head_fp32 && e->head_w2.p && can_gemm2(e, din_, e->head2_cout16, din_ / 32, c.num_classes, false);
+    };
     if (c.arch == POCR_ARCH_SA || c.arch == POCR_ARCH_S2S) {
     // ---- self-attention encoder (transformer.py:366-385)
     const int FF = c.sa_ff, heads = c.sa_heads, D = E / heads;
@@ -854,8 +863,7 @@ int run_network(pocr_engine *e, Slot &s) {
         if (s.sa_y[l].reserve(xe)) return 1;
         // att2: q | k | v leave the projection in P2 and attention runs on f16x2 MFMAs (encoder.hpp); POCR_ATT_FP32=1 keeps
         // the fp32-MFMA kernel on fp32 q | k | v
-        static const bool att_fp32 = getenv("POCR_ATT_FP32") && atoi(getenv("POCR_ATT_FP32")) != 0;
-        const bool att2 = g2 && !att_fp32 && conv_split() == 2 && (D == 32 || D == 64 || D == 128);
+        const bool att2 = g2 && !e->att_fp32 && conv_split() == 2 && (D == 32 || D == 64 || D == 128);
         if (gemm(g2 ? s.sa_xp2.p : (const void *)xin, E, L.w_in, L.b_in, 3 * E, s.sa_qkv.p, false, g2, att2)) return 1;
         const dim3 agrid((T + 15) / 16, heads, n);
         const float scale = 1.0f / sqrtf((float)D);
@@ -883,6 +891,7 @@ int run_network(pocr_engine *e, Slot &s) {
     }
     layer_in = s.sa_y[c.sa_layers - 1].as<float>();
     din = E;
+    if (g2 && head2_ok(E)) layer_in_p2 = s.sa_xp2.p;      // the last LayerNorm's P2 copy
     if (c.arch == POCR_ARCH_S2S) {
         // keys / values of the encoder output for every decoder layer, computed once per launch
         // (CustomMultiheadAttention.cached_forward, transformer.py:237-247): [rows][2E] = memory W[E:3E]^T + b[E:3E]
@@ -993,7 +1002,9 @@ int run_network(pocr_engine *e, Slot &s) {
     // lstm_store_y) when that projection runs on the persistent GEMM; the last layer's output feeds the head (fp32 MFMA).
     const bool proj2 = e->gemm2 && (2 * Hh) % 32 == 0 && can_gemm2(e, 2 * Hh, e->proj_cout16, 2 * Hh / 32, 8 * Hh, false) &&
                        e->b3_weights.count(e->proj_w[0].p) != 0;
-    s.lstm_p2_layers = proj2 ? c.lstm_layers - 1 : 0;
+    // ... unless the head runs on the persistent GEMM too (head2): then every layer writes P2
+    const bool head2_lstm = proj2 && head2_ok(2 * Hh);
+    s.lstm_p2_layers = proj2 ? c.lstm_layers - (head2_lstm ? 0 : 1) : 0;
     bool in_p2 = s.feat_is_p2;
     for (int l = 0; l < c.lstm_layers; ++l) {
         const bool y_p2 = l < s.lstm_p2_layers;
@@ -1095,6 +1106,7 @@ int run_network(pocr_engine *e, Slot &s) {
         layer_in = s.lstm_y[l].as<float>();
         din = 2 * Hh;
     }
+    if (head2_lstm) layer_in_p2 = s.lstm_y[c.lstm_layers - 1].p;
     }
     // ---- head: [n*T][din] -> logits [n][T][C]
     const int C = c.num_classes;
@@ -1105,7 +1117,14 @@ int run_network(pocr_engine *e, Slot &s) {
         a.cout16 = e->head_cout16; a.cout_valid = C; a.out_stride = C;
         a.wfrag = e->head_w.as<float>(); a.bias = e->head_b.as<float>(); a.y = s.logits.as<float>();
         mark(POCR_STAGE_HEAD);
-        if (gemm64_k(a, st)) return 1;
+        if (layer_in_p2) {
+            GemmP2Args g{};
+            g.a = layer_in_p2; g.w = e->head_w2.p; g.bias = e->head_b2.as<float>(); g.y = s.logits.p;
+            g.M = rows; g.nk = din / 32; g.N16 = e->head2_cout16; g.n_valid = C; g.ldy = C; g.lda = (int64_t)din * 4;
+            gemm2_shape(e, g, rows, e->head2_cout16);
+            g.range_flag = rset(kRangeOther);
+            if (launch_gemm2<ACT_NONE, false, false>(e, g, st)) return 1;
+        } else if (gemm64_k(a, st)) return 1;
     }
     // ---- greedy CTC
     {
@@ -1413,6 +1432,8 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     e->p2 = conv_split() == 2 && !(getenv("POCR_NO_P2") && atoi(getenv("POCR_NO_P2")) != 0);
     e->fuse12 = e->p2 && !(getenv("POCR_NO_FUSE12") && atoi(getenv("POCR_NO_FUSE12")) != 0) && !((p2_alt_tiles() >> 1) & 1);
     e->gemm2 = e->p2 && !(getenv("POCR_NO_GEMM2") && atoi(getenv("POCR_NO_GEMM2")) != 0);
+    e->head_fp32 = getenv("POCR_HEAD_FP32") && atoi(getenv("POCR_HEAD_FP32")) != 0;
+    e->att_fp32 = getenv("POCR_ATT_FP32") && atoi(getenv("POCR_ATT_FP32")) != 0;
     e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->device = device_id;
     auto bail = [&](int rc) { pocr_destroy(e); return rc; };
@@ -1630,6 +1651,13 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         std::vector<float> bias(e->head_cout16 * 16, 0.f);
         for (int k = 0; k < C; ++k) bias[k] = b[k];
         if (upload(e->head_w, frag, st) || upload(e->head_b, bias, st)) return bail(1);
+        if (e->bf16x3 && conv_split() == 2 && head_in % 32 == 0) {     // the same layer for gemm_f16x2_kernel (P2 input)
+            e->head2_cout16 = round_up(C, kGemmBN) / 16;
+            auto wsp = build_wsplit(1, head_in, e->head2_cout16, [&](int co, int ci, int) { return w[(size_t)co * head_in + ci]; }, C);
+            std::vector<float> bias2(e->head2_cout16 * 16, 0.f);
+            for (int k = 0; k < C; ++k) bias2[k] = b[k];
+            if (upload_u16(e->head_w2, wsp, st) || upload(e->head_b2, bias2, st)) return bail(1);
+        }
     }
     if (cfg->embed_num > 0) {   // style embeddings: kept on the host, one row goes to the device per pocr_set_embed_id
         const size_t nf = (size_t)(cfg->embed_num + 1) * 2 * cfg->conv_out;
@@ -1673,7 +1701,7 @@ void pocr_destroy(pocr_engine *e) {
         for (DevBuf *b : {&L.ws_in, &L.bs_in, &L.ws_out, &L.bs_out, &L.wc_q, &L.bc_q, &L.wc_kv, &L.bc_kv, &L.wc_out, &L.bc_out,
                           &L.w1, &L.b1, &L.w2, &L.b2, &L.n1w, &L.n1b, &L.n2w, &L.n2b, &L.n3w, &L.n3b}) b->release();
     e->dec_embed.release();
-    for (DevBuf *b : {&e->sa_nw, &e->sa_nb, &e->pe, &e->bn_scale, &e->bn_shift, &e->agg_w, &e->agg_b, &e->head_w, &e->head_b, &e->lut, &e->conv1_w2})
+    for (DevBuf *b : {&e->sa_nw, &e->sa_nb, &e->pe, &e->bn_scale, &e->bn_shift, &e->agg_w, &e->agg_b, &e->head_w, &e->head_b, &e->head_w2, &e->head_b2, &e->lut, &e->conv1_w2})
         b->release();
     for (Slot &s : e->slot) {
         for (auto &b : s.act) b.release();

@@ -993,10 +993,10 @@ def test_presplit_activations_are_bit_identical(monkeypatch):
     offs = np.concatenate([[0], np.cumsum([c.size for c in crops])[:-1]]).astype(np.int64)
     cases = [([-(-max(w, 1) // 32) * 32 + 64 for w in widths], 32), ([1088] * len(widths), 32)]
 
-    def run(env):
-        for k in ("POCR_NO_P2", "POCR_NO_GEMM2"):
+    def run(env, head_fp32=True):
+        for k in ("POCR_NO_P2", "POCR_NO_GEMM2", "POCR_HEAD_FP32"):
             monkeypatch.delenv(k, raising=False)
-        for k in env:
+        for k in list(env) + (["POCR_HEAD_FP32"] if head_fp32 else []):
             monkeypatch.setenv(k, "1")
         eng = _native.NativeEngine(spec, weights, 0)
         out = []
@@ -1012,6 +1012,8 @@ def test_presplit_activations_are_bit_identical(monkeypatch):
 
     # default: P2 activations + the persistent P2-input GEMM (gemm_f16x2.hpp) for the aggregation conv and the LSTM projections;
     # POCR_NO_GEMM2: P2 conv stack, conv3x3_bf16x3_kernel's GEMM mode on fp32 features; POCR_NO_P2: the split inside every consumer
+    # (the three with the fp32-MFMA output layer, POCR_HEAD_FP32=1: by default the head runs on the persistent GEMM as well,
+    # which is another - closer - rounding of the same products; checked with a tolerance at the end)
     a, g, b = run([]), run(["POCR_NO_GEMM2"]), run(["POCR_NO_P2"])
     for other, what in ((g, "the GEMM-mode conv kernel"), (b, "the in-kernel split")):
         for (acts_a, outs_a), (acts_b, outs_b) in zip(a, other):
@@ -1021,6 +1023,16 @@ def test_presplit_activations_are_bit_identical(monkeypatch):
                 assert x.shape == y.shape
                 # (values below f16's normal range, 6.1e-5, keep an absolute precision of 2^-35 instead of a relative one)
                 assert np.all(np.abs(x - y) <= 2.0 ** -21 * np.abs(y) + 1e-9), f"activation {k}: P2 read-back is not the fp32 value of {what} to 2^-21"
+    d = run([], head_fp32=False)           # the shipped default: the last BiLSTM layer's output in P2, the head on gemm_f16x2_kernel
+    for (acts_a, outs_a), (acts_d, outs_d) in zip(a, d):
+        for k, (x, y) in enumerate(zip(acts_a, acts_d)):
+            assert np.array_equal(x, y), f"activation {k} depends on the head's kernel"
+        y11, logits_a, amax_a = outs_a[0], outs_a[1], outs_a[2]
+        assert np.all(np.abs(outs_d[0] - y11) <= 2.0 ** -21 * np.abs(y11) + 1e-9)
+        assert float(np.max(np.abs(outs_d[1] - logits_a))) < 2e-5
+        srt = np.sort(logits_a, axis=-1)
+        safe = (srt[..., -1] - srt[..., -2]) > 1e-4
+        assert np.array_equal(outs_d[2][safe], amax_a[safe])
 
 
 @pytest.mark.parametrize("height", [40, 32, 64])
