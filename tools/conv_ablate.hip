@@ -2,7 +2,7 @@
 // several times with parts of the main loop switched off (-DPOCR_BF16X3_DBG=n: 1 no A reads, 2 no weight loads, 4 no A
 // staging, 8 no barrier; results are then wrong, only the time matters).
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -DPOCR_BF16X3_DBG=<n> -o tools/bin/conv_ablate_<n> tools/conv_ablate.hip
-// Run  : tools/bin/conv_ablate_<n> [layer 9|8|6|4|2] [n_lines=256] [w_pad=576]
+// Run  : tools/bin/conv_ablate_<n> [layer 9|8|6|4|2] [n_lines=256] [w_pad=576] [only this variant of the layer's list]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -152,6 +152,8 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double flops = 2.0 * n * s.H * s.W * (double)s.cout * s.cin * (layer >= 100 ? 1 : 9);
     printf("DBG=%d conv%d %d->%d @%dx%d n=%d\n", POCR_BF16X3_DBG, layer, s.cin, s.cout, s.H, s.W, n);
+    const int only = argc > 4 ? atoi(argv[4]) : -1;      // run (and trace) only this variant of the layer's list
+    if (only >= 0 && only < (int)vars.size()) vars = {vars[only]};
     for (auto &v : vars) {
         ConvArgs a{};
         a.x = dx; a.wfrag = dw; a.bias = db; a.bn_scale = db; a.bn_shift = db; a.y = dy;
