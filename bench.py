@@ -343,6 +343,8 @@ def main():
     engine = PytorchEngineLineOCR(os.path.join(tmp.name, "ocr.json"), Dev(local_rank), batch_size=wl["batch_size"])
     eng = engine.model
     n_slots = min(eng.num_slots, 2)          # launches in flight in the c2 / c4 loop (the engine has 4 slots; deeper pipelines measured slower)
+    if os.environ.get("POCR_BENCH_SLOTS"):   # experiments
+        n_slots = max(1, min(eng.num_slots, int(os.environ["POCR_BENCH_SLOTS"])))
 
     # the exchange step: RCCL through the C ABI (POCR_FORCE_DIST=1 exercises it with a single rank)
     transport = None

@@ -313,6 +313,7 @@ inline int conv_tile_w(bool p2, bool b3, int k) { return p2 ? ((p2_alt_tiles() >
 const int kConvLvlIn[10] = {0, 0, 1, 1, 2, 2, 2, 2, 2, 2};
 const int kConvLvlOut[10] = {0, 1, 1, 2, 2, 2, 2, 2, 2, 2};
 const int kAggNT = 256, kProjNT = 128, kHeadNT = 64, kSkinnyNT = 64;
+const int kConvWaitLayer = 4;        // index into kConvPlan (conv5): see run_network
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -363,6 +364,8 @@ std::vector<uint16_t> build_wsplit(int ntaps, int cin, int cout16, const std::fu
 // latency-bound tail of chunk k (2*T*L serial LSTM step launches, D2H, host decode).
 struct Slot {
     hipStream_t stream = nullptr;        // uploads + conv backbone
+    hipEvent_t conv_part = nullptr;      // recorded behind conv layer kConvWaitLayer of a launch: the NEXT launch's backbone may start then (run_network)
+    bool conv_part_valid = false;
     hipStream_t seq_stream = nullptr;    // sequence model, head, CTC, D2H: high priority, so its short
                                          // latency-bound kernels are dispatched ahead of the other slot's conv workgroups
     // staged chunk
@@ -647,11 +650,23 @@ int run_network(pocr_engine *e, Slot &s) {
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(s.ev[i], st); };
     const int T = s.t_max, E = c.conv_out, AH = H / 8, rows = s.rows;
 
-    // ---- conv stack (after the previous launch's backbone, if that ran on another slot)
+    // ---- conv stack.  If the previous launch ran on another slot, this backbone starts behind that one's conv5
+    // (kConvWaitLayer): the first layers of this launch then share the chip with conv6 .. conv9 + aggregation of the one
+    // ahead and fill the ends of its kernels - every kernel of a stream leaves the CUs half empty while its last round of
+    // workgroups finishes (conv6 .. conv9: 18 rounds of 45-95 us tiles) and the next one cannot start before it has.
+    // Measured on one box (profiles/r04_backbone_overlap.txt): c2 9.73 -> 9.39 ms per step, c4 +1.2 %, c3 / c5 unchanged;
+    // no wait at all (POCR_CONV_NOWAIT=1) is as good on c2 and costs the c3 stream 3 %; behind the WHOLE backbone
+    // (POCR_CONV_WAIT_LAYER=-1, rounds 1-3) two backbones never share the chip.
+    static const int conv_wait_layer = getenv("POCR_CONV_WAIT_LAYER") ? atoi(getenv("POCR_CONV_WAIT_LAYER")) : kConvWaitLayer;
     {
         Slot &prev = e->slot[e->last_slot];
-        if (&prev != &s && prev.conv_done_valid) HIP_TRY(hipStreamWaitEvent(st, prev.conv_done, 0));
+        static const bool conv_nowait = getenv("POCR_CONV_NOWAIT") && atoi(getenv("POCR_CONV_NOWAIT")) != 0;
+        if (&prev != &s && prev.conv_done_valid && !conv_nowait) {
+            if (conv_wait_layer >= 0 && conv_wait_layer < 9 && prev.conv_part_valid) HIP_TRY(hipStreamWaitEvent(st, prev.conv_part, 0));
+            else HIP_TRY(hipStreamWaitEvent(st, prev.conv_done, 0));
+        }
     }
+    s.conv_part_valid = false;
     int h = H;
     for (int i = 0; i < 9; ++i)
         if (s.act[i].reserve((size_t)s.act_elems[i] * sizeof(float))) return 1;
@@ -731,6 +746,7 @@ int run_network(pocr_engine *e, Slot &s) {
         if (rc) return rc;
         h /= L.ph;
         s.act_h[i] = h; s.act_c[i] = L.cout;
+        if (conv_wait_layer >= 0 && i == conv_wait_layer) { HIP_TRY(hipEventRecord(s.conv_part, st)); s.conv_part_valid = true; }
     }
     // ---- aggregation conv: line i [H/8][T_i][512] -> rows row_off[i] .. of feat [rows][E]
     {
@@ -1398,11 +1414,16 @@ static int compute_pad_constants(pocr_engine *e) {
     for (int l = 0; l < 9; ++l) {
         const int W = wl[kConvLvlOut[l]], C = kConvPlan[l].cout, Hl = s.act_h[l];
         if (e->cconst[l].reserve((size_t)Hl * C * sizeof(float))) return 1;
-        HIP_TRY(locked_memcpy2d(e->cconst[l].p, (size_t)C * sizeof(float), s.act[l].as<float>() + (size_t)(W / 2) * C,
-                            (size_t)W * C * sizeof(float), (size_t)C * sizeof(float), (size_t)Hl, hipMemcpyDeviceToDevice));
+        // (on the slot's stream and waited for below: a device-to-device hipMemcpy2D is ordered in the NULL stream and may return
+        //  before it has run - the slots' streams are non-blocking, so the first launch's pad_fill_kernel could read the constants
+        //  before they were there when other engines of the process kept the GPU busy: a wrong line in the FIRST call of a fresh
+        //  engine, once in ~100 engines under tools/stress_first_job.py)
+        HIP_TRY(hipMemcpy2DAsync(e->cconst[l].p, (size_t)C * sizeof(float), s.act[l].as<float>() + (size_t)(W / 2) * C,
+                                 (size_t)W * C * sizeof(float), (size_t)C * sizeof(float), (size_t)Hl, hipMemcpyDeviceToDevice, s.stream));
     }
+    HIP_TRY(hipStreamSynchronize(s.stream));
     s.staged = false;
-    s.conv_done_valid = false;
+    s.conv_done_valid = false; s.conv_part_valid = false;
     e->cconst_ready = true;
     return 0;
 }
@@ -1446,6 +1467,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically lower = higher priority
         if (const char *env = getenv("POCR_SEQ_PRIO")) prio_hi = atoi(env) == 0 ? 0 : (atoi(env) < 0 ? prio_lo : prio_hi);   // A/B: 0 normal, -1 low
         if (hipStreamCreateWithPriority(&sl.seq_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(fail("hipStreamCreate failed"));
+        if (hipEventCreateWithFlags(&sl.conv_part, hipEventDisableTiming) != hipSuccess) return bail(fail("hipEventCreate failed"));
         for (auto &ev : sl.ev)
             if (hipEventCreate(&ev) != hipSuccess) return bail(fail("hipEventCreate failed"));
         if (hipEventCreateWithFlags(&sl.conv_done, hipEventDisableTiming) != hipSuccess) return bail(fail("hipEventCreate failed"));
@@ -1733,6 +1755,7 @@ void pocr_destroy(pocr_engine *e) {
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);
         if (s.conv_done) (void)hipEventDestroy(s.conv_done);
+        if (s.conv_part) (void)hipEventDestroy(s.conv_part);
         if (s.ev_conv_end) (void)hipEventDestroy(s.ev_conv_end);
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.seq_stream) (void)hipStreamDestroy(s.seq_stream);

@@ -2,7 +2,7 @@
 // several times with parts of the main loop switched off (-DPOCR_BF16X3_DBG=n: 1 no A reads, 2 no weight loads, 4 no A
 // staging, 8 no barrier; results are then wrong, only the time matters).
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -DPOCR_BF16X3_DBG=<n> -o tools/bin/conv_ablate_<n> tools/conv_ablate.hip
-// Run  : tools/bin/conv_ablate_<n> [layer 9|8|6|4|2] [n_lines=256] [w_pad=576] [only this variant of the layer's list]
+// Run  : tools/bin/conv_ablate_<n> [layer 9|8|6|4|2] [n_lines=256] [w_pad=576] [only this variant of the layer's list, -1 = all] [sustained launches]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +57,12 @@ VP(p7_e, 2, 4, 1, 1, 2, 1, ACT_RELU, false, 2, true)      // 2x64 NS 1 (MS 8)
 VP(p9_b, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 3, true)      // conv8/9: 3 WG/CU budget
 VP(p9_c, 5, 2, 1, 1, 1, 1, ACT_LEAKY, true, 2, true)      // 5x32 NS 1 (NT 64)
 VP(p9_d, 5, 1, 1, 1, 1, 1, ACT_LEAKY, true, 4, true)      // 5x16 NS 1 (NT 64), 4 WG/CU
+// one workgroup per CU (512 registers per lane): every weight fragment feeds 10 row strips AND every A fragment two channel tiles
+VP(p9_e, 5, 2, 2, 1, 1, 1, ACT_LEAKY, true, 1, true)      // conv8/9: 5x32 NT128 (MS 10, NS 2)
+VP(p6_x, 10, 1, 2, 1, 1, 1, ACT_RELU, false, 1, true)     // conv3/5/6: 10x16 NT128 (MS 10, NS 2)
+VP(p6_y, 10, 2, 1, 1, 1, 1, ACT_RELU, false, 1, true)     // 10x32 NT64 (MS 20, NS 1)
+VP(p4_x, 10, 1, 2, 1, 2, 2, ACT_RELU, false, 1, true)     // conv4: 10x16 NT128
+VP(p7_x, 10, 1, 2, 1, 2, 1, ACT_RELU, false, 1, true)     // conv7: 10x16 NT128
 V(h9, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true, 2)
 // GEMM mode (1x1): rows x cin -> cout, "pixels" = rows.  (TH, MW, NS, WM, MINW, BDIR, PRE_IN, PRE_OUT)
 #define VG(NAME, MW, NS, WM, MINW, BDIR, PIN, POUT) static void NAME(ConvArgs a, hipStream_t st) { \
@@ -131,12 +137,12 @@ int main(int argc, char **argv) {
         vars = {{"GEMM 128x128 LDS, split inside (shipped)", g_ship, 2}, {"GEMM 128x128 direct weights, split inside", g_ship_d, 2}, {"GEMM P2 in", g_pin, 2}, {"GEMM P2 in, direct weights", g_pin_d, 2},
                 {"GEMM P2 in + out", g_pin_out, 2}, {"GEMM P2 128x128 N-split direct", g_pin_8x2, 2}, {"GEMM P2 64x256 direct", g_pin_4x4, 2},
                 {"GEMM P2 128x64 M-split LDS", g_pin_8x4m, 2}, {"GEMM P2 256x64 M-split LDS", g_pin_16, 2}};
-    } else if (layer == 9) { s = {512, 512, 5, wpad / 4, 1, 1}; vars = {{"f16x2 in-kernel split 5x16 NT128", h9, 2}, {"P2 5x16 NT128 (shipped)", p9, 2}, {"P2 5x16 NT128 3WG", p9_b, 2}, {"P2 5x32 NT64", p9_c, 2}, {"P2 5x16 NT64 4WG", p9_d, 2}}; }
+    } else if (layer == 9) { s = {512, 512, 5, wpad / 4, 1, 1}; vars = {{"f16x2 in-kernel split 5x16 NT128", h9, 2}, {"P2 5x16 NT128 (shipped)", p9, 2}, {"P2 5x16 NT128 3WG", p9_b, 2}, {"P2 5x32 NT64", p9_c, 2}, {"P2 5x16 NT64 4WG", p9_d, 2}, {"P2 5x32 NT128 1WG", p9_e, 2}}; }
     else if (layer == 8) { s = {256, 512, 5, wpad / 4, 1, 1}; vars = {{"P2 5x16 NT128 (shipped)", p8, 2}}; }
-    else if (layer == 7) { s = {256, 256, 10, wpad / 4, 2, 1}; vars = {{"P2 2x32 NT128 (shipped)", p7, 2}, {"P2 2x32 3WG", p7_b, 2}, {"P2 2x16 3WG", p7_c, 2}, {"P2 10x16 NT64", p7_d, 2}, {"P2 2x64 NT64", p7_e, 2}}; }
-    else if (layer == 6 || layer == 5) { s = {layer == 5 ? 128 : 256, 256, 10, wpad / 4, 1, 1}; vars = {{"P2 5x16 NT128 (shipped)", p6, 2}, {"P2 5x16 3WG", p3_d, 2}, {"P2 2x32 3WG", p3_e, 2}, {"P2 5x32 NT64", p3_f, 2}, {"P2 10x16 NT64", p3_g, 2}}; }
-    else if (layer == 4) { s = {128, 128, 20, wpad / 2, 2, 2}; vars = {{"P2 4x16 NT128 (shipped)", p4, 2}, {"P2 4x16 3WG", p4_b, 2}, {"P2 4x32", p4_c, 2}, {"P2 10x16 NT64", p4_e, 2}, {"P2 4x32 NT64", p4_f, 2}}; }
-    else if (layer == 3) { s = {64, 128, 20, wpad / 2, 1, 1}; vars = {{"P2 5x16 NT128 (shipped)", p3, 2}, {"P2 4x16 3WG", p3_b, 2}, {"P2 4x32", p3_c, 2}, {"P2 5x16 3WG", p3_d, 2}, {"P2 2x32 3WG", p3_e, 2}, {"P2 5x32 NT64", p3_f, 2}, {"P2 10x16 NT64", p3_g, 2}}; }
+    else if (layer == 7) { s = {256, 256, 10, wpad / 4, 2, 1}; vars = {{"P2 2x32 NT128 (shipped)", p7, 2}, {"P2 2x32 3WG", p7_b, 2}, {"P2 2x16 3WG", p7_c, 2}, {"P2 10x16 NT64", p7_d, 2}, {"P2 2x64 NT64", p7_e, 2}, {"P2 10x16 NT128 1WG", p7_x, 2}}; }
+    else if (layer == 6 || layer == 5) { s = {layer == 5 ? 128 : 256, 256, 10, wpad / 4, 1, 1}; vars = {{"P2 5x16 NT128 (shipped)", p6, 2}, {"P2 5x16 3WG", p3_d, 2}, {"P2 2x32 3WG", p3_e, 2}, {"P2 5x32 NT64", p3_f, 2}, {"P2 10x16 NT64", p3_g, 2}, {"P2 10x16 NT128 1WG", p6_x, 2}, {"P2 10x32 NT64 1WG", p6_y, 2}}; }
+    else if (layer == 4) { s = {128, 128, 20, wpad / 2, 2, 2}; vars = {{"P2 4x16 NT128 (shipped)", p4, 2}, {"P2 4x16 3WG", p4_b, 2}, {"P2 4x32", p4_c, 2}, {"P2 10x16 NT64", p4_e, 2}, {"P2 4x32 NT64", p4_f, 2}, {"P2 10x16 NT128 1WG", p4_x, 2}}; }
+    else if (layer == 3) { s = {64, 128, 20, wpad / 2, 1, 1}; vars = {{"P2 5x16 NT128 (shipped)", p3, 2}, {"P2 4x16 3WG", p3_b, 2}, {"P2 4x32", p3_c, 2}, {"P2 5x16 3WG", p3_d, 2}, {"P2 2x32 3WG", p3_e, 2}, {"P2 5x32 NT64", p3_f, 2}, {"P2 10x16 NT64", p3_g, 2}, {"P2 10x16 NT128 1WG", p6_x, 2}, {"P2 10x32 NT64 1WG", p6_y, 2}}; }
     else { s = {64, 64, 40, wpad, 2, 2}; vars = {{"P2 lds 4x32 NT64 3WG (shipped)", p2, 2}, {"P2 lds 8x32", p2_b, 2}, {"P2 direct 4x32 3WG", p2_c, 2}, {"P2 direct 8x32", p2_d, 2}, {"P2 lds 4x64 M-split NS4", p2_e, 2}, {"P2 direct 4x64 M-split NS4", p2_f, 2}, {"P2 lds 4x32 2WG", p2_g, 2}, {"P2 direct 10x16 NS1", p4_e, 2}, {"P2 direct 4x32 NS1", p4_f, 2}}; }
     const size_t xin = (size_t)n * s.H * s.W * s.cin, yout = (size_t)n * (s.H / s.ph) * (s.W / s.pw) * s.cout;
     std::vector<float> hx(xin);
@@ -152,6 +158,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double flops = 2.0 * n * s.H * s.W * (double)s.cout * s.cin * (layer >= 100 ? 1 : 9);
     printf("DBG=%d conv%d %d->%d @%dx%d n=%d\n", POCR_BF16X3_DBG, layer, s.cin, s.cout, s.H, s.W, n);
+    const int sustained = argc > 5 ? atoi(argv[5]) : 0;  // > 0: time this many back-to-back launches at the power cap instead of 10 single ones
     const int only = argc > 4 ? atoi(argv[4]) : -1;      // run (and trace) only this variant of the layer's list
     if (only >= 0 && only < (int)vars.size()) vars = {vars[only]};
     for (auto &v : vars) {
@@ -161,6 +168,17 @@ int main(int argc, char **argv) {
         for (int w = 0; w < 3; ++w) v.fn(a, st);
         CK(hipStreamSynchronize(st)); CK(hipGetLastError());
         float sum = 0, best = 1e30f;
+        if (sustained > 0) {
+            // power-limited steady state (profiles/r04_power_cap.txt): `sustained` launches back to back; the first third brings the
+            // package to its cap and is not timed - what this measures is the variant's ENERGY per launch, which is what the engine pays
+            for (int rep = 0; rep < sustained / 3; ++rep) v.fn(a, st);
+            CK(hipEventRecord(e0, st));
+            for (int rep = 0; rep < sustained; ++rep) v.fn(a, st);
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("  %-28s sustained over %d launches %.3f ms  %.1f TF(alg)\n", v.name, sustained, ms / sustained, flops / (ms / sustained * 1e-3) / 1e12);
+            continue;
+        }
         for (int rep = 0; rep < 10; ++rep) {
             CK(hipEventRecord(e0, st)); v.fn(a, st); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); sum += ms; best = ms < best ? ms : best;
