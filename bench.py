@@ -302,6 +302,8 @@ def main():
     ap.add_argument("--head-temperature", type=float, default=8.0,
                     help="c5: scale of the CTC head of the synthetic weights (8: ~8 classes per frame above p = 1e-4; 1: 219 of 232)")
     ap.add_argument("--pages-per-batch", type=int, default=4, help="c5: pages whose lines share one process_lines call")
+    ap.add_argument("--front-workers", type=int, default=int(os.environ.get("POCR_BENCH_FRONTS", "2")),
+                    help="c5: (layout network, cropper) pairs, one helper thread each, working on consecutive pages of the stream")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 5 if args.workload == "c3" else 20
@@ -471,7 +473,22 @@ def main():
 
         page_index = {id(pg): k for k, pg in enumerate(pages)}
         ppb = args.pages_per_batch
-        stream = PageStream(layout_front, cropper, page_ocr, pages_per_batch=ppb)
+        # further front pairs (layout network + cropper instances of their own: a pair owns device buffers), one worker thread each
+        n_fronts = max(1, args.front_workers)
+        extra_fronts = []
+        for _w in range(1, n_fronts):
+            pn_w = torch_parsenet.TorchParseNet(pn_path, Dev(local_rank), downsample=4, adaptive_downsample=False)
+            cr_w = LineCropper({"LINE_HEIGHT": str(spec.height), "INTERP": "2", "LINE_SCALE": "1.0",
+                                "RESIDENT_CROPS": "no" if os.environ.get("POCR_BENCH_HOST_CROPS") == "1" else "yes"}, device_id=local_rank)
+
+            def front_w(img, pn_w=pn_w):
+                k = page_index[id(img)]
+                maps, ds = pn_w.get_maps_with_optimal_resolution(img)
+                assert maps.shape == (ph // 4, pw // 4, 5) and ds == 4
+                return Layout([Line(i, [[x0, y0 + 30], [x0 + wd // 2, y0 + 30], [x0 + wd, y0 + 30]], [30, 10])
+                               for i, (x0, y0, wd) in enumerate(boxes[k])])
+            extra_fronts.append((front_w, cr_w))
+        stream = PageStream(layout_front, cropper, page_ocr, pages_per_batch=ppb, extra_fronts=extra_fronts)
 
         def run_stream(n):
             nonlocal lines_done
@@ -505,11 +522,18 @@ def main():
             # recogniser fed with the lines of `ppb` pages per call
             run_stream(max(ppb, args.warmup))
             lines_done = 0
+            for k in stream.stats:
+                stream.stats[k] = 0
             fence()
             t0 = time.perf_counter()
             texts = run_stream(args.steps)
             fence()
             elapsed = time.perf_counter() - t0
+            # where the consumer thread's time went: waiting for the front (layout network + cropper of the NEXT pages, helper
+            # thread) or inside the recogniser's calls
+            extra["stream_consumer_ms_per_page"] = {"waiting_for_front": round(1e3 * stream.stats["wait_front_s"] / args.steps, 3),
+                                                    "recogniser_calls": round(1e3 * stream.stats["ocr_s"] / args.steps, 3),
+                                                    "batches_in_flight_overlap": bool(stream.overlap_batches), "front_workers": n_fronts}
         assert all(isinstance(t, str) for t in texts)
         # the stream's result is CHECKED: the last batch of `ppb` pages again, sequentially (same lines in one process_lines call ->
         # same reference chunk plan -> the deterministic GPU path must reproduce every string and coordinate); and against one
@@ -547,7 +571,8 @@ def main():
         workload_txt = (f"c5: stream of {ph}x{pw} synthetic pages, one per step per GPU: layout network (parsenet_unet64, downsample 4 -> {ph // 4}x{pw // 4}) -> "
                         f"layout post-processing stub (ground-truth baselines of the {len(boxes[0])} pasted lines) -> resident GPU line cropper (crops stay in HBM) -> "
                         f"VGG+BiLSTM+CTC line OCR (default batch_size 8, sparse logits + confidences) -> strings; inputs: host page per step; "
-                        f"layout + crop of the next pages on a helper thread, the recogniser gets the lines of {ppb} pages per process_lines call")
+                        f"layout + crop of the next pages on {n_fronts} helper thread(s) (a layout-network + cropper instance each), the recogniser gets the lines of {ppb} pages per process_lines call"
+                        + (", the next call's launches enqueued before a call's last ones are collected" if stream.overlap_batches else ""))
         w_pad = None
     elif args.workload == "c3":
         # ------------------------------------------------------------------ c3: sharded page stream (strong scaling)

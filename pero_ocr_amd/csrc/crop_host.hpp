@@ -1,6 +1,6 @@
 // crop_host.hpp — host side + C ABI of the resident line cropper (included by pocr_hip.hip, which provides DevBuf /
 // fail / HIP_TRY).  Replaces EngineLineCropper.crop per line (pero_ocr/core/crop_engine.py:16-30, 54-99, 146-163) by
-// three launches per PAGE: the page is uploaded once (helper thread: pageable -> pinned -> DMA in 8 MB chunks, behind
+// three launches per PAGE: the page is uploaded once (helper thread: pageable -> pinned -> DMA in 4 MB pieces on several host threads, behind
 // the caller's per-line host work) and stays in HBM for every line; the only host<->device traffic per page besides
 // the page itself is ~100 B of spline per line up, 4 B of width per line back, and the crops.
 #include <atomic>
@@ -74,7 +74,7 @@ int pocr_cropper_create(int device_id, pocr_cropper **out) {
     HIP_TRY(hipSetDevice(device_id));
     auto *c = new pocr_cropper();
     c->device = device_id;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+    if (create_front_stream(&c->stream) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
@@ -117,13 +117,8 @@ int pocr_cropper_set_page(pocr_cropper *c, const uint8_t *page_hwc, int32_t H, i
     c->H = H; c->W = W; c->C = C;
     c->upload_rc.store(0);
     c->uploader = std::thread([c, page_hwc, bytes]() {
-        const size_t chunk = (size_t)8 << 20;
         hipError_t e = hipSetDevice(c->device);
-        for (size_t o = 0; o < bytes && e == hipSuccess; o += chunk) {
-            const size_t nb = std::min(chunk, bytes - o);
-            std::memcpy(static_cast<uint8_t *>(c->pin_page) + o, page_hwc + o, nb);
-            e = hipMemcpyAsync(static_cast<uint8_t *>(c->page.p) + o, static_cast<uint8_t *>(c->pin_page) + o, nb, hipMemcpyHostToDevice, c->copy_stream);
-        }
+        if (e == hipSuccess) e = upload_through_pinned(c->page.p, c->pin_page, page_hwc, bytes, c->copy_stream, c->device);
         if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
         if (e != hipSuccess) { c->upload_err = hipGetErrorString(e); c->upload_rc.store(1); }
     });

@@ -92,7 +92,7 @@ int pocr_parsenet_create(const float *weights, size_t n_floats, int device_id, p
     pocr_parsenet *p = new pocr_parsenet();
     p->device = device_id;
     auto bail = [&](int rc) { pocr_parsenet_destroy(p); return rc; };
-    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
+    if (create_front_stream(&p->stream) != hipSuccess) return bail(fail("hipStreamCreate failed"));
     if (hipEventCreate(&p->ev0) != hipSuccess || hipEventCreate(&p->ev1) != hipSuccess) return bail(fail("hipEventCreate failed"));
     hipStream_t st = p->stream;
     WeightCursor cur{weights};
@@ -194,9 +194,8 @@ static int parsenet_get_maps_impl(pocr_parsenet *p, const uint8_t *img_hwc, int3
         HIP_TRY(locked_host_malloc(&p->pin_in, in_bytes, hipHostMallocDefault));
         p->pin_in_cap = in_bytes;
     }
-    memcpy(p->pin_in, img_hwc, in_bytes);
     if (p->page.reserve(in_bytes)) return 1;
-    HIP_TRY(hipMemcpyAsync(p->page.p, p->pin_in, in_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(upload_through_pinned(p->page.p, p->pin_in, img_hwc, in_bytes, st, p->device));
     HIP_TRY(hipEventRecord(p->ev0, st));
     const uint8_t *src = p->page.as<uint8_t>();
     if (taps) {          // fractional factor: separable area weights from the host, applied in float64 (parsenet.hpp)

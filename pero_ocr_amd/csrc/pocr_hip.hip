@@ -14,6 +14,7 @@
 #include <map>
 #include <tuple>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pocr.h"
@@ -32,6 +33,10 @@
 #include "parsenet.hpp"
 
 using namespace pocr;
+
+#ifndef POCR_FRONT_PRIORITY_DEFAULT_HIGH
+#define POCR_FRONT_PRIORITY_DEFAULT_HIGH false
+#endif
 
 namespace {
 
@@ -68,6 +73,49 @@ struct UnsafeLock { std::lock_guard<std::recursive_mutex> g{g_unsafe_mu}; };
 inline hipError_t locked_host_malloc(void **p, size_t n, unsigned flags) { UnsafeLock l; return hipHostMalloc(p, n, flags); }
 inline hipError_t locked_host_free(void *p) { UnsafeLock l; return hipHostFree(p); }
 inline hipError_t locked_device_sync() { UnsafeLock l; return hipDeviceSynchronize(); }
+
+// A page (36 MB at 4k x 3k) from pageable memory to the device: `n_threads` host threads (the caller is one of them) take 4 MB
+// pieces in turn, copy each into the pinned buffer and queue its DMA on `st` - the pieces are independent, so neither their order on
+// the stream nor which thread queued them matters, and the DMA of a piece runs behind the host copies of the next ones.  One
+// thread moves ~12 GB/s out of pageable memory, so a lone memcpy in front of a lone DMA (rounds 1-3) cost a 4k x 3k page 3.6 ms.
+inline int upload_threads() {
+    static const int n = [] { const char *e = getenv("POCR_UPLOAD_THREADS"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : v > 16 ? 16 : v; }();
+    return n;
+}
+inline hipError_t upload_through_pinned(void *dev, void *pin, const void *src, size_t bytes, hipStream_t st, int device) {
+    const size_t piece = (size_t)4 << 20;
+    const size_t n_pieces = (bytes + piece - 1) / piece;
+    const int n_threads = (int)std::min<size_t>((size_t)upload_threads(), std::max<size_t>(n_pieces, 1));
+    std::atomic<size_t> next{0};
+    std::atomic<int> err{(int)hipSuccess};
+    auto work = [&](bool set_device) {
+        if (set_device) { hipError_t e = hipSetDevice(device); if (e != hipSuccess) { err.store((int)e); return; } }
+        for (size_t i = next.fetch_add(1); i < n_pieces && err.load() == (int)hipSuccess; i = next.fetch_add(1)) {
+            const size_t o = i * piece, nb = std::min(piece, bytes - o);
+            std::memcpy(static_cast<uint8_t *>(pin) + o, static_cast<const uint8_t *>(src) + o, nb);
+            hipError_t e = hipMemcpyAsync(static_cast<uint8_t *>(dev) + o, static_cast<uint8_t *>(pin) + o, nb, hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) err.store((int)e);
+        }
+    };
+    std::vector<std::thread> helpers;
+    for (int t = 1; t < n_threads; ++t) helpers.emplace_back(work, true);
+    work(false);
+    for (std::thread &h : helpers) h.join();
+    return (hipError_t)err.load();
+}
+
+// The streams of the page front (layout network, cropper).  In a page stream their kernels share the GPU with the recogniser's
+// convolutions of EARLIER pages; the front is a chain of short dependent launches with host steps between them, so what it needs is
+// latency: POCR_FRONT_PRIORITY=high puts its streams at the device's greatest priority (default: see DESIGN section 5).
+inline hipError_t create_front_stream(hipStream_t *st) {
+    const char *e = getenv("POCR_FRONT_PRIORITY");
+    const bool high = e ? (strcmp(e, "high") == 0 || strcmp(e, "1") == 0) : POCR_FRONT_PRIORITY_DEFAULT_HIGH;
+    if (!high) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    int lo = 0, hi = 0;
+    hipError_t r = hipDeviceGetStreamPriorityRange(&lo, &hi);          // numerically lowest = greatest priority
+    if (r != hipSuccess) return r;
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
+}
 inline hipError_t locked_memcpy(void *d, const void *s_, size_t n, hipMemcpyKind k) { UnsafeLock l; return hipMemcpy(d, s_, n, k); }
 inline hipError_t locked_memcpy2d(void *d, size_t dp, const void *s_, size_t sp, size_t w, size_t h, hipMemcpyKind k) { UnsafeLock l; return hipMemcpy2D(d, dp, s_, sp, w, h, k); }
 

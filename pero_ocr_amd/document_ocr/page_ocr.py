@@ -62,14 +62,28 @@ class PageOCR:
         the chunks of a page stream differ from the per-page ones exactly as they do when the reference's
         `process_lines` is handed more lines.  Results are written to the lines as process_page does.
         `sharded`: a sharding.ShardedLineOCR built over this engine - the stream's chunks are dealt to the ranks."""
+        return self.process_pages_end(self.process_pages_begin(page_layouts, sharded))
+
+    def process_pages_begin(self, page_layouts, sharded=None):
+        """First half of process_pages: the lines' launches are enqueued (`process_lines_begin`), nothing is waited for.
+        A page stream begins batch k + 1 before it ends batch k, so the recogniser's pipeline is not drained between
+        batches; tickets are ended in the order they were begun."""
         lines = [line for layout in page_layouts for line in layout.lines_iterator()]
         for line in lines:
             if line.crop is None:
                 raise Exception(f"Missing crop in line {line.id}.")
         # sharded (sharding.ShardedLineOCR over this engine, one process per GPU): every rank gets every transcription,
         # logits / logit_coords for the lines of its own chunks and None for the others (they stay on the producing rank)
-        recogniser = sharded if sharded is not None else self.ocr_engine
-        texts, logits, coords = recogniser.process_lines([line.crop for line in lines])
+        crops = [line.crop for line in lines]
+        begin = getattr(self.ocr_engine, "process_lines_begin", None) if sharded is None else None
+        if begin is None:                # sharded calls (one collective each) and engines without the two halves: in one piece
+            recogniser = sharded if sharded is not None else self.ocr_engine
+            return (page_layouts, lines, None, recogniser.process_lines(crops))
+        return (page_layouts, lines, begin(crops), None)
+
+    def process_pages_end(self, ticket):
+        page_layouts, lines, job, result = ticket
+        texts, logits, coords = result if job is None else self.ocr_engine.process_lines_end(job)
         for line, text, line_logits, line_coords in zip(lines, texts, logits, coords):
             line.transcription = text
             line.logits = line_logits

@@ -173,38 +173,85 @@ class BaseEngineLineOCR:
         (scipy.sparse.csc_matrix float32 [T_i, C]; dense ndarray if sparse_logits=False;
         None if no_logits) and logit_coords ([start, end] frame span of the un-padded
         line; [None, None] with tight_crop_logits; None if no_logits)."""
-        for i, line in enumerate(lines):
-            if line.ndim != 3 or line.shape[0] != self.line_px_height or line.shape[2] != 3:
-                raise ValueError(f"line {i}: expected a [{self.line_px_height}, w, 3] crop, got {line.shape}")
-        chunks = plan_chunks([l.shape[1] for l in lines], self.max_input_horizontal_pixels, int(self.line_padding_px))
-        return self.process_chunks(lines, chunks, sparse_logits, tight_crop_logits, no_logits)
+        return self.process_lines_end(self.process_lines_begin(lines, sparse_logits, tight_crop_logits, no_logits))
 
     def process_chunks(self, lines, chunks, sparse_logits=True, tight_crop_logits=False, no_logits=False):
         """The body of process_lines for a GIVEN subset of the reference's chunk plan of `lines` (all of it: process_lines;
         one rank's share: sharding.ShardedLineOCR - a line's result depends on its chunk's padded width, so a rank must run
         chunks of the plan over ALL lines, never a plan of its own lines).  Returns the three lists of process_lines, in
         input order, with None for the lines of chunks that were not given."""
-        n = len(lines)
-        transcriptions: List[Optional[str]] = [None] * n
-        logits_out: List[object] = [None] * n
-        coords_out: List[Optional[list]] = [None] * n
+        return self.process_lines_end(self._begin_chunks(lines, chunks, sparse_logits, tight_crop_logits, no_logits))
 
-        sub = int(self.net_subsampling)
-        pad = int(self.line_padding_px)
+    # -- the same call in two halves: a caller with a STREAM of process_lines calls (document_ocr.page_stream) begins call
+    #    k + 1 before it ends call k, so the launches of consecutive calls share the engine's slots and the pipeline is not
+    #    drained between calls.  What a call returns does not depend on what else is in flight (launches are independent).
+    def process_lines_begin(self, lines, sparse_logits=True, tight_crop_logits=False, no_logits=False):
+        """First half of process_lines: validates, plans and ENQUEUES (as far as the engine's slots allow); -> a ticket for
+        process_lines_end.  Tickets must be ended in the order they were begun."""
+        for i, line in enumerate(lines):
+            if line.ndim != 3 or line.shape[0] != self.line_px_height or line.shape[2] != 3:
+                raise ValueError(f"line {i}: expected a [{self.line_px_height}, w, 3] crop, got {line.shape}")
+        chunks = plan_chunks([l.shape[1] for l in lines], self.max_input_horizontal_pixels, int(self.line_padding_px))
+        return self._begin_chunks(lines, chunks, sparse_logits, tight_crop_logits, no_logits)
 
-        device_sparse = sparse_logits and not no_logits and getattr(self, "supports_device_sparsify", False)
-
+    def process_lines_end(self, job):
+        """Second half: collects what is still in flight for this ticket; -> the three lists of process_lines."""
+        if job.error is not None:
+            raise job.error
+        if job.done:
+            raise RuntimeError("process_lines_end: this ticket was already ended")
+        try:
+            while job.open_launches:
+                self._collect_oldest()
+                if job.error is not None:
+                    raise job.error
+        except BaseException as exc:
+            self._abort_inflight(exc)
+            raise
+        job.done = True
         # Side channel (not part of the reference's return contract): with GPU-built sparse logits the engine also
         # returns every line's transcription confidence, i.e. what PageParser.update_confidences would compute
         # from these logits (page_parser.py:485-496, 505-508).  None where it was not computed.
-        self.line_confidences = [None] * n
+        self.line_confidences = job.confidences
+        return job.transcriptions, job.logits_out, job.coords_out
+
+    def _abort_inflight(self, exc):
+        """A launch may still be in flight on any slot: fail every open ticket and leave the engine usable."""
+        inflight = getattr(self, "_inflight", None)
+        if inflight:
+            for job, _launch, _handle, _sparse in inflight:
+                if job.error is None:
+                    job.error = exc if isinstance(exc, Exception) else RuntimeError(f"engine reset while this call was in flight: {exc!r}")
+                job.open_launches = 0
+            inflight.clear()
+        reset = getattr(getattr(self, "model", None), "reset", None)
+        if reset is not None:
+            reset()
+
+    def _collect_oldest(self):
+        job, launch, handle, on_device = self._inflight.popleft()
+        job.open_launches -= 1
+        try:
+            job.scatter(launch.line_ids, *self._collect_launch(handle), on_device=on_device)
+        except BaseException as exc:
+            job.error = exc if isinstance(exc, Exception) else RuntimeError(f"interrupted while this call was collected: {exc!r}")
+            job.open_launches = 0
+            raise
+
+    def _begin_chunks(self, lines, chunks, sparse_logits, tight_crop_logits, no_logits):
+        n = len(lines)
+        sub = int(self.net_subsampling)
+        pad = int(self.line_padding_px)
+        device_sparse = sparse_logits and not no_logits and getattr(self, "supports_device_sparsify", False)
+        job = _LinesJob(n)
 
         def scatter(line_ids, texts, chunk_logits, conf=None, on_device=False):
             """chunk_logits: per-line list (ragged launches, GPU-built csc or dense [T_i, C]) or [n, T, C] array."""
+            transcriptions, logits_out, coords_out = job.transcriptions, job.logits_out, job.coords_out
             for k, i in enumerate(line_ids):
                 transcriptions[i] = texts[k]
                 if conf is not None:
-                    self.line_confidences[i] = float(conf[k])
+                    job.confidences[i] = float(conf[k])
             if no_logits:
                 return
             if on_device:               # chunk_logits is already a list of csc_matrix (built on the GPU)
@@ -225,32 +272,37 @@ class BaseEngineLineOCR:
                 if sparse_logits:
                     ll = sparse.csc_matrix(np.where(softmax(ll, axis=1) < SPARSE_PROB_THRESHOLD, np.float32(0), ll))
                 logits_out[i] = ll
+        job.scatter = scatter
 
-        # One-deep software pipeline over the chunks: chunk k+1 is enqueued on the other engine slot
-        # before chunk k is collected, so its GPU work overlaps chunk k's read-back and the host-side
-        # softmax / CSC assembly.  (The reference runs chunk after chunk, line_ocr_engine.py:80-129;
-        # the chunks are independent, so the results are the same.)
         for chunk in chunks:
             if chunk.max_width + 2 * pad > chunk.w_pad:
                 print(f"WARNING: Line too long for OCR engine. Cropping from {chunk.max_width + 2 * pad} px "
                       f"down to {chunk.w_pad}.")
-        if not hasattr(self, "_submit_launch"):          # engines without the asynchronous ragged path
+        if not hasattr(self, "_submit_launch"):          # engines without the asynchronous ragged path: chunk after chunk
             for chunk in chunks:
                 scatter(chunk.line_ids, *self._recognise_chunk(lines, chunk, want_logits=not no_logits))
-            return transcriptions, logits_out, coords_out
+            return job
 
         # Software pipeline over LAUNCHES (merged chunks): launch k+1 is enqueued on another engine slot before launch k is
         # collected, so its GPU work overlaps launch k's read-back and the host-side assembly.  (The reference runs chunk
         # after chunk, line_ocr_engine.py:80-129; lines are independent given their padded width, so the results are the same.)
         # `depth` launches in flight (one engine slot each): with long lines the recurrent layers of a launch are a chain of
-        # ~2 T dependent 12-us steps that leaves the GPU mostly idle - several chains side by side fill it (pages of 3-4 k px
+        # ~2 T dependent steps that leaves the GPU mostly idle - several chains side by side fill it (pages of 3-4 k px
         # lines: 2 -> 4 launches in flight is +30 %); with short lines one chain already hides behind the next launch's convs.
+        # The queue of launches in flight belongs to the ENGINE: launch number s runs on slot s % depth, which is free once
+        # launch s - depth has been collected - whichever call (ticket) that one belongs to.
         from collections import deque
-        pending = deque()
+        if getattr(self, "_inflight", None) is None:
+            self._inflight = deque()
+            self._launch_seq = 0
         depth = pipeline_depth(self)
+        if self._inflight and depth != getattr(self, "_inflight_depth", depth):
+            while self._inflight:                        # the depth was changed between calls: start from an empty pipeline
+                self._collect_oldest()
+        self._inflight_depth = depth
         max_sparse_frames = getattr(self, "device_sparsify_max_frames", 0)
         try:
-            for k, launch in enumerate(plan_launches(chunks, launch_target(self))):
+            for launch in plan_launches(chunks, launch_target(self)):
                 rows = None
                 frames = [(wp // 2) // 2 for wp in launch.w_pads]
                 # the GPU sparsification kernels hold one line's frames per workgroup pass: launches with longer lines
@@ -261,20 +313,31 @@ class BaseEngineLineOCR:
                     if tight_crop_logits:
                         ws = [lines[i].shape[1] for i in launch.line_ids]
                         rows = ([min(pad // sub, f) for f in frames], [min((pad + w) // sub, f) for w, f in zip(ws, frames)])
-                while len(pending) >= depth:             # slot k % depth is free again once launch k - depth has been collected
-                    old = pending.popleft()
-                    scatter(old[0].line_ids, *self._collect_launch(old[1]), on_device=old[2])
-                handle = self._submit_launch(lines, launch, not no_logits, k % depth, rows)
-                pending.append((launch, handle, launch_sparse))
-            while pending:
-                old = pending.popleft()
-                scatter(old[0].line_ids, *self._collect_launch(old[1]), on_device=old[2])
-        except BaseException:
-            reset = getattr(getattr(self, "model", None), "reset", None)
-            if reset is not None:
-                reset()               # a launch may still be in flight on either slot: leave the engine usable
+                while len(self._inflight) >= depth:      # slot s % depth is free again once launch s - depth has been collected
+                    self._collect_oldest()
+                handle = self._submit_launch(lines, launch, not no_logits, self._launch_seq % depth, rows)
+                self._launch_seq += 1
+                job.open_launches += 1
+                self._inflight.append((job, launch, handle, launch_sparse))
+        except BaseException as exc:
+            self._abort_inflight(exc)
             raise
-        return transcriptions, logits_out, coords_out
+        return job
+
+
+class _LinesJob:
+    """Ticket of one process_lines call: its result lists and the number of its launches still in flight."""
+    __slots__ = ("transcriptions", "logits_out", "coords_out", "confidences", "open_launches", "scatter", "error", "done")
+
+    def __init__(self, n: int):
+        self.transcriptions: List[Optional[str]] = [None] * n
+        self.logits_out: List[object] = [None] * n
+        self.coords_out: List[Optional[list]] = [None] * n
+        self.confidences: List[Optional[float]] = [None] * n
+        self.open_launches = 0
+        self.scatter = None
+        self.error = None
+        self.done = False
 
 
 # ---- helpers of the "transformer" branch (over-long lines are recognised in overlapping parts) -------------

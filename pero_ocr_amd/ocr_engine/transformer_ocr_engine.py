@@ -122,6 +122,11 @@ def plan_launches(batches: Sequence[_Batch]) -> List[List[_Batch]]:
 
 
 class TransformerEngineLineOCR(BaseEngineLineOCR):
+    # the two halves of the CTC form's process_lines (BaseEngineLineOCR.process_lines_begin / _end) do not apply here:
+    # this engine overrides process_lines with the reference's "transformer" branches (callers look for None)
+    process_lines_begin = None
+    process_lines_end = None
+
     def __init__(self, json_def, device, batch_size=4):
         super().__init__(json_def, device, batch_size=batch_size, model_type="transformer")
         self.characters = list(self.characters) + ["\u200B", ""]            # transformer_ocr_engine.py:16
