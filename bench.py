@@ -764,11 +764,13 @@ def main():
                 "vs_bf16x3_ceiling_416.7": round(dom_tf / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
                 "vs_fp32_mfma_peak_157.3": round(dom_tf / F32_MFMA_PEAK_TFLOPS, 4)}
             if split:
-                # measured on this part (tools/mfma_bf16_peak.hip, profiles/r02_mfma_bf16_sustained.txt): a register-only loop of
-                # independent v_mfma_f32_16x16x32_bf16 sustains 2.30 PFLOP/s on zero operands and 1.85-1.91 PFLOP/s on random
-                # ones (power-limited clock), and one wave per SIMD cannot issue more than 1.5 PFLOP/s
-                result["roofline"]["sustained_mfma_probe"] = {"random_operands_tflops": 1880.0, "zero_operands_tflops": 2300.0,
-                                                              "frac_of_sustained_random": round(nm * dom_tf / 1880.0, 4)}
+                # measured on this part, register-only loops of independent MFMAs, 2 waves per SIMD, at the package power cap:
+                # v_mfma_f32_16x16x32_f16 sustains 2432 TFLOP/s on zero operands and 2027 on random ones (tools/mfma_shape_probe.hip,
+                # profiles/r04_mfma_shape_probe.txt); v_mfma_f32_16x16x32_bf16 2300 / 1880 (tools/mfma_bf16_peak.hip,
+                # profiles/r02_mfma_bf16_sustained.txt) - constants from those committed files, not measured in this run
+                probe = {2: (2027.0, 2432.0, "profiles/r04_mfma_shape_probe.txt"), 3: (1880.0, 2300.0, "profiles/r02_mfma_bf16_sustained.txt")}[split]
+                result["roofline"]["sustained_mfma_probe"] = {"random_operands_tflops": probe[0], "zero_operands_tflops": probe[1], "source": probe[2],
+                                                              "frac_of_sustained_random": round(nm * dom_tf / probe[0], 4)}
             result["conv_backbone"] = {"achieved": round(conv_tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                        "frac": round(conv_tf / peak, 4),
                                        "vs_bf16x3_ceiling_416.7": round(conv_tf / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),

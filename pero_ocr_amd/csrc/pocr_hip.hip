@@ -561,6 +561,7 @@ struct pocr_engine {
     Slot slot[POCR_NUM_SLOTS + 1];   // the last one is internal (padding-column constants), not reachable through the API
     int last_slot = 0;               // slot of the most recent launch (stage timings / debug taps)
     size_t sp_prev_total = 0;        // kept entries of the most recent sparse launch (sizes the next speculative copy)
+    int sp_prev_rows = 0;            // ... and its frames
     bool use_graphs = true;          // replay the LSTM recurrence from captured hipGraphs (POCR_NO_GRAPHS=1 disables)
     bool profiling = false;
     Comm comm;                       // RCCL communicator of the multi-GPU path (comm.hpp); inactive on a single GPU
@@ -1276,9 +1277,16 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
         const size_t off_bytes = (size_t)(n + 1) * sizeof(int64_t), ip_bytes = (size_t)n * (C + 1) * sizeof(int32_t);
         // The number of kept entries is known only on the device, but a copy enqueued at collect time would
         // queue up behind the NEXT launch's conv kernels (measured: 31 ms per launch).  So the triplets are
-        // copied back speculatively now, in stream order: 1.25x the previous launch's count (first launch:
-        // 1/3 density); collect tops up the rest in the rare case that was not enough.
-        size_t spec = e->sp_prev_total ? e->sp_prev_total + e->sp_prev_total / 4 : cap / 3;
+        // copied back speculatively now, in stream order: 1.25x the previous launch's kept entries PER FRAME times this
+        // launch's frames (launches of one call differ in size - the last one of a call, pages of different lengths - and a
+        // copy sized by the previous launch's absolute count then falls short: 10-20 ms per launch measured,
+        // profiles/r04_launch_timeline.txt); first launch: 1/3 density; collect tops up the rest in the rare case
+        // that was not enough.
+        size_t spec = cap / 3;
+        if (e->sp_prev_total && e->sp_prev_rows > 0) {
+            const double per_row = (double)e->sp_prev_total / (double)e->sp_prev_rows;
+            spec = (size_t)(per_row * 1.25 * (double)std::max(s.rows, 1)) + 4096;
+        }
         if (const char *env = getenv("POCR_SPARSE_SPEC")) spec = (size_t)std::max(1L, atol(env));     // tests: force the top-up path
         spec = std::min(spec, cap);
         const size_t conf_off = off_bytes + ip_bytes;                    // [line_off | indptr | confidence | data | indices]
@@ -2219,6 +2227,7 @@ int pocr_slot_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t 
         }
     }
     e->sp_prev_total = (size_t)total;
+    e->sp_prev_rows = s.rows;
     return collect_outputs(e, s, nullptr, frame_argmax_nt, labels_nt, label_len_n);
 }
 
