@@ -332,7 +332,7 @@ static int parsenet_get_maps_impl(pocr_parsenet *p, const uint8_t *img_hwc, int3
                 return fail("layout network: conv layer %d left the range of the default f16x2 arithmetic (%s) - set POCR_CONV_SPLIT=3 (bf16x3, fp32's range)",
                             k + 1, m >= 0x477fe000u ? "|x| >= 65504 or not finite" : "its whole activation lies below 2^-13");
         }
-    memcpy(out_hw5, p->pin_out, out_bytes);
+    parallel_memcpy(out_hw5, p->pin_out, out_bytes);
     HIP_TRY(hipEventElapsedTime(&p->last_ms, p->ev0, p->ev1));
     return 0;
 }

@@ -104,6 +104,26 @@ inline hipError_t upload_through_pinned(void *dev, void *pin, const void *src, s
     return (hipError_t)err.load();
 }
 
+// Host copy of a large result (the layout maps: 15.7 MB per 4k x 3k page, into a fresh numpy array whose pages are touched for the
+// first time) split over the same helper threads.
+inline void parallel_memcpy(void *dst, const void *src, size_t bytes) {
+    const size_t piece = (size_t)2 << 20;
+    const size_t n_pieces = (bytes + piece - 1) / piece;
+    const int n_threads = (int)std::min<size_t>((size_t)upload_threads(), std::max<size_t>(n_pieces, 1));
+    if (n_threads <= 1) { std::memcpy(dst, src, bytes); return; }
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t i = next.fetch_add(1); i < n_pieces; i = next.fetch_add(1)) {
+            const size_t o = i * piece;
+            std::memcpy(static_cast<uint8_t *>(dst) + o, static_cast<const uint8_t *>(src) + o, std::min(piece, bytes - o));
+        }
+    };
+    std::vector<std::thread> helpers;
+    for (int t = 1; t < n_threads; ++t) helpers.emplace_back(work);
+    work();
+    for (std::thread &h : helpers) h.join();
+}
+
 // The streams of the page front (layout network, cropper).  In a page stream their kernels share the GPU with the recogniser's
 // convolutions of EARLIER pages; the front is a chain of short dependent launches with host steps between them, so what it needs is
 // latency: POCR_FRONT_PRIORITY=high puts its streams at the device's greatest priority (default: see DESIGN section 5).
