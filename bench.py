@@ -742,8 +742,13 @@ def main():
             fl = conv_flops_per_line(w_pad)
             dom = "conv9"                                    # 24 % of the conv FLOPs, the largest single kernel
             dom_tf = fl[dom] * n_lines / (ms[dom] * 1e-3) / 1e12
+            # Since round 4 the backbone of launch k+1 starts behind conv5 of launch k (profiles/r04_backbone_overlap.txt): two backbones
+            # share the chip for half a step, so a stage's event-to-event time contains the other launch's kernels and the stage times
+            # no longer add up to a step (their sum is reported as `sum_of_stage_events_ms`).  The backbone's rate is therefore its FLOPs
+            # per step over the step's WALL time - a lower bound: the step also contains whatever the sequence stage is not hidden behind.
             conv_ms = sum(ms[k] for k in fl)
-            conv_tf = sum(fl.values()) * n_lines / (conv_ms * 1e-3) / 1e12
+            step_ms = 1e3 * elapsed / args.steps
+            conv_tf = sum(fl.values()) * n_lines / (step_ms * 1e-3) / 1e12
             kname = (f"conv3x3_bf16x3_kernel<TH5,MW1,NS2,leaky+BN,{SPLIT_NAME[split]}>" if split else "conv_igemm_kernel<3x3,TH5,NT256,leaky+BN>")
             nm = MFMA_PER_BLOCK[split]
             result["roofline"] = {
@@ -755,6 +760,9 @@ def main():
                 "traffic_source_head": pmc_meta.get("head", "") if traffic is not None else None,
                 "traffic_library_source_hash": pmc_meta.get("library_source_hash", "") if traffic is not None else None,
                 "flops_per_launch": fl[dom] * n_lines, "avg_launch_ms": round(ms[dom], 4),
+                "concurrency": ("in the timed region a launch of this kernel shares the chip with conv2..conv5 of the NEXT launch's backbone (backbones overlap "
+                                "from conv5 on, profiles/r04_backbone_overlap.txt) and with the previous launch's sequence stage: its duration is a lower "
+                                "bound of the kernel's own rate; `alone` = one chunk at a time, nothing else on the GPU") if n_slots > 1 else "one launch in flight",
                 "peak_dtype": {2: "algorithmic fp32 FLOPs on the f16 MFMA pipe: operands as two f16 planes, 3 v_mfma_f32_16x16x32_f16 per 32-deep "
                                   "block -> ceiling = 2500 TFLOP/s dense f16 / 3; executed MFMA rate = 3 x achieved",
                                3: "algorithmic fp32 FLOPs on the bf16 MFMA pipe: exact 3-way bf16 split, 6 v_mfma_f32_16x16x32_bf16 per "
@@ -775,7 +783,9 @@ def main():
                                        "frac": round(conv_tf / peak, 4),
                                        "vs_bf16x3_ceiling_416.7": round(conv_tf / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
                                        "vs_fp32_mfma_peak_157.3": round(conv_tf / F32_MFMA_PEAK_TFLOPS, 4),
-                                       "gflop_per_line": round(sum(fl.values()) / 1e9, 3), "ms_per_step": round(conv_ms, 3),
+                                       "gflop_per_line": round(sum(fl.values()) / 1e9, 3), "ms_per_step": round(step_ms, 3),
+                                       "definition": "conv FLOPs of a step / the step's wall time (overlapping backbones: stage events are not additive)",
+                                       "sum_of_stage_events_ms": round(conv_ms, 3),
                                        "note": ("conv1 (uint8 crops -> 64 channels, K = 27: one f16x2 product block) is computed inside conv2's prologue for the "
                                                 "workgroup's own halo tile: its FLOPs (counted once, not per halo overlap) and its time are conv2's" if split == 2 else
                                                 "conv1 (K = 27) stays on its fused uint8 -> fp32-MFMA kernel" if split else "")}
@@ -789,6 +799,8 @@ def main():
                                              f"{SPLIT_NAME[split]} kernel in GEMM mode (attention, LayerNorm, head: fp32)" if split else
                                              "LayerNorm+PE, encoder layers (QKV / attention / out / FFN) and the head, stage events"}
             result["stage_ms"] = {k: round(v, 4) for k, v in ms.items()}
+            result["stage_ms_note"] = ("event-to-event times on each launch's own streams with several launches in flight: a stage's time contains the kernels of the "
+                                       "other launch it shares the chip with, the stages do not add up to ms_per_step; stage_ms_alone: one chunk at a time")
             if ms_alone:
                 # the same kernels with the GPU to themselves (one chunk at a time): what the two-chunk overlap costs each stage
                 conv_ms_a = sum(ms_alone[k] for k in fl)

@@ -742,6 +742,44 @@ def test_random_page_stream_against_oracle(small, tmp_path):
     assert worst < LOGIT_TOL, worst
 
 
+def test_process_lines_in_two_halves_equals_the_plain_calls(small, tmp_path):
+    """process_lines_begin / process_lines_end with TWO calls in flight on one engine (the page stream's arrangement): every
+    list equals what the plain calls return - strings, coords, dense logits bit for bit, sparse logits entry for entry, and the
+    confidences side channel belongs to the call that was ended.  Reference contract: line_ocr_engine.py:57-177."""
+    import json
+    import os
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    chars = synth.make_charset(99)
+    path = os.path.join(str(tmp_path), "ocr.json")
+    json.dump({"line_px_height": 40, "line_vertical_scale": 1.0, "checkpoint": "absent.pocrw", "characters": chars,
+               "net_name": "x", "net": {"weight_seed": 20260928}}, open(path, "w"))
+    eng = PytorchEngineLineOCR(path, Dev())
+    eng.launch_work_target = 6000                       # many launches per call: the two calls interleave on the slots
+    la = synth.make_crops(178, synth.make_widths(177, 60, lo=20, hi=900))
+    lb = synth.make_crops(278, synth.make_widths(277, 45, lo=1, hi=1500))
+    want_a = eng.process_lines(la)
+    conf_a = list(eng.line_confidences)
+    want_b = eng.process_lines(lb, sparse_logits=False, tight_crop_logits=True)
+    want_c = eng.process_lines(la, no_logits=True)
+    for depth in (2, 4):
+        eng.pipeline_depth = depth
+        ta = eng.process_lines_begin(la)
+        tb = eng.process_lines_begin(lb, sparse_logits=False, tight_crop_logits=True)
+        tc = eng.process_lines_begin(la, no_logits=True)
+        got_a = eng.process_lines_end(ta)
+        assert list(eng.line_confidences) == conf_a
+        got_b = eng.process_lines_end(tb)
+        got_c = eng.process_lines_end(tc)
+        assert got_a[0] == want_a[0] and got_a[2] == want_a[2]
+        for m, w in zip(got_a[1], want_a[1]):
+            assert m.shape == w.shape and np.array_equal(m.indptr, w.indptr) and np.array_equal(m.indices, w.indices) and np.array_equal(m.data, w.data)
+        assert got_b[0] == want_b[0] and got_b[2] == want_b[2]
+        for m, w in zip(got_b[1], want_b[1]):
+            assert np.array_equal(m, w)
+        assert got_c == want_c
+    assert not eng._inflight
+
+
 def test_engine_lifecycle_and_buffer_growth(small):
     """Engines can be created and destroyed repeatedly, and one engine can see growing and shrinking
     chunks (device buffers are re-reserved on demand) without changing results."""

@@ -12,5 +12,5 @@ cp $O/stage_ms_c2_alone.txt $P/r04_stage_ms_c2_single_chunk_alone.txt
 cp $O/stage_ms_c4_alone.txt $P/r04_stage_ms_c4_single_chunk_alone.txt
 cp $O/crop_bench.txt $P/r04_crop_bench_resident.txt
 cp $O/gemm_bench.txt $P/r04_gemm_bench.txt
-grep -o "\[c[0-9a-z ]*\].*\|\[rescale.*\|\[range.*\|\[smoke.*\|[0-9]* passed.*\|[0-9]* failed.*" $O/pytest_gpu.txt > $P/r04_parity_prints.txt || true
+grep -oE "\[c[0-9a-z ]*\].*|\[rescale.*|\[range.*|\[smoke.*|\[full.*|^[0-9]+ passed.*|^[0-9]+ failed.*" $O/pytest_gpu.txt > $P/r04_parity_prints.txt || true
 ls $P | grep r04_ | wc -l
