@@ -482,7 +482,7 @@ struct Slot {
     // device-side CSC sparsification of the logits (sparsify.hpp)
     bool want_sparse = false;
     float sp_thr = 1e-4f;
-    DevBuf sp_rowstat, sp_colcount, sp_line_nnz, sp_line_off, sp_indptr, sp_data, sp_indices, sp_rows, sp_conf;
+    DevBuf sp_rowstat, sp_colcount, sp_line_nnz, sp_line_off, sp_indptr, sp_data, sp_indices, sp_rows, sp_conf, sp_bid, sp_bp;   // sp_colcount: [n][frame blocks][C]
     bool sp_has_rows = false;
     size_t sp_spec = 0;              // entries copied back speculatively at launch time
     void *sp_pinned = nullptr;       // [line_off (n+1) int64 | indptr n*(C+1) int32] then data | indices at collect time
@@ -1274,25 +1274,21 @@ int enqueue_outputs(pocr_engine *e, Slot &s) {
     HIP_TRY(hipMemcpyAsync(pin + 2 * nt_bytes, s.lens.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (lg_bytes) HIP_TRY(hipMemcpyAsync(pin + 2 * nt_bytes + (size_t)round_up(n, 4) * sizeof(int32_t), s.logits.p, lg_bytes, hipMemcpyDeviceToHost, st));
     if (s.want_sparse) {
-        if (T > SP_MAXT) return fail("sparse logits: T = %d exceeds %d frames", T, SP_MAXT);
         if (C > 256 * SP_COLS) return fail("sparse logits: C = %d exceeds %d classes", C, 256 * SP_COLS);
         const size_t cap = (size_t)rows * C;
-        if (s.sp_rowstat.reserve((size_t)rows * 2 * sizeof(float)) || s.sp_colcount.reserve((size_t)n * C * sizeof(int32_t)) ||
+        const int nblk = sp_blocks(T);                       // T: the launch's longest line
+        if (s.sp_rowstat.reserve((size_t)rows * 2 * sizeof(float)) || s.sp_colcount.reserve((size_t)n * nblk * C * sizeof(int32_t)) ||
             s.sp_line_nnz.reserve((size_t)n * sizeof(int32_t)) || s.sp_line_off.reserve((size_t)(n + 1) * sizeof(int64_t)) ||
             s.sp_indptr.reserve((size_t)n * (C + 1) * sizeof(int32_t)) || s.sp_data.reserve(cap * sizeof(float)) ||
-            s.sp_indices.reserve(cap * sizeof(int32_t)))
+            s.sp_indices.reserve(cap * sizeof(int32_t)) || s.sp_conf.reserve((size_t)n * sizeof(float)) ||
+            s.sp_bid.reserve((size_t)rows * sizeof(int32_t)) || s.sp_bp.reserve((size_t)rows * sizeof(float)))
             return 1;
         const int32_t *r0 = s.sp_has_rows ? s.sp_rows.as<int32_t>() : nullptr;
         const int32_t *r1 = s.sp_has_rows ? s.sp_rows.as<int32_t>() + n : nullptr;
-        hipLaunchKernelGGL(sparse_count_kernel, dim3(n), dim3(256), 0, st, s.logits.as<float>(), r0, r1, s.sp_rowstat.as<float>(),
-                           s.sp_colcount.as<int32_t>(), s.sp_line_nnz.as<int32_t>(), T, C, s.sp_thr, s.g_line_T, s.g_row_off);
-        if (s.sp_conf.reserve((size_t)n * sizeof(float))) return 1;
-        hipLaunchKernelGGL(line_confidence_kernel, dim3(n), dim3(256), 0, st, s.logits.as<float>(), r0, r1, s.sp_rowstat.as<float>(),
-                           s.sp_conf.as<float>(), T, C, s.sp_thr, -80.0f, s.g_line_T, s.g_row_off);
-        hipLaunchKernelGGL(sparse_scan_kernel, dim3(1), dim3(64), 0, st, s.sp_line_nnz.as<int32_t>(), s.sp_line_off.as<int64_t>(), n);
-        hipLaunchKernelGGL(sparse_fill_kernel, dim3(n), dim3(256), 0, st, s.logits.as<float>(), r0, r1, s.sp_rowstat.as<float>(),
-                           s.sp_colcount.as<int32_t>(), s.sp_line_off.as<int64_t>(), s.sp_indptr.as<int32_t>(), s.sp_data.as<float>(),
-                           s.sp_indices.as<int32_t>(), T, C, s.sp_thr, (int64_t)cap, s.g_line_T, s.g_row_off);
+        sparsify_launch(st, s.logits.as<float>(), r0, r1, s.sp_rowstat.as<float>(), s.sp_colcount.as<int32_t>(), s.sp_line_nnz.as<int32_t>(),
+                        s.sp_line_off.as<int64_t>(), s.sp_indptr.as<int32_t>(), s.sp_data.as<float>(), s.sp_indices.as<int32_t>(),
+                        s.sp_bid.as<int32_t>(), s.sp_bp.as<float>(), s.sp_conf.as<float>(), n, T, T, C, s.sp_thr, -80.0f, (int64_t)cap,
+                        s.g_line_T, s.g_row_off);
         HIP_TRY(hipGetLastError());
         const size_t off_bytes = (size_t)(n + 1) * sizeof(int64_t), ip_bytes = (size_t)n * (C + 1) * sizeof(int32_t);
         // The number of kept entries is known only on the device, but a copy enqueued at collect time would
@@ -1813,7 +1809,7 @@ void pocr_destroy(pocr_engine *e) {
             if (ev) (void)hipEventDestroy(ev);
         for (DevBuf *b : {&s.crops, &s.lines, &s.feat, &s.xproj, &s.hbuf, &s.cbuf, &s.logits, &s.best, &s.labels, &s.lens,
                           &s.sa_x, &s.sa_x1, &s.sa_qkv, &s.sa_att, &s.sa_tmp, &s.sa_ff, &s.sa_xp2, &s.sa_x1p2, &s.feat_p2, &s.sp_rowstat, &s.sp_colcount,
-                          &s.sp_line_nnz, &s.sp_line_off, &s.sp_indptr, &s.sp_data, &s.sp_indices, &s.sp_rows, &s.sp_conf, &s.geom, &s.seqgeom})
+                          &s.sp_line_nnz, &s.sp_line_off, &s.sp_indptr, &s.sp_data, &s.sp_indices, &s.sp_rows, &s.sp_conf, &s.sp_bid, &s.sp_bp, &s.geom, &s.seqgeom})
             b->release();
         if (s.pinned) (void)locked_host_free(s.pinned);
         if (s.sp_pinned) (void)locked_host_free(s.sp_pinned);
@@ -2663,7 +2659,6 @@ int pocr_s2s_sparse(pocr_engine *e, int32_t slot, const int32_t *row_end, float 
     if (!row_end || !total_nnz) return fail("NULL pointer");
     HIP_TRY(hipSetDevice(e->device));
     const int n = s.n, S_cap = s.s2s_cap, C = e->cfg.num_classes;
-    if (S_cap > SP_MAXT) return fail("sparse logits: %d steps exceed %d", S_cap, SP_MAXT);
     if (C > 256 * SP_COLS) return fail("sparse logits: C = %d exceeds %d classes", C, 256 * SP_COLS);
     size_t cap = 0;
     for (int i = 0; i < n; ++i) {
@@ -2671,7 +2666,7 @@ int pocr_s2s_sparse(pocr_engine *e, int32_t slot, const int32_t *row_end, float 
         cap += (size_t)row_end[i] * C;
     }
     hipStream_t st = s.seq_stream;
-    if (s.sp_rowstat.reserve((size_t)n * S_cap * 2 * sizeof(float)) || s.sp_colcount.reserve((size_t)n * C * sizeof(int32_t)) ||
+    if (s.sp_rowstat.reserve((size_t)n * S_cap * 2 * sizeof(float)) || s.sp_colcount.reserve((size_t)n * sp_blocks(S_cap) * C * sizeof(int32_t)) ||
         s.sp_line_nnz.reserve((size_t)n * sizeof(int32_t)) || s.sp_line_off.reserve((size_t)(n + 1) * sizeof(int64_t)) ||
         s.sp_indptr.reserve((size_t)n * (C + 1) * sizeof(int32_t)) || s.sp_data.reserve(std::max<size_t>(cap, 1) * sizeof(float)) ||
         s.sp_indices.reserve(std::max<size_t>(cap, 1) * sizeof(int32_t)) || s.sp_rows.reserve((size_t)n * sizeof(int32_t)))
@@ -2690,14 +2685,9 @@ int pocr_s2s_sparse(pocr_engine *e, int32_t slot, const int32_t *row_end, float 
     HIP_TRY(hipMemcpyAsync(s.sp_rows.p, h_rows, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
     const int32_t *r1 = s.sp_rows.as<int32_t>();
     // decoder logits: line i owns rows [i * S_cap, (i + 1) * S_cap); rows [0, row_end[i]) are compacted
-    hipLaunchKernelGGL(sparse_count_kernel, dim3(n), dim3(256), 0, st, s.s2s_logits.as<float>(), (const int32_t *)nullptr, r1,
-                       s.sp_rowstat.as<float>(), s.sp_colcount.as<int32_t>(), s.sp_line_nnz.as<int32_t>(), S_cap, C, threshold,
-                       (const int32_t *)nullptr, (const int32_t *)nullptr);
-    hipLaunchKernelGGL(sparse_scan_kernel, dim3(1), dim3(64), 0, st, s.sp_line_nnz.as<int32_t>(), s.sp_line_off.as<int64_t>(), n);
-    hipLaunchKernelGGL(sparse_fill_kernel, dim3(n), dim3(256), 0, st, s.s2s_logits.as<float>(), (const int32_t *)nullptr, r1,
-                       s.sp_rowstat.as<float>(), s.sp_colcount.as<int32_t>(), s.sp_line_off.as<int64_t>(), s.sp_indptr.as<int32_t>(),
-                       s.sp_data.as<float>(), s.sp_indices.as<int32_t>(), S_cap, C, threshold, (int64_t)std::max<size_t>(cap, 1),
-                       (const int32_t *)nullptr, (const int32_t *)nullptr);
+    sparsify_launch(st, s.s2s_logits.as<float>(), nullptr, r1, s.sp_rowstat.as<float>(), s.sp_colcount.as<int32_t>(), s.sp_line_nnz.as<int32_t>(),
+                    s.sp_line_off.as<int64_t>(), s.sp_indptr.as<int32_t>(), s.sp_data.as<float>(), s.sp_indices.as<int32_t>(), nullptr, nullptr, nullptr,
+                    n, S_cap, S_cap, C, threshold, -80.0f, (int64_t)std::max<size_t>(cap, 1), nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(sp, s.sp_line_off.p, off_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(sp + off_bytes, s.sp_indptr.p, ip_bytes, hipMemcpyDeviceToHost, st));
@@ -2785,7 +2775,6 @@ int pocr_sparsify(int device_id, const float *logits_ntc, int32_t n, int32_t T, 
                   float *data, int32_t *indices, int64_t capacity, int32_t *indptr, int64_t *line_off) {
     if (!logits_ntc || !data || !indices || !indptr || !line_off) return fail("NULL pointer");
     if (n <= 0 || T <= 0 || C < 1) return fail("need n > 0, T > 0, C >= 1 (got %d, %d, %d)", n, T, C);
-    if (T > SP_MAXT) return fail("sparse logits: T = %d exceeds %d frames", T, SP_MAXT);
     if (C > 256 * SP_COLS) return fail("sparse logits: C = %d exceeds %d classes", C, 256 * SP_COLS);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available: this library has no CPU fallback");
@@ -2793,18 +2782,14 @@ int pocr_sparsify(int device_id, const float *logits_ntc, int32_t n, int32_t T, 
     HIP_TRY(hipSetDevice(device_id));
     DevBuf lg, rowstat, colcount, nnz, off, ip, dd, di;
     const size_t cap = (size_t)n * T * C;
-    int rc = lg.reserve(cap * sizeof(float)) || rowstat.reserve((size_t)n * T * 2 * sizeof(float)) || colcount.reserve((size_t)n * C * sizeof(int32_t)) ||
+    int rc = lg.reserve(cap * sizeof(float)) || rowstat.reserve((size_t)n * T * 2 * sizeof(float)) || colcount.reserve((size_t)n * sp_blocks(T) * C * sizeof(int32_t)) ||
              nnz.reserve((size_t)n * sizeof(int32_t)) || off.reserve((size_t)(n + 1) * sizeof(int64_t)) ||
              ip.reserve((size_t)n * (C + 1) * sizeof(int32_t)) || dd.reserve(cap * sizeof(float)) || di.reserve(cap * sizeof(int32_t));
     auto done = [&](int r) { for (DevBuf *b : {&lg, &rowstat, &colcount, &nnz, &off, &ip, &dd, &di}) b->release(); return r; };
     if (rc) return done(1);
     if (locked_memcpy(lg.p, logits_ntc, cap * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return done(fail("H2D copy failed"));
-    hipLaunchKernelGGL(sparse_count_kernel, dim3(n), dim3(256), 0, 0, lg.as<float>(), (const int32_t *)nullptr, (const int32_t *)nullptr,
-                       rowstat.as<float>(), colcount.as<int32_t>(), nnz.as<int32_t>(), T, C, threshold, (const int32_t *)nullptr, (const int32_t *)nullptr);
-    hipLaunchKernelGGL(sparse_scan_kernel, dim3(1), dim3(64), 0, 0, nnz.as<int32_t>(), off.as<int64_t>(), n);
-    hipLaunchKernelGGL(sparse_fill_kernel, dim3(n), dim3(256), 0, 0, lg.as<float>(), (const int32_t *)nullptr, (const int32_t *)nullptr,
-                       rowstat.as<float>(), colcount.as<int32_t>(), off.as<int64_t>(), ip.as<int32_t>(), dd.as<float>(), di.as<int32_t>(), T, C,
-                       threshold, (int64_t)cap, (const int32_t *)nullptr, (const int32_t *)nullptr);
+    sparsify_launch(0, lg.as<float>(), nullptr, nullptr, rowstat.as<float>(), colcount.as<int32_t>(), nnz.as<int32_t>(), off.as<int64_t>(), ip.as<int32_t>(),
+                    dd.as<float>(), di.as<int32_t>(), nullptr, nullptr, nullptr, n, T, T, C, threshold, -80.0f, (int64_t)cap, nullptr, nullptr);
     if (hipGetLastError() != hipSuccess || locked_device_sync() != hipSuccess) return done(fail("sparsify kernels failed"));
     if (locked_memcpy(line_off, off.p, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));
     if (locked_memcpy(indptr, ip.p, (size_t)n * (C + 1) * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return done(fail("D2H copy failed"));

@@ -305,8 +305,8 @@ class BaseEngineLineOCR:
             for launch in plan_launches(chunks, launch_target(self)):
                 rows = None
                 frames = [(wp // 2) // 2 for wp in launch.w_pads]
-                # the GPU sparsification kernels hold one line's frames per workgroup pass: launches with longer lines
-                # (batch_size > 8 and a padded width over 4096 px) take the dense read-back + host softmax / CSC instead
+                # an engine may bound the frames per line its GPU sparsification takes (`device_sparsify_max_frames`; the HIP engine: no bound
+                # since round 4): launches with longer lines take the dense read-back + host softmax / CSC instead
                 launch_sparse = device_sparse and max(frames, default=0) <= max_sparse_frames
                 if launch_sparse:
                     rows = (None, None)

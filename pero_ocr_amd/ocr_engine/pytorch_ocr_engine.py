@@ -310,7 +310,7 @@ class PytorchEngineLineOCR(BaseEngineLineOCR):
         return texts, (np.stack(per_line) if per_line is not None else None)
 
     supports_device_sparsify = True
-    device_sparsify_max_frames = 1024      # SP_MAXT of csrc/sparsify.hpp
+    device_sparsify_max_frames = 1 << 30   # csrc/sparsify.hpp works on blocks of 64 frames: no limit on a line's length (rounds 1-3: 1024)
 
     def frame_argmax(self, batch_data) -> np.ndarray:
         """Per-frame class ids [n, T] (what greedy_decode_ctc's torch.argmax sees)."""
