@@ -81,6 +81,8 @@ class Launch:
         return sum(len(c.line_ids) * c.w_pad for c in self.chunks)
 
 
+CHAIN_BOUND_FRAMES = 512              # a call whose longest line has at least this many frames (2048 px) ...
+CHAIN_BOUND_MIN_WORK = 24 * 1024      # ... and at least three times this many padded columns is cut into three launches (see _begin_chunks)
 LAUNCH_WORK_TARGET = 256 * 384          # padded pixel columns per launch (measured on the c3 stream: 82-98 k is 2-3 % better than 147 k; c5 neutral)
 
 
@@ -295,14 +297,28 @@ class BaseEngineLineOCR:
         if getattr(self, "_inflight", None) is None:
             self._inflight = deque()
             self._launch_seq = 0
+        if not self._inflight:
+            self._launch_seq = 0                         # an isolated call numbers its launches from slot 0, whatever ran before
         depth = pipeline_depth(self)
+        launches = plan_launches(chunks, launch_target(self))
+        # A lone call of one or two launches of LONG lines is bound by its recurrence chains (2 x T dependent steps per launch), not by
+        # its convolutions: three launches in flight start the longest chain after a third of the convolutions instead of half
+        # (one 4k x 3k page of 47 lines: 14.8-15.6 -> 13.9-14.6 ms, profiles/r04_sparse_blocks.txt).  Streams of calls and calls of
+        # short lines keep the plan above (smaller launches cost them conv efficiency: c5 stream 64 -> 55 pages/s at half the target).
+        if (not self._inflight and len(launches) <= 2 and getattr(self, "pipeline_depth", None) is None and
+                "POCR_PIPELINE_DEPTH" not in os.environ and getattr(getattr(self, "model", None), "num_slots", 2) >= 3):
+            total = sum(l.work for l in launches)
+            longest = max((ch.frames for ch in chunks), default=0)
+            if longest >= CHAIN_BOUND_FRAMES and total >= 3 * CHAIN_BOUND_MIN_WORK:
+                launches = plan_launches(chunks, -(-total // 3))
+                depth = 3
         if self._inflight and depth != getattr(self, "_inflight_depth", depth):
             while self._inflight:                        # the depth was changed between calls: start from an empty pipeline
                 self._collect_oldest()
         self._inflight_depth = depth
         max_sparse_frames = getattr(self, "device_sparsify_max_frames", 0)
         try:
-            for launch in plan_launches(chunks, launch_target(self)):
+            for launch in launches:
                 rows = None
                 frames = [(wp // 2) // 2 for wp in launch.w_pads]
                 # an engine may bound the frames per line its GPU sparsification takes (`device_sparsify_max_frames`; the HIP engine: no bound
