@@ -34,9 +34,12 @@ from .line_ocr_engine import (BaseEngineLineOCR, SPARSE_PROB_THRESHOLD, ceil32, 
 from .pytorch_ocr_engine import _device_index
 from .softmax import softmax
 
+S2S_DEPTH = 3                    # launches whose decoding loops run side by side (one worker thread and one engine slot each)
 MIN_INPUT_WIDTH = 1088           # transformer_ocr_engine.py:36-40: narrower batches are centred in 1088 columns
-LAUNCH_MAX_LINES = 256           # device lines decoded side by side in one launch: a decoding step is latency-bound,
-LAUNCH_MAX_COLUMNS = 256 * 1088  # so wide launches amortise it (measured 2.3k / 2.7k / 2.9k lines/s for 64 / 128 / 256)
+# device lines decoded side by side in one launch: a decoding step is latency-bound, so wide launches amortise it (round 1: 2.3k / 2.7k /
+# 2.9k lines/s for 64 / 128 / 256; round 4, one decoding loop at a time: 6.9k / 7.5k / 7.6k / 7.7k for 256 / 384 / 512 / 1024)
+LAUNCH_MAX_LINES = int(os.environ.get("POCR_S2S_MAX_LINES", 512))
+LAUNCH_MAX_COLUMNS = LAUNCH_MAX_LINES * 1088
 
 
 class _Batch:
@@ -282,21 +285,41 @@ class TransformerEngineLineOCR(BaseEngineLineOCR):
                         merged = sparse.csc_matrix(np.where(softmax(merged, axis=1) < SPARSE_PROB_THRESHOLD, np.float32(0), merged))
                     logits_out[i] = merged
 
-        # one-deep pipeline over launches: the encoder of launch k+1 is enqueued on the other slot before the
-        # (blocking) decoding loop of launch k runs
-        pending = None
+        # Launches side by side: the encoder of a launch is enqueued by this thread, its decoding loop (blocking, latency-bound:
+        # ~31 kernels of 13-40 us per step that leave most of the GPU idle) runs on a worker thread of its slot - the native calls
+        # release the GIL - so up to `depth` decoding loops and the next launch's encoder share the GPU (rounds 1-3: one decoding
+        # loop at a time next to the next encoder; 2048 lines of 512 px: 7.6 k -> see profiles/r04_s2s_concurrent_decode.txt).
+        # Every launch owns its slot's buffers and streams; results land at the positions of their own lines.
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
         serial = os.environ.get("POCR_S2S_SERIAL") == "1"        # measurement switch: no overlap between launches
+        depth = 1 if serial else max(1, min(int(os.environ.get("POCR_S2S_DEPTH", S2S_DEPTH)), int(getattr(self.net, "num_slots", 2))))
+        launches = plan_launches(batches)
+        if depth == 1 or len(launches) == 1:
+            try:
+                for group in launches:
+                    finish(0, group, submit(0, group))
+            except BaseException:
+                self.net.reset()
+                raise
+            return
+        pending = deque()
+        pool = ThreadPoolExecutor(max_workers=depth, thread_name_prefix="pocr-s2s")
         try:
-            for k, group in enumerate(plan_launches(batches)):
-                first = submit(k % 2, group)
-                if serial:
-                    finish(k % 2, group, first)
-                    continue
-                if pending is not None:
-                    finish(*pending)
-                pending = (k % 2, group, first)
-            if pending is not None:
-                finish(*pending)
+            for k, group in enumerate(launches):
+                while len(pending) >= depth:                     # slot k % depth is free once launch k - depth has finished
+                    pending.popleft().result()
+                first = submit(k % depth, group)
+                pending.append(pool.submit(finish, k % depth, group, first))
+            while pending:
+                pending.popleft().result()
         except BaseException:
-            self.net.reset()          # a launch may still be in flight on either slot: leave the engine usable
+            for f in pending:                                    # let the running decoding loops end before the engine is reset
+                try:
+                    f.result()
+                except BaseException:
+                    pass
+            self.net.reset()          # leave the engine usable
             raise
+        finally:
+            pool.shutdown(wait=True)
