@@ -22,7 +22,8 @@ timeout 600 python tools/s2s_bench.py 2048 512 4 3 20 > $O/s2s_bench.json 2> $O/
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_c2 -o c2 -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_c2_under_rocprof.json 2> $O/prof_c2.err
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_c4 -o c4 -- python $R/bench.py --workload c4 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_c4_under_rocprof.json 2> $O/prof_c4.err
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_s2s -o s2s -- python $R/tools/s2s_bench.py 2048 512 4 3 20 > $O/s2s_under_rocprof.json 2> $O/prof_s2s.err
+# (kernel trace with ONE decoding loop at a time: side by side the loops share the HBM and a kernel's duration is no longer its own)
+POCR_S2S_DEPTH=1 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_s2s -o s2s -- python $R/tools/s2s_bench.py 2048 512 4 3 20 > $O/s2s_under_rocprof.json 2> $O/prof_s2s.err
 for grp in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
   name=$(echo $grp | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $grp --kernel-trace -d $O/pmc -o pmc_$name -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_$name.out 2> $O/pmc_$name.err
@@ -30,7 +31,7 @@ done
 cd $R
 for w in c2 c4 s2s; do f=$(find $O/prof_$w -name "*.db" | head -1); [ -n "$f" ] && python tools/rocprof_summary.py $f > $O/${w}_kernel_stats.txt 2>&1; done
 python tools/pmc_summary.py $(find $O/pmc -name "*.db") > $O/pmc_summary.json 2> $O/pmc_summary.err
-python tools/s2s_roofline.py $O/s2s_kernel_stats.txt $O/s2s_bench.json > $O/s2s_roofline.json 2> $O/s2s_roofline.err
+python tools/s2s_roofline.py $O/s2s_kernel_stats.txt $O/s2s_bench.json 512 > $O/s2s_roofline.json 2> $O/s2s_roofline.err
 find $O -name "*.db" -delete
 tail -2 $O/pytest_gpu.txt
 for f in bench_c2 bench_c2_bf16x3 bench_c2_fp32mfma bench_c3 bench_c3_rccl_world1 bench_c4 bench_c5 bench_c5_host_crops; do echo $f; cut -c1-200 $O/$f.json; echo; done

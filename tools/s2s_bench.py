@@ -36,7 +36,7 @@ def main():
         eng = TransformerEngineLineOCR(path, torch.device("cuda:0"), batch_size=batch_size)
     widths = synth.make_widths(602, n, 128, 2000) if width == 0 else [width] * n      # width 0: ragged 128..2000 px
     crops = synth.make_crops(602, widths, 40)
-    eng.process_lines(crops[:64], no_logits=True)            # warm-up
+    eng.process_lines(crops, no_logits=True)                 # warm-up: the same call (every slot's buffers reach their size; a cold slot costs a timed pass seconds)
     out = {}
     for mode, kw in (("no_logits", dict(no_logits=True)), ("dense", dict(sparse_logits=False)), ("sparse", {})):
         t0 = time.perf_counter()
@@ -44,6 +44,12 @@ def main():
         dt = time.perf_counter() - t0
         out[mode] = round(n / dt, 1)
     lens = np.array([len(t) for t in texts])
+    # (line, step) pairs the memory attention really evaluates: a line is skipped once its REFERENCE BATCH (batch_size consecutive lines
+    # of the width-sorted order; equal widths: input order) has ended, and a batch runs max(len) + 1 steps (the boundary symbol's step)
+    if width:
+        groups = [lens[i:i + batch_size] for i in range(0, n, batch_size)]
+        out["attention_line_steps_per_pass"] = int(sum(len(g) * (int(g.max()) + 1) for g in groups))
+        out["passes"] = 4                                    # warm-up + the three timed modes: what a kernel trace of this command contains
     out.update(lines=n, width=width, batch_size=batch_size, dec_layers=dec_layers,
                mean_len=float(lens.mean()), share_at_limit=float((lens >= 272).mean()))
     print(json.dumps(out))
