@@ -1351,7 +1351,7 @@ int collect_outputs(pocr_engine *e, Slot &s, float *logits_ntc, int32_t *frame_a
     if (labels_nt) memcpy(labels_nt, pin, nt_bytes);
     if (frame_argmax_nt) memcpy(frame_argmax_nt, pin + nt_bytes, (size_t)rows * sizeof(int32_t));
     if (label_len_n) memcpy(label_len_n, pin + 2 * nt_bytes, (size_t)n * sizeof(int32_t));
-    if (logits_ntc) memcpy(logits_ntc, pin + 2 * nt_bytes + (size_t)round_up(n, 4) * sizeof(int32_t), (size_t)rows * C * sizeof(float));
+    if (logits_ntc) parallel_memcpy(logits_ntc, pin + 2 * nt_bytes + (size_t)round_up(n, 4) * sizeof(int32_t), (size_t)rows * C * sizeof(float));
     if (e->profiling) {
         for (int i = 0; i < POCR_NUM_STAGES; ++i) s.stage_ms[i] = 0.f;
         const int order[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, POCR_STAGE_AGG, POCR_STAGE_LSTM, POCR_STAGE_HEAD, POCR_STAGE_CTC, POCR_NUM_STAGES};
@@ -2235,8 +2235,8 @@ int pocr_slot_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t 
     if (total > 0) {
         const size_t trip_base = (off_bytes + ip_bytes + (size_t)n * sizeof(float) + 15) / 16 * 16, have = std::min<size_t>(s.sp_spec, (size_t)total);
         const char *pin = static_cast<const char *>(s.sp_pinned) + trip_base;
-        memcpy(data, pin, have * sizeof(float));
-        memcpy(indices, pin + s.sp_spec * sizeof(float), have * sizeof(int32_t));
+        parallel_memcpy(data, pin, have * sizeof(float));                  // (flat posteriors: 30 MB each per 256 lines, into fresh pages of the caller's arrays)
+        parallel_memcpy(indices, pin + s.sp_spec * sizeof(float), have * sizeof(int32_t));
         if ((size_t)total > have) {      // the speculative copy was too short: fetch the tail now
             HIP_TRY(hipMemcpyAsync(data + have, s.sp_data.as<float>() + have, ((size_t)total - have) * sizeof(float), hipMemcpyDeviceToHost, s.seq_stream));
             HIP_TRY(hipMemcpyAsync(indices + have, s.sp_indices.as<int32_t>() + have, ((size_t)total - have) * sizeof(int32_t), hipMemcpyDeviceToHost, s.seq_stream));
@@ -2647,7 +2647,7 @@ int pocr_s2s_collect(pocr_engine *e, int32_t slot, int32_t *tokens, float *logit
     if (tokens)
         for (int i = 0; i < n; ++i)
             memcpy(tokens + (size_t)i * smax, pin + (size_t)i * S_cap * sizeof(int32_t), (size_t)smax * sizeof(int32_t));
-    if (logits) memcpy(logits, pin + (size_t)n * S_cap * sizeof(int32_t), (size_t)n * smax * C * sizeof(float));
+    if (logits) parallel_memcpy(logits, pin + (size_t)n * S_cap * sizeof(int32_t), (size_t)n * smax * C * sizeof(float));
     return 0;
 }
 

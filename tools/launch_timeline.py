@@ -13,7 +13,8 @@ bs = int(sys.argv[3]) if len(sys.argv) > 3 else 274
 kw = dict(no_logits=True) if os.environ.get("NO_LOGITS") else {}
 meta, spec, weights = bench.fixture_model("c2")
 weights = dict(weights)
-weights["head.weight"] = weights["head.weight"] * np.float32(8); weights["head.bias"] = weights["head.bias"] * np.float32(8)
+temp = np.float32(os.environ.get("POCR_HEAD_TEMP", "8"))          # 8: peaked posteriors (4 entries per frame kept); 1: the seeded flat head (208 of 232)
+weights["head.weight"] = weights["head.weight"] * temp; weights["head.bias"] = weights["head.bias"] * temp
 tmp = tempfile.mkdtemp()
 netspec.save_blob(os.path.join(tmp, "w.pocrw"), spec, weights)
 json.dump({"line_px_height": spec.height, "line_vertical_scale": 1.0, "checkpoint": "w.pocrw", "characters": meta["characters"][:-1], "net_name": "b"},
