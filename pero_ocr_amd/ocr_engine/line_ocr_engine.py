@@ -81,7 +81,6 @@ class Launch:
         return sum(len(c.line_ids) * c.w_pad for c in self.chunks)
 
 
-HEAVY_RESULT_ENTRIES_PER_FRAME = 32   # sparse logits denser than this per frame count as a large result (three launches in flight, see _begin_chunks)
 CHAIN_BOUND_FRAMES = 512              # a call whose longest line has at least this many frames (2048 px) ...
 CHAIN_BOUND_MIN_WORK = 24 * 1024      # ... and at least three times this many padded columns is cut into three launches (see _begin_chunks)
 LAUNCH_WORK_TARGET = 256 * 384          # padded pixel columns per launch (measured on the c3 stream: 82-98 k is 2-3 % better than 147 k; c5 neutral)
@@ -306,14 +305,15 @@ class BaseEngineLineOCR:
         # its convolutions: three launches in flight start the longest chain after a third of the convolutions instead of half
         # (one 4k x 3k page of 47 lines: 14.8-15.6 -> 13.9-14.6 ms, profiles/r04_sparse_blocks.txt).  Streams of calls and calls of
         # short lines keep the plan above (smaller launches cost them conv efficiency: c5 stream 64 -> 55 pages/s at half the target).
-        # Calls whose results are LARGE - dense logits, or "sparse" logits of a flat head (hundreds of entries per frame: the previous
-        # launches' density) - put 30-60 MB per launch on the read-back path; with two launches in flight the pair then completes
-        # together and the GPU waits for the host in between, a third launch in flight fills the gap (2048 lines @512 px, flat head:
-        # 91.5 -> 81.5 ms; peaked head and no logits: unchanged or 2 % worse, so they stay at two; profiles/r04_launch_timeline.txt)
+        # Calls that RETURN LOGITS keep three launches in flight: a launch's results (CSC triplets or dense logits, up to 30-60 MB with a
+        # flat head) are read back and assembled by this thread, and with two in flight the pair completes together and the GPU waits
+        # for the host in between (collects of 14 / 2 / 14 / 2 ms).  2048 lines, 1x MI355X (profiles/r04_launch_timeline.txt): c3 width
+        # mix, sparse 98.7 -> 94.0 ms; 512-px lines with a flat head 91.5 -> 81.5 ms, with a peaked head 76.8 -> 77.0.  Without logits
+        # two stay the default (mix 95.5-97.0 -> 93.7-94.4, uniform 512-px lines 75.2 -> 76.7: a third resident recurrence costs the
+        # convolutions what the shorter gaps give).
         depth_is_default = getattr(self, "pipeline_depth", None) is None and "POCR_PIPELINE_DEPTH" not in os.environ
         slots = getattr(getattr(self, "model", None), "num_slots", 2)
-        if depth_is_default and slots >= 3 and not no_logits and (
-                not device_sparse or getattr(self, "sparse_entries_per_frame", 0.0) > HEAVY_RESULT_ENTRIES_PER_FRAME):
+        if depth_is_default and slots >= 3 and not no_logits:
             depth = max(depth, 3)
         if (not self._inflight and len(launches) <= 2 and getattr(self, "pipeline_depth", None) is None and
                 "POCR_PIPELINE_DEPTH" not in os.environ and getattr(getattr(self, "model", None), "num_slots", 2) >= 3):

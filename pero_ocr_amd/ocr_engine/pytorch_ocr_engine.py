@@ -295,7 +295,6 @@ class PytorchEngineLineOCR(BaseEngineLineOCR):
             return labels_to_strings(labels, lens, self.characters), per_line
         data, indices, indptr, line_off, _amax, labels, lens = self.model.slot_collect_sparse(slot)
         conf = self.model.slot_confidence(slot)          # page_parser.py:485-496 on the same kept set, computed on the GPU
-        self.sparse_entries_per_frame = float(data.size) / max(1.0, float(np.sum(frames)))      # sizes the pipeline of the next calls (_begin_chunks)
         n, C = indptr.shape[0], indptr.shape[1] - 1
         mats = []
         for i in range(n):

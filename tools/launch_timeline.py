@@ -21,6 +21,8 @@ json.dump({"line_px_height": spec.height, "line_vertical_scale": 1.0, "checkpoin
           open(os.path.join(tmp, "ocr.json"), "w"))
 crops = synth.make_crops(305, [512] * 256, spec.height)
 big = [crops[i % 256] for i in range(n_lines)]
+if os.environ.get("MIX"):                                          # the c3 width mix (128..1024 px) instead of uniform 512-px lines
+    big = synth.make_crops(77, synth.make_widths(33, n_lines), spec.height)
 eng = PytorchEngineLineOCR(os.path.join(tmp, "ocr.json"), bench.Dev(0), batch_size=bs)
 ev = []
 sub, col = eng._submit_launch, eng._collect_launch
