@@ -94,12 +94,18 @@ def launch_target(engine=None) -> int:
     return max(1, int(t))
 
 
+PIPELINE_DEPTH = 3          # launches in flight (see pipeline_depth)
+
+
 def pipeline_depth(engine=None) -> int:
-    """Launches in flight: the engine's `pipeline_depth` attribute, else POCR_PIPELINE_DEPTH, else 2; at most the slots the
-    native engine has."""
+    """Launches in flight: the engine's `pipeline_depth` attribute, else POCR_PIPELINE_DEPTH, else 3; at most the slots the
+    native engine has.  Three since the end of round 4 (profiles/r04_launch_timeline.txt): with two in flight the launches of a
+    ragged stream complete in pairs and the GPU runs out of queued work in between - 2048 lines of 128..1024 px without logits
+    95.2-96.3 -> 90.7-90.9 ms, with sparse logits 98.7 -> 94.0, a flat head's 61 MB of triplets per launch 91.5 -> 81.5; uniform
+    512-px lines are unchanged within the run-to-run spread (78.7-84.1 against 80.8-81.3 ms)."""
     d = getattr(engine, "pipeline_depth", None)
     if d is None:
-        d = int(os.environ.get("POCR_PIPELINE_DEPTH", 2))
+        d = int(os.environ.get("POCR_PIPELINE_DEPTH", PIPELINE_DEPTH))
     slots = getattr(getattr(engine, "model", None), "num_slots", 2)
     return max(1, min(int(d), int(slots)))
 
@@ -288,9 +294,10 @@ class BaseEngineLineOCR:
         # Software pipeline over LAUNCHES (merged chunks): launch k+1 is enqueued on another engine slot before launch k is
         # collected, so its GPU work overlaps launch k's read-back and the host-side assembly.  (The reference runs chunk
         # after chunk, line_ocr_engine.py:80-129; lines are independent given their padded width, so the results are the same.)
-        # `depth` launches in flight (one engine slot each): with long lines the recurrent layers of a launch are a chain of
-        # ~2 T dependent steps that leaves the GPU mostly idle - several chains side by side fill it (pages of 3-4 k px
-        # lines: 2 -> 4 launches in flight is +30 %); with short lines one chain already hides behind the next launch's convs.
+        # `depth` launches in flight (one engine slot each, pipeline_depth): with long lines the recurrent layers of a launch are a
+        # chain of ~2 T dependent steps that leaves the GPU mostly idle - several chains side by side fill it; with short lines one
+        # chain already hides behind the next launch's convolutions, and the third launch keeps work queued while this thread assembles
+        # results.
         # The queue of launches in flight belongs to the ENGINE: launch number s runs on slot s % depth, which is free once
         # launch s - depth has been collected - whichever call (ticket) that one belongs to.
         from collections import deque
@@ -305,16 +312,6 @@ class BaseEngineLineOCR:
         # its convolutions: three launches in flight start the longest chain after a third of the convolutions instead of half
         # (one 4k x 3k page of 47 lines: 14.8-15.6 -> 13.9-14.6 ms, profiles/r04_sparse_blocks.txt).  Streams of calls and calls of
         # short lines keep the plan above (smaller launches cost them conv efficiency: c5 stream 64 -> 55 pages/s at half the target).
-        # Calls that RETURN LOGITS keep three launches in flight: a launch's results (CSC triplets or dense logits, up to 30-60 MB with a
-        # flat head) are read back and assembled by this thread, and with two in flight the pair completes together and the GPU waits
-        # for the host in between (collects of 14 / 2 / 14 / 2 ms).  2048 lines, 1x MI355X (profiles/r04_launch_timeline.txt): c3 width
-        # mix, sparse 98.7 -> 94.0 ms; 512-px lines with a flat head 91.5 -> 81.5 ms, with a peaked head 76.8 -> 77.0.  Without logits
-        # two stay the default (mix 95.5-97.0 -> 93.7-94.4, uniform 512-px lines 75.2 -> 76.7: a third resident recurrence costs the
-        # convolutions what the shorter gaps give).
-        depth_is_default = getattr(self, "pipeline_depth", None) is None and "POCR_PIPELINE_DEPTH" not in os.environ
-        slots = getattr(getattr(self, "model", None), "num_slots", 2)
-        if depth_is_default and slots >= 3 and not no_logits:
-            depth = max(depth, 3)
         if (not self._inflight and len(launches) <= 2 and getattr(self, "pipeline_depth", None) is None and
                 "POCR_PIPELINE_DEPTH" not in os.environ and getattr(getattr(self, "model", None), "num_slots", 2) >= 3):
             total = sum(l.work for l in launches)

@@ -303,17 +303,17 @@ def engine_recogniser(engine) -> Callable:
                 out[id(ch)] = (labels[k:k + m, :ch.frames], lens[k:k + m])
                 k += m
 
-        pending = None
+        from collections import deque
+        pending = deque()
         try:
             from .ocr_engine.line_ocr_engine import pipeline_depth
-            depth = pipeline_depth(engine)
+            depth = pipeline_depth(engine)                # launches in flight, one engine slot each (as process_lines)
             for j, launch in enumerate(plan_launches(chunks, launch_target(engine))):
-                handle = engine._submit_launch(lines, launch, False, j % min(2, depth))
-                if pending is not None:
-                    finish(*pending)
-                pending = (launch, handle)
-            if pending is not None:
-                finish(*pending)
+                while len(pending) >= depth:              # slot j % depth is free once launch j - depth has been collected
+                    finish(*pending.popleft())
+                pending.append((launch, engine._submit_launch(lines, launch, False, j % depth)))
+            while pending:
+                finish(*pending.popleft())
         except BaseException:
             engine.model.reset()      # a launch may still be in flight on either slot: leave the engine usable
             raise
