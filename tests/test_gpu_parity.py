@@ -650,6 +650,36 @@ def test_device_sparsify_equals_host_sparsify(golden, tmp_path):
                 assert abs(int(sp[i].nnz) - g.nnz_sparse[i]) <= max(2, g.nnz_sparse[i] // 200)
 
 
+def test_device_sparsify_has_no_frame_limit(golden, tmp_path):
+    """Round 4: the sparsification kernels work on blocks of 64 frames, so a line may be longer than the 1024 frames the per-line
+    kernels of rounds 1-3 could hold (they fell back to the dense read-back + host softmax above that).  Lines of 4500 / 5200 px at
+    batch_size 16 (1141 / 1316 frames, blocks that end inside a block, an empty tail block for the short line of the chunk): the
+    GPU-built matrices and confidences against the rule of line_ocr_engine.py:168-171 applied on the host to the engine's own dense
+    logits, with and without tight row ranges."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import PytorchEngineLineOCR
+    from pero_ocr_amd.ocr_engine.softmax import softmax
+    g = golden("ragged")
+    eng = PytorchEngineLineOCR(g.write_engine_json(tmp_path), Dev(), batch_size=16)
+    assert eng.device_sparsify_max_frames > 2000
+    crops = synth.make_crops(4242, [5200, 4500, 700, 64, 4500], 40)
+    for tight in (False, True):
+        _t, dense, _c = eng.process_lines(crops, sparse_logits=False, tight_crop_logits=tight)
+        texts, sp, _coords = eng.process_lines(crops, tight_crop_logits=tight)
+        assert texts == _t and max(m.shape[0] for m in sp) > 1024
+        for i in range(len(crops)):
+            d, m = np.asarray(dense[i]), sp[i]
+            assert m.format == "csc" and m.shape == d.shape and m.has_sorted_indices and m.indptr[-1] == m.nnz
+            p = softmax(d, axis=1)
+            ref = np.where(p < 1e-4, np.float32(0), d)
+            borderline = np.abs(p - 1e-4) < 1e-7
+            assert np.array_equal(m.toarray()[~borderline], ref[~borderline]), f"line {i} tight={tight}"
+        if not tight:
+            conf = list(eng.line_confidences)
+            assert all(c is not None and 0.0 < c <= 1.0 for c in conf)
+            again = eng.process_lines(crops)
+            assert list(eng.line_confidences) == conf and all((a != b).nnz == 0 for a, b in zip(again[1], sp))
+
+
 def test_gpu_ctc_kernels_known_answers_ties_nan_inf():
     """The GPU arg-max / collapse kernels alone (pocr_ctc_greedy) on adversarial scores: the CTC
     known-answer cases of the reference's tests (test/test_decoding/test_decoders.py:24-96), exact
