@@ -375,7 +375,7 @@ const int kConvTW[10] = {32, 64, 32, 32, 16, 16, 16, 16, 16, 48};
 const int kConvTW3[10] = {32, 32, 16, 16, 16, 16, 32, 16, 16, 48};
 const int kConvTHP[10] = {4, 10, 10, 10, 10, 10, 10, 5, 5, 1};       // the P2 configurations (POCR_CONVP)
 const int kConvTWP[10] = {32, 16, 16, 16, 16, 16, 16, 16, 16, 48};
-inline int conv_tile_h(bool p2, bool b3, int k) { return p2 ? (k == 1 && ((p2_alt_tiles() >> 7) & 1) ? 8 : (p2_alt_tiles() >> k) & 1 ? kConvTH3[k] : kConvTHP[k]) : b3 ? kConvTH3[k] : kConvTH[k]; }
+inline int conv_tile_h(bool p2, bool b3, int k, bool conv2_tile8 = false) { return p2 ? (k == 1 && conv2_tile8 ? 8 : (p2_alt_tiles() >> k) & 1 ? kConvTH3[k] : kConvTHP[k]) : b3 ? kConvTH3[k] : kConvTH[k]; }
 inline int conv_tile_w(bool p2, bool b3, int k) { return p2 ? ((p2_alt_tiles() >> k) & 1 ? kConvTW3[k] : kConvTWP[k]) : b3 ? kConvTW3[k] : kConvTW[k]; }
 // input width level of each conv (0: W_pad, 1: W_pad/2, 2: (W_pad/2)/2) and of its output
 const int kConvLvlIn[10] = {0, 0, 1, 1, 2, 2, 2, 2, 2, 2};
@@ -561,6 +561,7 @@ struct pocr_engine {
     bool lstm_resident = true;       // one launch per BiLSTM layer with the hidden state handed over inside an XCD (lstm_resident.hpp); POCR_LSTM_RESIDENT=0: one launch per step
     bool warned_nonfinite = false, warned_placement = false;
     bool fuse12 = false;             // conv1 inside conv2's prologue (P2 only; POCR_NO_FUSE12=1: conv1 as its own launch, its activation in HBM)
+    bool conv2_tile8 = false;        // the fused conv1+2 kernel as 8 x 16 tiles, three workgroups per CU (networks without a recurrence)
     DevBuf conv1_w2;                 // conv1's weights as f16x2 fragments (Conv1Args::w1x2)
     pocr_engine *shadow = nullptr;   // f16x2 range guard: the same network on bf16x3 (fp32's range), created when a launch first leaves f16's range
     std::vector<float> weights_host; // the weight blob (kept for the fall-back engine; f16x2 engines only)
@@ -778,7 +779,7 @@ int run_network(pocr_engine *e, Slot &s) {
                         if (e->fuse12) {
                             a.f1_crops = s.crops_ext ? s.crops_ext : s.crops.as<uint8_t>(); a.f1_lines = s.lines.as<LineDesc>();
                             a.f1_lut = e->lut.as<float>(); a.f1_w = e->conv1_w2.p; a.f1_bias = e->conv_b[0].as<float>(); a.f1_src_h = 0;
-                            rc = (p2_alt_tiles() >> 7) & 1 ? conv2_p2_fused8(a, st) : conv2_p2_fused(a, st);
+                            rc = e->conv2_tile8 ? conv2_p2_fused8(a, st) : conv2_p2_fused(a, st);
                         } else {
                             rc = (p2_alt_tiles() >> 1) & 1 ? conv2_p2_alt(a, st) : conv2_p2(a, st);
                         }
@@ -1524,6 +1525,11 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     if (const char *env = getenv("POCR_LSTM_RESIDENT")) e->lstm_resident = atoi(env) != 0;
     e->p2 = conv_split() == 2 && !(getenv("POCR_NO_P2") && atoi(getenv("POCR_NO_P2")) != 0);
     e->fuse12 = e->p2 && !(getenv("POCR_NO_FUSE12") && atoi(getenv("POCR_NO_FUSE12")) != 0) && !((p2_alt_tiles() >> 1) & 1);
+    // The fused conv1+2 kernel as 8 x 16 pixel tiles with THREE workgroups per CU (52 KB of LDS each) is 14 % faster alone than the 10 x 16 /
+    // two-per-CU tiles, but it leaves no LDS for a resident recurrence of the launch ahead on the same CU: networks WITHOUT a recurrence (the
+    // self-attention encoder) take it (c4 18.15 -> 18.49 k lines/s, three alternating pairs), the BiLSTM network keeps the larger tile (c3 -2.2 %
+    // with the small one; profiles/r04_backbone_overlap.txt).  POCR_P2_ALT_TILES (bit 7) overrides either way.
+    e->conv2_tile8 = e->fuse12 && (getenv("POCR_P2_ALT_TILES") ? ((p2_alt_tiles() >> 7) & 1) != 0 : cfg->arch == POCR_ARCH_SA);
     e->gemm2 = e->p2 && !(getenv("POCR_NO_GEMM2") && atoi(getenv("POCR_NO_GEMM2")) != 0);
     e->head_fp32 = getenv("POCR_HEAD_FP32") && atoi(getenv("POCR_HEAD_FP32")) != 0;
     e->att_fp32 = getenv("POCR_ATT_FP32") && atoi(getenv("POCR_ATT_FP32")) != 0;
@@ -1884,7 +1890,7 @@ static int build_geometry(pocr_engine *e, Slot &s, const int32_t *w_pads, int n,
             zlo[1][i] = std::max(c_hi, c_lo); zhi[1][i] = w_pads[i];
         }
     for (int k = 0; k < 10; ++k) {
-        const int th = conv_tile_h(e->p2, e->bf16x3, k), tw = conv_tile_w(e->p2, e->bf16x3, k);
+        const int th = conv_tile_h(e->p2, e->bf16x3, k, e->conv2_tile8), tw = conv_tile_w(e->p2, e->bf16x3, k);
         const int h_in = k < 9 ? hh : hh;                       // aggregation conv: one output row
         const int rows_out = k < 9 ? h_in : 1;
         const int pw = k < 9 ? kConvPlan[k].pw : 1;
