@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define POCR_ABI_VERSION 11
+#define POCR_ABI_VERSION 12
 #define POCR_NUM_SLOTS 4
 
 typedef struct pocr_engine pocr_engine;
@@ -87,6 +87,14 @@ int pocr_conv_split(void);
  * plain fp32 of pero_ocr/ocr_engine/pytorch_ocr_engine.py:61-69.  Returns the number of launches re-run so far.
  * (The sequence-to-sequence engine returns an error instead; POCR_CONV_SPLIT=3 selects bf16x3 for everything.) */
 int64_t pocr_range_fallbacks(pocr_engine *e);
+/* Resident BiLSTM recurrence (ABI 12).  One launch per layer hands the hidden state from step to step between co-resident
+ * workgroups (torch.nn.LSTM of the reference's model, pero_ocr/ocr_engine/pytorch_ocr_engine.py:66-69); every wait is bounded.  A launch
+ * in which a hand-off timed out (not all of a cluster's workgroups became resident: other tenants on the chip) is repeated - same
+ * lines, same requests, at collect time - with one launch per step; the next 4 (8, 16 ... 256 after further timeouts) launches
+ * then use the step kernels before the resident path is tried again.  Returns the number of launches repeated so far (this engine
+ * and its range-guard fall-back engine).  POCR_LSTM_RESIDENT=0: step kernels only; POCR_LSTM_SPIN_LIMIT=<polls> at creation: the
+ * bound of a wait (tests force the timeout path with 1). */
+int64_t pocr_lstm_timeouts(pocr_engine *e);
 /* Number of visible HIP devices (0 when none / no driver). */
 int pocr_device_count(void);
 

@@ -500,6 +500,9 @@ struct Slot {
     DevBuf lstm_sync;                    // resident recurrence (lstm_resident.hpp): [clusters][32] sync words, then 4 error / diagnostic words
     size_t lstm_err_off = 0;             // index (uint32) of the error words inside lstm_sync
     bool lstm_resident_used = false;     // this launch ran the resident kernel: collect checks the error word
+    bool lstm_force_step = false;        // the repeat of a launch whose resident recurrence timed out: step kernels
+    hipEvent_t lstm_done = nullptr;      // recorded behind this slot's last resident launch: while it is pending, its workgroups count against the chip's capacity
+    int lstm_grid_pending = 0;           // workgroups of that launch
     uint32_t *lstm_err_host = nullptr;   // pinned copy of the error words
     DevBuf nf_flag;                      // set by frame_argmax_kernel when a winning logit is NaN / inf
     int32_t *nf_host = nullptr;          // pinned copy, read at collect time
@@ -557,8 +560,13 @@ struct pocr_engine {
     std::vector<DecLayer> dec;
     DevBuf dec_embed, dec_out_w, dec_out_b;
     int dec_out_cout16 = 0;
-    int lstm_capacity = -1;          // workgroups of the resident recurrence the chip holds at once (occupancy query, first launch)
+    int lstm_capacity[3][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};   // [KPW 1/2/4][SL 1/2/4]: workgroups of that instantiation of the resident recurrence the chip holds at once (occupancy query, first use)
     bool lstm_resident = true;       // one launch per BiLSTM layer with the hidden state handed over inside an XCD (lstm_resident.hpp); POCR_LSTM_RESIDENT=0: one launch per step
+    // A hand-off timeout (a cluster that was not fully resident: other tenants on the chip) sends the NEXT lstm_skip launches to the
+    // step kernels, then the resident path is tried again; every further timeout doubles the pause (4 .. 256 launches).
+    int lstm_skip = 0, lstm_skip_len = 0;
+    int64_t lstm_timeouts = 0;       // launches repeated on the step kernels after a timeout (pocr_lstm_timeouts)
+    int lstm_spin_limit = 1 << 22;   // POCR_LSTM_SPIN_LIMIT at creation (tests force the timeout path with a tiny limit)
     bool warned_nonfinite = false, warned_placement = false;
     bool fuse12 = false;             // conv1 inside conv2's prologue (P2 only; POCR_NO_FUSE12=1: conv1 as its own launch, its activation in HBM)
     bool conv2_tile8 = false;        // the fused conv1+2 kernel as 8 x 16 tiles, three workgroups per CU (networks without a recurrence)
@@ -1065,15 +1073,40 @@ int run_network(pocr_engine *e, Slot &s) {
     // for where the query is known to be optimistic); a launch that does not fit takes more slices per workgroup, then the
     // step kernels.
     auto resident_grid = [&](int sl) { return ((2 * ((n_sl + sl - 1) / sl) + 7) / 8) * ug_n * 8; };
-    if (e->lstm_capacity < 0) {
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_resident_kernel<4, 4>, 256, 0) != hipSuccess) per_cu = 1;
-        e->lstm_capacity = std::max(1, std::min(per_cu, 4)) * e->n_cus;
-        if (per_cu > 1) e->lstm_capacity -= e->n_cus;
-    }
-    while (SLn < 4 && resident_grid(SLn) > e->lstm_capacity) SLn *= 2;
-    const bool resident = e->lstm_resident && (Hh == 64 || Hh == 128 || Hh == 256) && c.lstm_layers <= 8 &&
-                          resident_grid(SLn) <= e->lstm_capacity;
+    // capacity of the instantiation that would be launched (they differ in registers and LDS), minus the workgroups of resident
+    // launches of OTHER slots that have not finished yet (three launches are in flight by default: their recurrences overlap)
+    auto capacity = [&](int sl) {
+        const int ki = Hh == 64 ? 0 : Hh == 128 ? 1 : 2, si = sl == 1 ? 0 : sl == 2 ? 1 : 2;
+        int &cap = e->lstm_capacity[ki][si];
+        if (cap < 0) {
+            int per_cu = 0;
+            hipError_t qe = hipErrorUnknown;
+#define POCR_OCC(KPW_, SL_) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_resident_kernel<KPW_, SL_>, 256, 0)
+            switch (ki * 3 + si) {
+                case 0: POCR_OCC(1, 1); break; case 1: POCR_OCC(1, 2); break; case 2: POCR_OCC(1, 4); break;
+                case 3: POCR_OCC(2, 1); break; case 4: POCR_OCC(2, 2); break; case 5: POCR_OCC(2, 4); break;
+                case 6: POCR_OCC(4, 1); break; case 7: POCR_OCC(4, 2); break; default: POCR_OCC(4, 4); break;
+            }
+#undef POCR_OCC
+            if (qe != hipSuccess || per_cu < 1) per_cu = 1;
+            cap = std::min(per_cu, 4) * e->n_cus;
+            if (per_cu > 1) cap -= e->n_cus;
+        }
+        int pending = 0;
+        for (int k = 0; k <= POCR_NUM_SLOTS; ++k) {
+            Slot &o = e->slot[k];
+            if (&o == &s || o.lstm_grid_pending == 0 || !o.lstm_done) continue;
+            if (hipEventQuery(o.lstm_done) == hipSuccess) o.lstm_grid_pending = 0;
+            else pending += o.lstm_grid_pending;
+        }
+        (void)hipGetLastError();                       // (hipErrorNotReady of the query is not an error)
+        return cap - pending;
+    };
+    while (SLn < 4 && resident_grid(SLn) > capacity(SLn)) SLn *= 2;
+    const bool resident_shape = e->lstm_resident && (Hh == 64 || Hh == 128 || Hh == 256) && c.lstm_layers <= 8;
+    const bool paused = resident_shape && !s.lstm_force_step && e->lstm_skip > 0;      // back-off after a timeout (sync_and_guard)
+    if (paused) --e->lstm_skip;
+    const bool resident = resident_shape && !s.lstm_force_step && !paused && resident_grid(SLn) <= capacity(SLn);
     const size_t sync_words = (size_t)n_clusters * 32 + 32;     // + error / diagnostic words
     s.lstm_resident_used = resident;
     if (resident) {
@@ -1120,7 +1153,7 @@ int run_network(pocr_engine *e, Slot &s) {
             ra.xproj = s.xproj.as<float>(); ra.whh_frag = e->whh[l].as<float>(); ra.hbuf = s.hbuf.as<float>(); ra.y = s.lstm_y[l].as<float>();
             ra.sync = s.lstm_sync.as<unsigned>(); ra.err = s.lstm_sync.as<unsigned>() + s.lstm_err_off;
             ra.line_T = s.g_line_T; ra.row_off = s.g_row_off; ra.slice_T = s.g_slice_T;
-            ra.n = n; ra.npad = npad; ra.T = T; ra.spin_limit = 1 << 22;
+            ra.n = n; ra.npad = npad; ra.T = T; ra.spin_limit = e->lstm_spin_limit;
             ra.y_p2 = y_p2;
             static const int force_agent = getenv("POCR_LSTM_FORCE_AGENT") ? atoi(getenv("POCR_LSTM_FORCE_AGENT")) : 0;
             ra.force_agent = force_agent;
@@ -1139,6 +1172,11 @@ int run_network(pocr_engine *e, Slot &s) {
 #undef POCR_RES
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(s.lstm_err_host + 4 * l, s.lstm_sync.as<unsigned>() + s.lstm_err_off, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            if (l == c.lstm_layers - 1) {
+                if (!s.lstm_done) HIP_TRY(hipEventCreateWithFlags(&s.lstm_done, hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(s.lstm_done, st));
+                s.lstm_grid_pending = (int)grid;
+            }
 #if POCR_LSTM_RES_DBG
             {
                 unsigned long long ph[6];
@@ -1523,6 +1561,7 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     if (const char *env = getenv("POCR_NO_GRAPHS")) e->use_graphs = atoi(env) == 0;
     e->bf16x3 = conv_split() != 0;
     if (const char *env = getenv("POCR_LSTM_RESIDENT")) e->lstm_resident = atoi(env) != 0;
+    if (const char *env = getenv("POCR_LSTM_SPIN_LIMIT")) e->lstm_spin_limit = std::max(1, atoi(env));
     e->p2 = conv_split() == 2 && !(getenv("POCR_NO_P2") && atoi(getenv("POCR_NO_P2")) != 0);
     e->fuse12 = e->p2 && !(getenv("POCR_NO_FUSE12") && atoi(getenv("POCR_NO_FUSE12")) != 0) && !((p2_alt_tiles() >> 1) & 1);
     // The fused conv1+2 kernel as 8 x 16 pixel tiles with THREE workgroups per CU (52 KB of LDS each) is 14 % faster alone than the 10 x 16 /
@@ -1829,6 +1868,7 @@ void pocr_destroy(pocr_engine *e) {
         if (s.range_host) (void)locked_host_free(s.range_host);
         s.lstm_sync.release();
         if (s.lstm_err_host) (void)locked_host_free(s.lstm_err_host);
+        if (s.lstm_done) (void)hipEventDestroy(s.lstm_done);
         if (s.host_in) (void)locked_host_free(s.host_in);
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);
@@ -2076,6 +2116,7 @@ int pocr_slot_stage_lines(pocr_engine *e, int32_t slot, const uint8_t *crops, co
 // same requests - on a second engine of this process (created on first use from the retained weight blob), and the slot's
 // results are taken from there.  pero_ocr/ocr_engine/pytorch_ocr_engine.py:61-69 computes in plain fp32: no input may give
 // worse than fp32's range here either.
+static int sync_and_guard(pocr_engine *e, int32_t slot);
 static int run_fallback(pocr_engine *e, int32_t slot, int verdict, int which) {
     Slot &s = e->slot[slot];
     if (e->weights_host.empty()) return fail("internal error: range guard without a retained weight blob");
@@ -2090,6 +2131,8 @@ static int run_fallback(pocr_engine *e, int32_t slot, int verdict, int which) {
         e->shadow = sh;
     }
     pocr_engine *sh = e->shadow;
+    sh->lstm_resident = e->lstm_resident; sh->lstm_spin_limit = e->lstm_spin_limit;
+    sh->lstm_skip = std::max(sh->lstm_skip, e->lstm_skip);
     if (e->cfg.embed_num > 0 && e->embed_id >= 0 && sh->embed_id != e->embed_id && pocr_set_embed_id(sh, e->embed_id)) return 1;
     Slot &t = sh->slot[slot];
     if (t.in_flight && pocr_slot_reset(sh, slot)) return 1;
@@ -2104,7 +2147,7 @@ static int run_fallback(pocr_engine *e, int32_t slot, int verdict, int which) {
     if (run_network(sh, t) || enqueue_outputs(sh, t)) return 1;
     t.in_flight = true;
     sh->last_slot = slot;
-    HIP_TRY(hipStreamSynchronize(t.seq_stream));
+    if (sync_and_guard(sh, slot)) return 1;            // waits; a resident recurrence of the fall-back engine that timed out is repeated here too
     s.redirect = true;
     ++e->range_fallbacks;
     return 0;
@@ -2113,21 +2156,27 @@ static int run_fallback(pocr_engine *e, int32_t slot, int verdict, int which) {
 // every read of a launch's results goes through this: wait for the launch, judge its range words once, fall back if needed
 static int sync_and_guard(pocr_engine *e, int32_t slot) {
     Slot &s = e->slot[slot];
+    // the fall-back engine's kernels and weight layouts are bf16x3 whichever thread reads its results
+    SplitScope scope(e->is_shadow ? 3 : g_split_tls);
     HIP_TRY(hipStreamSynchronize(s.seq_stream));
     if (s.lstm_resident_used && s.lstm_err_host) {
         bool timed_out = false;
         for (int l = 0; l < e->cfg.lstm_layers && l < 8; ++l) timed_out = timed_out || s.lstm_err_host[4 * l] != 0;
         if (timed_out) {
-            // A cluster's workgroups did not all become resident in time (CU masking, a partitioned device, several processes
-            // on the GPU ...): this engine goes back to one launch per step, and THIS launch is run again - same slot, same
-            // requests - before anything of it is read.
-            if (e->lstm_resident)
-                fprintf(stderr, "NOTE: a hand-off of the resident BiLSTM recurrence timed out; this engine now runs one launch per step "
-                                "(POCR_LSTM_RESIDENT=0) and the launch is repeated.\n");
-            e->lstm_resident = false;
+            // A cluster's workgroups did not all become resident in time (other tenants on the chip, CU masking, a partitioned
+            // device ...): THIS launch is run again on the step kernels - same slot, same requests - before anything of it is
+            // read, and the next launches pause the resident path (4, then 8 ... 256 of them) before it is tried again.
+            e->lstm_skip_len = std::min(256, std::max(4, 2 * e->lstm_skip_len));
+            e->lstm_skip = e->lstm_skip_len;
+            if (e->lstm_timeouts++ == 0)
+                fprintf(stderr, "NOTE: a hand-off of the resident BiLSTM recurrence timed out; the launch is repeated with one launch per step and "
+                                "the resident path pauses for the next launches (pocr_lstm_timeouts counts; POCR_LSTM_RESIDENT=0 turns it off).\n");
             memset(s.lstm_err_host, 0, 8 * 4 * sizeof(uint32_t));
             const bool checked = s.guard_checked;
-            if (run_network(e, s) || enqueue_outputs(e, s)) return 1;
+            s.lstm_force_step = true;
+            const int rc = run_network(e, s) || enqueue_outputs(e, s);
+            s.lstm_force_step = false;
+            if (rc) return 1;
             HIP_TRY(hipStreamSynchronize(s.seq_stream));
             s.guard_checked = checked;
         }
@@ -2144,6 +2193,7 @@ static int sync_and_guard(pocr_engine *e, int32_t slot) {
 static inline pocr_engine *result_engine(pocr_engine *e, int32_t slot) { return e->slot[slot].redirect ? e->shadow : e; }
 
 int64_t pocr_range_fallbacks(pocr_engine *e) { return e ? e->range_fallbacks : 0; }
+int64_t pocr_lstm_timeouts(pocr_engine *e) { return e ? e->lstm_timeouts + (e->shadow ? e->shadow->lstm_timeouts : 0) : 0; }
 
 int pocr_slot_launch(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t want_argmax) {
     if (check_slot(e, slot)) return 1;

@@ -1299,6 +1299,44 @@ def test_resident_recurrence_equals_the_step_kernels(monkeypatch):
     # (the env switch is read once per process: this only takes effect in a fresh process, see the subprocess below)
 
 
+def test_resident_recurrence_timeout_backs_off_and_recovers(monkeypatch):
+    """A hand-off timeout of the resident recurrence (forced: POCR_LSTM_SPIN_LIMIT=1 bounds every wait to one poll) must not
+    cost a result nor the resident path for the engine's lifetime: the launch is repeated on the step
+    kernels - bit-identical to an engine that never timed out -, the next launches pause the resident path (4, 8, ...), and it is
+    tried again afterwards (pocr_lstm_timeouts counts the repeats: more than one, fewer than the launches)."""
+    chars = synth.make_charset(30)
+    spec = netspec.NetSpec(num_classes=len(chars) + 1, conv_out=512, lstm_hidden=256, lstm_layers=2)
+    weights = netspec.pack_weights(spec, netspec.generate_weights(spec, 311))
+    widths = [300, 17, 641, 640, 300, 96, 33, 512] * 5
+    crops = synth.make_crops(13, widths)
+    pool = np.concatenate([c.reshape(-1) for c in crops])
+    offs = np.concatenate([[0], np.cumsum([c.size for c in crops])[:-1]]).astype(np.int64)
+    w_pads = [-(-max(w, 1) // 32) * 32 + 64 for w in widths]
+
+    def run(spin, launches):
+        if spin: monkeypatch.setenv("POCR_LSTM_SPIN_LIMIT", str(spin))
+        else: monkeypatch.delenv("POCR_LSTM_SPIN_LIMIT", raising=False)
+        eng = _native.NativeEngine(spec, weights, 0)
+        out = []
+        for rep in range(launches):
+            slot = rep % 2
+            eng.slot_stage_ragged(slot, pool, offs, np.array(widths, np.int32), w_pads, 32)
+            eng.slot_launch(slot, want_logits=True, want_argmax=True)
+            out.append(eng.slot_collect(slot))
+        n_to = eng.lstm_timeouts()
+        eng.close()
+        return out, n_to
+
+    ref, to0 = run(0, 1)
+    assert to0 == 0
+    got, to1 = run(1, 14)
+    # launch 0 times out -> 4 paused -> launch 5 tries again and times out -> 8 paused -> launch 14 would be the next try
+    assert 2 <= to1 < 14, to1
+    for k, res in enumerate(got):
+        for x, y in zip(res, ref[0]):
+            assert x.shape == y.shape and np.array_equal(x, y), f"launch {k} differs after a timeout"
+
+
 def test_resident_recurrence_cross_xcd_protocol(tmp_path):
     """HIP promises no workgroup -> XCD placement: a cluster of the resident recurrence whose members do not share an XCD must
     run the agent-scope hand-off instead of the L2-local one.  POCR_LSTM_FORCE_AGENT=1 forces that protocol for every
