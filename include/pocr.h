@@ -85,7 +85,9 @@ int pocr_conv_split(void);
  * 65504 (or was not finite), or in which a whole activation tensor lay below 2^-13, is re-run - same lines, same requests,
  * transparently, at collect time - on the bf16x3 kernels (fp32's range) of a second engine created on first use.  Replaces
  * plain fp32 of pero_ocr/ocr_engine/pytorch_ocr_engine.py:61-69.  Returns the number of launches re-run so far.
- * (The sequence-to-sequence engine returns an error instead; POCR_CONV_SPLIT=3 selects bf16x3 for everything.) */
+ * The sequence-to-sequence engine does the same at pocr_s2s_decode (encoder and decoding loop again on the second engine, ABI 12);
+ * POCR_CONV_SPLIT=3 selects bf16x3 for everything.  Memory: the second engine holds its own weights (~90 MB) and, for every slot
+ * it has served, activation buffers of that launch's size - only once a launch has left the range. */
 int64_t pocr_range_fallbacks(pocr_engine *e);
 /* Resident BiLSTM recurrence (ABI 12).  One launch per layer hands the hidden state from step to step between co-resident
  * workgroups (torch.nn.LSTM of the reference's model, pero_ocr/ocr_engine/pytorch_ocr_engine.py:66-69); every wait is bounded.  A launch
@@ -355,6 +357,10 @@ int pocr_parsenet_get_maps_area(pocr_parsenet *p, const uint8_t *img_hwc, int32_
                                 float *out_hw5);
 /* GPU time in ms of the last get_maps between the end of the upload and the end of the last kernel (HIP events). */
 int pocr_parsenet_last_ms(pocr_parsenet *p, float *ms);
+/* f16x2 range guard of the layout network (ABI 12): a page on which a conv layer's activation reached 65504 (or was not finite) or
+ * lay below 2^-13 as a whole is run again - transparently, inside the same get_maps call - on the bf16x3 kernels (fp32's range)
+ * of a second network created on first use; torch_parsenet.py:49-53 computes in plain fp32.  Returns the pages re-run so far. */
+int64_t pocr_parsenet_range_fallbacks(pocr_parsenet *p);
 
 /* ---- measurement / test taps (not part of the reference surface) ----
  * Per-stage GPU time of the last pocr_run_* call in milliseconds, measured with HIP

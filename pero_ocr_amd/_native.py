@@ -119,6 +119,7 @@ SYMBOLS = {
     "pocr_parsenet_get_maps_area": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), _i32p,
                                               C.c_int32, C.POINTER(C.c_double), _i32p, C.c_int32, _f32p]),
     "pocr_parsenet_last_ms": (C.c_int, [C.c_void_p, _f32p]),
+    "pocr_parsenet_range_fallbacks": (C.c_int64, [C.c_void_p]),
     "pocr_last_stage_ms": (C.c_int, [C.c_void_p, _f32p, C.c_int32]),
     "pocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "pocr_debug_read": (C.c_int, [C.c_void_p, C.c_int32, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -495,6 +496,10 @@ class NativeParseNet:
             self.close()
         except Exception:
             pass
+
+    def range_fallbacks(self) -> int:
+        """Pages re-run on the bf16x3 fall-back network by the f16x2 range guard (include/pocr.h: pocr_parsenet_range_fallbacks)."""
+        return int(self._lib.pocr_parsenet_range_fallbacks(self._h))
 
     def out_shape(self, h: int, w: int, downsample: int = 1):
         oh, ow = C.c_int32(0), C.c_int32(0)

@@ -31,6 +31,11 @@ struct pocr_parsenet {
     float last_ms = 0.f;
     DevBuf range;                          // f16x2 range guard (conv_igemm.hpp): one set of 8 words per conv layer, 1 .. 18 (e1 .. d0)
     unsigned *range_host = nullptr;
+    // a page on which a layer leaves f16's range is run again on bf16x3 (fp32's range) by a second network created on first use
+    // from the retained weight blob (38 MB on the host; 77 MB of weights + its own activation buffers on the device, only then)
+    std::vector<float> weights_host;
+    pocr_parsenet *shadow = nullptr;
+    int64_t range_fallbacks = 0;
 };
 
 namespace {
@@ -71,6 +76,7 @@ void pocr_parsenet_destroy(pocr_parsenet *p) {
     if (p->pin_out) (void)locked_host_free(p->pin_out);
     if (p->range_host) (void)locked_host_free(p->range_host);
     p->range.release();
+    if (p->shadow) { pocr_parsenet_destroy(p->shadow); p->shadow = nullptr; }
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -144,9 +150,12 @@ int pocr_parsenet_create(const float *weights, size_t n_floats, int device_id, p
         for (int i = 0; i < 256; ++i) lut[i] = (float)i * inv;
         if (upload(p->lut, lut, st)) return bail(1);
     }
+    if (conv_split() == 2) p->weights_host.assign(weights, weights + n_floats);      // for the range guard's fall-back network
     *out = p;
     return 0;
 }
+
+int64_t pocr_parsenet_range_fallbacks(pocr_parsenet *p) { return p ? p->range_fallbacks : 0; }
 
 int pocr_parsenet_out_shape(int32_t h, int32_t w, int32_t downsample, int32_t *out_h, int32_t *out_w) {
     if (h <= 0 || w <= 0 || downsample < 1 || !out_h || !out_w) return fail("invalid arguments");
@@ -266,8 +275,8 @@ static int parsenet_get_maps_impl(pocr_parsenet *p, const uint8_t *img_hwc, int3
         HIP_TRY(hipGetLastError());
     }
     // f16x2 range guard: the activations of this network stay fp32 in HBM and are split inside every consumer, so what a layer
-    // writes must stay inside f16's range like the recogniser's (pocr_hip.hip: range_verdict) - here an excursion is an ERROR
-    // (no automatic re-run: POCR_CONV_SPLIT=3 runs the network on bf16x3)
+    // writes must stay inside f16's range like the recogniser's (pocr_hip.hip: range_verdict); a page that leaves it is run
+    // again on the bf16x3 kernels of a second network (below)
     const bool guard = conv_split() == 2;
     int n_guarded = 0;
     if (guard) {
@@ -328,9 +337,21 @@ static int parsenet_get_maps_impl(pocr_parsenet *p, const uint8_t *img_hwc, int3
         for (int k = 0; k < n_guarded; ++k) {
             unsigned m = 0;
             for (int j = 0; j < 8; ++j) m = std::max(m, p->range_host[8 * k + j]);
-            if (m >= 0x477fe000u || (m != 0 && m < 0x39000000u))
-                return fail("layout network: conv layer %d left the range of the default f16x2 arithmetic (%s) - set POCR_CONV_SPLIT=3 (bf16x3, fp32's range)",
+            if (m >= 0x477fe000u || (m != 0 && m < 0x39000000u)) {
+                // plain fp32 in the reference (pero_ocr/layout_engines/torch_parsenet.py:49-53): the page again on bf16x3
+                if (p->weights_host.empty()) return fail("internal error: layout network range guard without a retained weight blob");
+                SplitScope scope(3);
+                if (!p->shadow) {
+                    fprintf(stderr, "NOTE: layout network: conv layer %d left the range of the default f16x2 arithmetic (%s); this page and any later "
+                                    "such page are re-run on bf16x3 (fp32's range).  POCR_CONV_SPLIT=3 selects bf16x3 for everything.\n",
                             k + 1, m >= 0x477fe000u ? "|x| >= 65504 or not finite" : "its whole activation lies below 2^-13");
+                    if (pocr_parsenet_create(p->weights_host.data(), p->weights_host.size(), p->device, &p->shadow)) return 1;
+                }
+                ++p->range_fallbacks;
+                const int rc = parsenet_get_maps_impl(p->shadow, img_hwc, H, W, downsample, taps, out_hw5);
+                p->last_ms = p->shadow->last_ms;
+                return rc;
+            }
         }
     parallel_memcpy(out_hw5, p->pin_out, out_bytes);
     HIP_TRY(hipEventElapsedTime(&p->last_ms, p->ev0, p->ev1));

@@ -572,6 +572,7 @@ struct pocr_engine {
     bool conv2_tile8 = false;        // the fused conv1+2 kernel as 8 x 16 tiles, three workgroups per CU (networks without a recurrence)
     DevBuf conv1_w2;                 // conv1's weights as f16x2 fragments (Conv1Args::w1x2)
     pocr_engine *shadow = nullptr;   // f16x2 range guard: the same network on bf16x3 (fp32's range), created when a launch first leaves f16's range
+    std::mutex shadow_mu;            // creation of / launches on the fall-back engine (decoding loops of several slots run on worker threads)
     std::vector<float> weights_host; // the weight blob (kept for the fall-back engine; f16x2 engines only)
     int64_t range_fallbacks = 0;     // launches re-run on the fall-back engine
     bool is_shadow = false;
@@ -905,7 +906,9 @@ int run_network(pocr_engine *e, Slot &s) {
     const size_t xe = (size_t)rows * E * sizeof(float);
     if (s.sa_x.reserve(xe) || s.sa_x1.reserve(xe) || s.sa_att.reserve(xe) || s.sa_tmp.reserve(xe)) return 1;
     if (s.sa_qkv.reserve(3 * xe) || s.sa_ff.reserve((size_t)rows * FF * sizeof(float))) return 1;
-    const int pe_need = std::max(T, c.arch == POCR_ARCH_S2S ? s.s2s_cap + 8 : 0);      // the decoder adds pe[step]
+    // the decoder adds pe[step] while OTHER slots' launches run (worker threads): the table gets its largest size - every step the
+    // decoder can take, every frame a staged line can have - on the first launch and is not replaced under a running decode
+    const int pe_need = std::max(T, c.arch == POCR_ARCH_S2S ? DEC_MAX_KEYS + 8 : 1024);
     if (pe_need > e->pe_rows) {      // sinusoidal table, float32 like PositionalEncoding (transformer.py:316-332)
         const int rows_pe = round_up(pe_need, 256);
         std::vector<float> pe((size_t)rows_pe * E);
@@ -2117,19 +2120,26 @@ int pocr_slot_stage_lines(pocr_engine *e, int32_t slot, const uint8_t *crops, co
 // results are taken from there.  pero_ocr/ocr_engine/pytorch_ocr_engine.py:61-69 computes in plain fp32: no input may give
 // worse than fp32's range here either.
 static int sync_and_guard(pocr_engine *e, int32_t slot);
+// the fall-back engine (bf16x3 kernels and weight layouts: call under SplitScope(3)), created on first use from the retained
+// weight blob: a second set of weights (~90 MB for the recogniser) and, per slot it ever serves, its own activation buffers
+// (17.6 MB per staged line at W_pad 576); an engine whose launches stay in range never pays for either
+static int ensure_shadow(pocr_engine *e, int verdict, int which) {
+    if (e->weights_host.empty()) return fail("internal error: range guard without a retained weight blob");
+    if (e->shadow) return 0;
+    fprintf(stderr, "NOTE: a launch left the range of the default f16x2 arithmetic (%s in activation set %d); it and any later such launch "
+                    "are re-run on bf16x3 (fp32's range, ~0.6x the speed).  POCR_CONV_SPLIT=3 selects bf16x3 for everything.\n",
+            verdict == 1 ? "|x| >= 65504 or not finite" : "a whole tensor below 2^-13", which);
+    pocr_engine *sh = nullptr;
+    if (pocr_create(&e->cfg, e->weights_host.data(), e->weights_host.size(), e->device, &sh)) return 1;
+    sh->is_shadow = true;
+    e->shadow = sh;
+    return 0;
+}
 static int run_fallback(pocr_engine *e, int32_t slot, int verdict, int which) {
     Slot &s = e->slot[slot];
-    if (e->weights_host.empty()) return fail("internal error: range guard without a retained weight blob");
     SplitScope scope(3);
-    if (!e->shadow) {
-        fprintf(stderr, "NOTE: a launch left the range of the default f16x2 arithmetic (%s in activation set %d); it and any later such launch "
-                        "are re-run on bf16x3 (fp32's range, ~0.6x the speed).  POCR_CONV_SPLIT=3 selects bf16x3 for everything.\n",
-                verdict == 1 ? "|x| >= 65504 or not finite" : "a whole tensor below 2^-13", which);
-        pocr_engine *sh = nullptr;
-        if (pocr_create(&e->cfg, e->weights_host.data(), e->weights_host.size(), e->device, &sh)) return 1;
-        sh->is_shadow = true;
-        e->shadow = sh;
-    }
+    std::lock_guard<std::mutex> lock(e->shadow_mu);
+    if (ensure_shadow(e, verdict, which)) return 1;
     pocr_engine *sh = e->shadow;
     sh->lstm_resident = e->lstm_resident; sh->lstm_spin_limit = e->lstm_spin_limit;
     sh->lstm_skip = std::max(sh->lstm_skip, e->lstm_skip);
@@ -2546,9 +2556,23 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
         s.guard_checked = true;
         int which = 0;
         if (const int verdict = range_verdict(s, &which)) {
+            // the encoder left f16's range: the same lines and batches again on the bf16x3 engine (plain fp32 in the reference:
+            // pero_ocr/ocr_engine/transformer_ocr_engine.py:32-47); this slot's reads are redirected to its slot there
             s.in_flight = false; s.s2s_launched = false;
-            return fail("the encoder left the range of the default f16x2 arithmetic (%s in activation set %d): the sequence-to-sequence engine has no "
-                        "automatic fall-back - set POCR_CONV_SPLIT=3 (bf16x3, fp32's range)", verdict == 1 ? "|x| >= 65504 or not finite" : "a whole tensor below 2^-13", which);
+            SplitScope scope(3);
+            std::lock_guard<std::mutex> lock(e->shadow_mu);
+            if (ensure_shadow(e, verdict, which)) return 1;
+            pocr_engine *sh = e->shadow;
+            Slot &t = sh->slot[slot];
+            if (t.in_flight && pocr_slot_reset(sh, slot)) return 1;
+            const uint8_t *base = s.crops_ext ? s.crops_ext : s.crops.as<uint8_t>();
+            if (stage_ragged_impl(sh, slot, nullptr, s.st_off.data(), s.st_w.data(), s.st_wpad.data(), s.n, 0, s.st_padl.data(), base)) return 1;
+            t.s2s_wpads = s.s2s_wpads;
+            if (pocr_s2s_launch(sh, slot, s.s2s_batch_first.data(), s.s2s_batches)) return 1;
+            if (pocr_s2s_decode(sh, slot, want_logits, steps, s_max)) return 1;
+            s.redirect = true; s.s2s_decoded = true;
+            ++e->range_fallbacks;
+            return 0;
         }
     }
     const int32_t *d_batch_first = s.s2s_tables.as<int32_t>(), *d_limit = d_batch_first + nb + 1;
@@ -2697,6 +2721,7 @@ int pocr_s2s_collect(pocr_engine *e, int32_t slot, int32_t *tokens, float *logit
     if (check_slot(e, slot)) return 1;
     Slot &s = e->slot[slot];
     if (!s.s2s_decoded) return fail("slot %d: pocr_s2s_decode first", slot);
+    if (s.redirect && e->shadow) return pocr_s2s_collect(e->shadow, slot, tokens, logits);     // decoded on the fall-back engine (range guard)
     if (logits && !s.s2s_want_logits) return fail("logits were not requested at pocr_s2s_decode");
     const int n = s.n, S_cap = s.s2s_cap, smax = s.s2s_smax, C = e->cfg.num_classes;
     const char *pin = static_cast<const char *>(s.s2s_pinned);
@@ -2712,6 +2737,7 @@ int pocr_s2s_sparse(pocr_engine *e, int32_t slot, const int32_t *row_end, float 
     if (check_slot(e, slot)) return 1;
     Slot &s = e->slot[slot];
     if (!s.s2s_decoded) return fail("slot %d: pocr_s2s_decode first", slot);
+    if (s.redirect && e->shadow) { SplitScope scope(3); return pocr_s2s_sparse(e->shadow, slot, row_end, threshold, total_nnz); }
     if (!row_end || !total_nnz) return fail("NULL pointer");
     HIP_TRY(hipSetDevice(e->device));
     const int n = s.n, S_cap = s.s2s_cap, C = e->cfg.num_classes;
@@ -2762,6 +2788,7 @@ int pocr_s2s_sparse(pocr_engine *e, int32_t slot, const int32_t *row_end, float 
 int pocr_s2s_collect_sparse(pocr_engine *e, int32_t slot, float *data, int32_t *indices, int32_t *indptr, int64_t *line_off) {
     if (check_slot(e, slot)) return 1;
     Slot &s = e->slot[slot];
+    if (s.redirect && e->shadow) return pocr_s2s_collect_sparse(e->shadow, slot, data, indices, indptr, line_off);
     if (!s.s2s_decoded || !s.sp_pinned) return fail("slot %d: pocr_s2s_sparse first", slot);
     if (!data || !indices || !indptr || !line_off) return fail("NULL output pointer");
     const int n = s.n, C = e->cfg.num_classes;

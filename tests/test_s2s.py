@@ -334,3 +334,51 @@ def test_gpu_s2s_bench_configuration_against_oracle(tmp_path):
     assert got_t == want_t and max(len(t) for t in got_t) >= 272
     worst = max(float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) for a, b in zip(got_l, want_l))
     assert worst < LOGIT_TOL, worst
+
+
+@pytest.mark.gpu
+def test_gpu_s2s_range_guard_reruns_on_bf16x3(tmp_path):
+    """The sequence-to-sequence engine's encoder runs in the f16x2 arithmetic: fp32's precision, f16's range; the reference
+    computes in plain fp32 (pero_ocr/ocr_engine/transformer_ocr_engine.py:32-47).  A network whose activations leave f16's range
+    (conv4 x 2^17, conv5 x 2^-17: the same function) must decode like the oracle on the rescaled weights with no action by the
+    caller: pocr_s2s_decode runs encoder and decoding loop again on the bf16x3 engine and the slot's reads go there - dense,
+    sparse and text-only calls; a network in range never takes the fall-back."""
+    from pero_ocr_amd import _native, synth
+    if _native.conv_split() != 2:
+        pytest.skip("the range guard belongs to the f16x2 arithmetic")
+    import torch
+    chars = [chr(0x61 + i) for i in range(20)]
+    spec = netspec.NetSpec(num_classes=len(chars) + 2, arch=netspec.ARCH_S2S, conv_out=256, sa_heads=4, sa_ff=512, sa_layers=1, dec_layers=1)
+    base = netspec.generate_weights(spec, 99, boundary_bias=30.0)
+    w = dict(base)
+    w["conv4.weight"] = base["conv4.weight"] * np.float32(2.0 ** 17)
+    w["conv4.bias"] = base["conv4.bias"] * np.float32(2.0 ** 17)
+    w["conv5.weight"] = base["conv5.weight"] * np.float32(2.0 ** -17)
+    crops = synth.make_crops(31, [200, 64, 333, 500, 90, 310, 40], 40)
+    net_cfg = {"dim_model": spec.conv_out, "dim_ff": spec.sa_ff, "heads": spec.sa_heads, "encoder_layers": spec.sa_layers,
+               "decoder_layers": spec.dec_layers, "conv_subsampling": [8, 4]}
+    fallbacks = {}
+    for name, weights in (("rescaled", w), ("in range", base)):
+        path = os.path.join(str(tmp_path), f"{name[:2]}.pocrw")
+        netspec.save_blob(path, spec, weights)
+        jpath = os.path.join(str(tmp_path), f"{name[:2]}.json")
+        with open(jpath, "w", encoding="utf8") as f:
+            json.dump({"line_px_height": 40, "line_vertical_scale": 1.0, "checkpoint": path, "characters": chars, "max_line_width": 1024,
+                       "net_name": net_cfg}, f)
+        eng = tengine.TransformerEngineLineOCR(jpath, torch.device("cuda:0"), batch_size=4)
+        model = s2s_oracle.OracleS2S(spec, weights)
+        want_t, want_l, want_c, _ = s2s_oracle.process_lines(model, crops, eng.characters, 40, 480 * 4, 1024)
+        got_t, got_l, got_c = eng.process_lines(crops, sparse_logits=False)
+        assert got_t == want_t and got_c == want_c, name
+        worst = max([float(np.max(np.abs(a - b))) for a, b in zip(got_l, want_l) if a.size] or [0.0])
+        print(f"[s2s range guard, {name}] max |dlogit| vs the oracle {worst:.3e}, fall-backs {eng.net.range_fallbacks()}")
+        assert worst < LOGIT_TOL, (name, worst)
+        t2, l2, _c2 = eng.process_lines(crops)                      # sparse (CSC built on the device that decoded)
+        assert t2 == want_t
+        for a, b in zip(l2, got_l):
+            d = np.asarray(a.todense()); keep = d != 0
+            assert np.array_equal(d[keep], np.asarray(b)[keep])
+        t3, _l3, _c3 = eng.process_lines(crops, no_logits=True)
+        assert t3 == want_t
+        fallbacks[name] = eng.net.range_fallbacks()
+    assert fallbacks["rescaled"] >= 3 and fallbacks["in range"] == 0, fallbacks
