@@ -47,18 +47,72 @@ def ceil32(v: int) -> int:
     return -(-int(v) // 32) * 32
 
 
-def plan_chunks(widths: Sequence[int], max_input_horizontal_pixels: int, line_padding_px: int = 32) -> List[Chunk]:
-    order = sorted(range(len(widths)), key=lambda i: -int(widths[i]))      # stable, like the reference's sorted()
-    chunks, pos = [], 0
-    while pos < len(order):
-        max_width = ceil32(widths[order[pos]])
-        if max_width == 0:       # the reference divides by ceil32(0) here (line_ocr_engine.py:87)
+class ChunkPlan(Sequence):
+    """The chunks of one process_lines call as a read-only sequence of `Chunk`.  The plan is held as arrays (first sorted
+    position, size, ceil32 width and padded width of every chunk, over the width-sorted line order); a `Chunk` object is made
+    when it is first asked for.  A rank of a sharded pass plans ALL chunks of the page stream but runs one eighth of them:
+    it reads costs and payload geometry from the arrays (`sizes`, `w_pads`) and materialises only its own."""
+    __slots__ = ("order", "starts", "sizes", "max_widths", "w_pads", "_made")
+
+    def __init__(self, order: List[int], starts: np.ndarray, sizes: np.ndarray, max_widths: np.ndarray, w_pads: np.ndarray):
+        self.order, self.starts, self.sizes, self.max_widths, self.w_pads = order, starts, sizes, max_widths, w_pads
+        self._made: List[Optional[Chunk]] = [None] * len(starts)
+
+    def __len__(self) -> int:
+        return len(self._made)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self._made)))]
+        c = self._made[k]
+        if c is None:
+            a = int(self.starts[k])
+            c = self._made[k] = Chunk(self.order[a:a + int(self.sizes[k])], int(self.max_widths[k]), int(self.w_pads[k]))
+        return c
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def __repr__(self):
+        return f"ChunkPlan({list(self)!r})"
+
+
+def plan_chunks(widths: Sequence[int], max_input_horizontal_pixels: int, line_padding_px: int = 32) -> ChunkPlan:
+    """line_ocr_engine.py:79-90, 121-127 as a plan: stable sort by descending width, then chunks of
+    max(1, limit // ceil32(widest remaining)) lines.  The sort and the rounding are numpy; the chunk boundaries are
+    found run by run of equal ceil32 width (a chunk's size depends only on the width of its first line, so inside a run
+    the starts are an arithmetic progression - ~30 steps instead of one per chunk): 0.1 ms for the 2048 lines / 343
+    chunks of the c3 stream."""
+    n = len(widths)
+    limit, pad2 = int(max_input_horizontal_pixels), 2 * int(line_padding_px)
+    if n == 0:
+        z = np.zeros(0, np.int64)
+        return ChunkPlan([], z, z, z, z)
+    w = np.asarray(widths, dtype=np.int64)
+    top = int(w.max())
+    # (widths fit 16 bits on any real page: a stable sort of uint16 keys is numpy's radix sort, 4x the speed of the int64 one)
+    order = np.argsort((top - w).astype(np.uint16), kind="stable") if 0 <= int(w.min()) and top < 65536 else np.argsort(-w, kind="stable")
+    cw = -(-w[order] // 32) * 32                          # ceil32 of the widths, widest first
+    run_first = np.flatnonzero(np.concatenate(([True], cw[1:] != cw[:-1])))
+    run_end = np.concatenate((run_first[1:], [n])).tolist()
+    run_w = cw[run_first].tolist()
+    first, step, count, width, pos = [], [], [], [], 0
+    for v, b in zip(run_w, run_end):                     # chunks that START inside the run of width v, i.e. at pos .. b - 1
+        if pos >= b:
+            continue
+        if v == 0:               # the reference divides by ceil32(0) here (line_ocr_engine.py:87)
             raise ZeroDivisionError("zero-width line crop")
-        take = max(1, int(max_input_horizontal_pixels) // max_width)
-        w_pad = min(max_width + 2 * line_padding_px, int(max_input_horizontal_pixels))   # :121 then crop :125-127
-        chunks.append(Chunk(order[pos:pos + take], max_width, w_pad))
-        pos += take
-    return chunks
+        take = limit // v or 1
+        k = -(-(b - pos) // take)
+        first.append(pos); step.append(take); count.append(k); width.append(v)
+        pos += k * take
+    count = np.asarray(count, dtype=np.int64)
+    takes = np.repeat(np.asarray(step, dtype=np.int64), count)
+    max_widths = np.repeat(np.asarray(width, dtype=np.int64), count)
+    within = np.arange(int(count.sum()), dtype=np.int64) - np.repeat(np.cumsum(count) - count, count)
+    starts = np.repeat(np.asarray(first, dtype=np.int64), count) + within * takes
+    sizes = np.minimum(takes, n - starts)
+    return ChunkPlan(order.tolist(), starts, sizes, max_widths, np.minimum(max_widths + pad2, limit))     # :121 then crop :125-127
 
 
 @dataclass
@@ -188,6 +242,9 @@ class BaseEngineLineOCR:
         one rank's share: sharding.ShardedLineOCR - a line's result depends on its chunk's padded width, so a rank must run
         chunks of the plan over ALL lines, never a plan of its own lines).  Returns the three lists of process_lines, in
         input order, with None for the lines of chunks that were not given."""
+        if getattr(self, "process_lines_end", None) is None or self.model_type != "ctc":
+            raise TypeError("process_chunks is the CTC engine's call (chunks of the reference's CTC plan); the sequence-to-sequence "
+                            "engine shards whole batches: sharding.ShardedSeq2SeqOCR / seq2seq_recogniser")
         return self.process_lines_end(self._begin_chunks(lines, chunks, sparse_logits, tight_crop_logits, no_logits))
 
     # -- the same call in two halves: a caller with a STREAM of process_lines calls (document_ocr.page_stream) begins call

@@ -24,6 +24,7 @@ not exist and "weight_seed" is given, seeded synthetic weights are generated ins
 from __future__ import annotations
 
 import os
+import threading
 from typing import List, Tuple
 
 import numpy as np
@@ -56,29 +57,58 @@ def _device_index(device) -> int:
 _CP_CACHE = {}
 
 
-def labels_to_strings(labels: np.ndarray, lens: np.ndarray, characters) -> List[str]:
+def labels_to_strings(labels: np.ndarray, lens: np.ndarray, characters, col0: int = 0, rows=None) -> List[str]:
     """Label ids -> strings (pytorch_ocr_engine.py:29-32: ''.join(chars[c] for c in line)).  When every entry of `characters`
     is ONE code point (the reference's character sets) all lines are decoded in one pass - gather the code points of every
     kept label, one UTF-32 decode, then slice per line - 20x less host time than a Python loop per symbol (a 2048-line page
-    stream: 10 ms -> 0.5 ms per rank, which matters once 8 ranks share the GPU work)."""
-    n = labels.shape[0]
+    stream: 10 ms -> 0.5 ms per rank, which matters once 8 ranks share the GPU work).  `col0`: the symbols of a row start at
+    that column, and `rows` (int array) picks and orders the rows to decode (the gathered payload rows of sharding.py are read in
+    place, in line order)."""
+    n = labels.shape[0] if rows is None else len(rows)
     if n == 0:
         return []
-    key = id(characters)
-    ent = _CP_CACHE.get(key)
-    if ent is None or ent[0] is not characters:
-        cps = np.array([ord(c) for c in characters], dtype=np.uint32) if all(isinstance(c, str) and len(c) == 1 for c in characters) else None
-        if len(_CP_CACHE) > 16:
-            _CP_CACHE.clear()
-        ent = _CP_CACHE[key] = (characters, cps)
-    cps = ent[1]
-    if cps is None:
-        return ["".join(characters[c] for c in labels[i, :lens[i]]) for i in range(n)]
-    ln = np.asarray(lens, dtype=np.int64)
-    keep = np.arange(labels.shape[1])[None, :] < ln[:, None]
-    text = cps[labels[keep]].astype("<u4").tobytes().decode("utf-32-le")
+    if getattr(characters, "_cps", 0) is None:              # sharding._CodePoints: the rows hold code points already
+        cps = None
+        identity = True
+    else:
+        identity = False
+        key = id(characters)
+        ent = _CP_CACHE.get(key)
+        if ent is None or ent[0] is not characters:
+            cps = np.array([ord(c) for c in characters], dtype=np.uint32) if all(isinstance(c, str) and len(c) == 1 for c in characters) else None
+            if len(_CP_CACHE) > 16:
+                _CP_CACHE.clear()
+            ent = _CP_CACHE[key] = (characters, cps)
+        cps = ent[1]
+    if cps is None and not identity:
+        pick = range(n) if rows is None else [int(r) for r in rows]
+        return ["".join(characters[c] for c in labels[i, col0:col0 + max(int(lens[i]), 0)]) for i in pick]
+    ln = np.maximum(np.asarray(lens, dtype=np.int64), 0)
+    row_id = np.arange(n, dtype=np.int64) if rows is None else np.asarray(rows, dtype=np.int64)
+    if rows is not None:
+        ln = ln[row_id]
     ends = np.cumsum(ln)
-    return [text[e - k:e] for e, k in zip(ends.tolist(), ln.tolist())]
+    total = int(ends[-1])
+    flat_labels = (labels if labels.flags.c_contiguous else np.ascontiguousarray(labels)).reshape(-1)
+    if flat_labels.size >= 2 ** 31 or total + n >= 2 ** 31:
+        return ["".join(characters[c] for c in labels[int(i), col0:col0 + int(k)]) for i, k in zip(row_id, ln)]
+    # Work proportional to the SYMBOLS, not to lines x the widest row (a gathered page stream is 2048 rows of 272 columns holding
+    # ~30 symbols each), 32-bit indices, np.take: the output is the page's symbols with one NUL behind every line - position q
+    # belongs to line line_of[q] and is read at that row's start + its offset in the line -, then one decode and one split
+    if cps is not None and cps.size and int(cps.min()) == 0:
+        text = cps[flat_labels[(np.repeat(row_id * labels.shape[1] + col0 - (ends - ln), ln) + np.arange(total)).astype(np.int64)]].astype("<u4").tobytes().decode("utf-32-le")
+        return [text[e - k:e] for e, k in zip(ends.tolist(), ln.tolist())]         # (a character set with NUL in it: slice per line)
+    ln1 = ln + 1
+    ends1 = ends + np.arange(1, n + 1)
+    line_of = np.repeat(np.arange(n, dtype=np.int32), ln1)
+    src = np.take((row_id * labels.shape[1] + col0 - (ends1 - ln1)).astype(np.int32), line_of)
+    src += np.arange(total + n, dtype=np.int32)
+    stops = ends1 - 1                                       # where the NULs go
+    src[stops] = 0
+    sym = np.take(flat_labels, src)
+    sym = sym.astype("<u4") if identity else np.take(cps, sym, mode="clip")
+    sym[stops] = 0
+    return sym.astype("<u4", copy=False).tobytes().decode("utf-32-le").split("\x00")[:n]
 
 
 def greedy_decode_ctc(scores_probs, chars, device_id: int = 0) -> List[str]:
@@ -121,7 +151,9 @@ class _EmbeddingView:
 
 _FAST_CSC = None          # None: not probed yet; dict / False: the attribute-level construction below is / is not in use
 _FAST_CSC_SCIPY = ((1, 8), (1, 17))      # scipy versions [lo, hi) on which the attribute-level construction has been run against the constructor (1.15.3 here)
-_FAST_CSC_CHECKED = 0     # matrices of this process whose GPU triplets were verified to be canonical (the first few of every process)
+_FAST_CSC_CHECKED = 0     # matrices of this process so far: the first 64 and then every 256th have their GPU triplets verified to be canonical
+_FAST_CSC_SHAPES = set()  # ... and the first matrix of every distinct number of rows (a new kernel path - long lines, the fall-back engine - shows up as one)
+_FAST_CSC_LOCK = threading.Lock()
 
 
 def _canonical_triplets(indices, indptr, shape) -> bool:
@@ -138,6 +170,33 @@ def _canonical_triplets(indices, indptr, shape) -> bool:
     return bool(np.all(np.diff(indices, prepend=-1)[inner] > 0)) if len(indices) else True
 
 
+def _probe_fast_csc(data, indices, indptr, shape):
+    """-> the per-instance state of a constructor-built csc_matrix if the attribute-level construction of _csc_from_device gives
+    an object indistinguishable from the constructor's on this scipy, else False."""
+    env = os.environ.get("POCR_FAST_CSC", "")
+    import scipy
+    ver = tuple(int(x) for x in scipy.__version__.split(".")[:2] if x.isdigit())
+    if not (env == "1" or (env != "0" and _FAST_CSC_SCIPY[0] <= ver < _FAST_CSC_SCIPY[1])):
+        return False
+    try:
+        ref = sparse.csc_matrix((data, indices, indptr), shape=shape)
+        ref.sort_indices(); ref.sum_duplicates()                   # what the constructor leaves to be found out lazily
+        state = {k: v for k, v in ref.__dict__.items() if k not in ("data", "indices", "indptr", "_shape")}
+        probe = sparse.csc_matrix.__new__(sparse.csc_matrix)
+        probe.__dict__.update(state)
+        probe.data, probe.indices, probe.indptr, probe._shape = data, indices, indptr, tuple(int(v) for v in shape)
+        fresh = sparse.csc_matrix((data, indices, indptr), shape=shape)      # an independent constructor-built object to compare with
+        extra = set(vars(probe)) - set(vars(fresh))             # only the two lazily cached flags may be new
+        if (set(vars(fresh)) <= set(vars(probe)) and extra <= {"_has_sorted_indices", "_has_canonical_format"} and
+                probe.shape == fresh.shape and probe.nnz == fresh.nnz and
+                (probe != fresh).nnz == 0 and np.array_equal(probe.toarray(), fresh.toarray()) and
+                np.array_equal((probe.T @ probe).toarray(), (fresh.T @ fresh).toarray())):
+            return state
+    except Exception:
+        pass
+    return False
+
+
 def _csc_from_device(data, indices, indptr, shape):
     """scipy.sparse.csc_matrix((data, indices, indptr), shape) for the triplets the GPU's compaction builds (sorted row
     indices, no duplicates, int32 index arrays).  The public constructor spends ~16 us per matrix on validation - 4 ms per
@@ -148,32 +207,18 @@ def _csc_from_device(data, indices, indptr, shape):
     process (_canonical_triplets).  Everything else goes through the constructor."""
     global _FAST_CSC, _FAST_CSC_CHECKED
     if _FAST_CSC is None:
-        env = os.environ.get("POCR_FAST_CSC", "")
-        import scipy
-        ver = tuple(int(x) for x in scipy.__version__.split(".")[:2] if x.isdigit())
-        allowed = env == "1" or (env != "0" and _FAST_CSC_SCIPY[0] <= ver < _FAST_CSC_SCIPY[1])
-        _FAST_CSC = False
-        if allowed:
-            try:
-                ref = sparse.csc_matrix((data, indices, indptr), shape=shape)
-                ref.sort_indices(); ref.sum_duplicates()                   # what the constructor leaves to be found out lazily
-                state = {k: v for k, v in ref.__dict__.items() if k not in ("data", "indices", "indptr", "_shape")}
-                probe = sparse.csc_matrix.__new__(sparse.csc_matrix)
-                probe.__dict__.update(state)
-                probe.data, probe.indices, probe.indptr, probe._shape = data, indices, indptr, tuple(int(v) for v in shape)
-                fresh = sparse.csc_matrix((data, indices, indptr), shape=shape)      # an independent constructor-built object to compare with
-                extra = set(vars(probe)) - set(vars(fresh))             # only the two lazily cached flags may be new
-                if (set(vars(fresh)) <= set(vars(probe)) and extra <= {"_has_sorted_indices", "_has_canonical_format"} and
-                        probe.shape == fresh.shape and probe.nnz == fresh.nnz and
-                        (probe != fresh).nnz == 0 and np.array_equal(probe.toarray(), fresh.toarray()) and
-                        np.array_equal((probe.T @ probe).toarray(), (fresh.T @ fresh).toarray())):
-                    _FAST_CSC = state
-            except Exception:
-                _FAST_CSC = False
+        with _FAST_CSC_LOCK:         # (decoding loops of the sequence-to-sequence engine build matrices on worker threads: one probe)
+            if _FAST_CSC is None:
+                _FAST_CSC = _probe_fast_csc(data, indices, indptr, shape)
     if not _FAST_CSC:
         return sparse.csc_matrix((data, indices, indptr), shape=shape)
-    if _FAST_CSC_CHECKED < 64:               # the GPU compaction's contract, verified where it is cheap: the first matrices of the process
-        _FAST_CSC_CHECKED += 1
+    # the GPU compaction's contract, verified where it is cheap and where a new path would first show: the first matrices of the
+    # process, the first of every row count, and a sample of the rest (ADVICE r04)
+    _FAST_CSC_CHECKED += 1
+    rows_key = int(shape[0])
+    if _FAST_CSC_CHECKED <= 64 or _FAST_CSC_CHECKED % 256 == 0 or rows_key not in _FAST_CSC_SHAPES:
+        if len(_FAST_CSC_SHAPES) < 4096:
+            _FAST_CSC_SHAPES.add(rows_key)
         if not _canonical_triplets(indices, indptr, shape):
             _FAST_CSC = False
             return sparse.csc_matrix((data, indices, indptr), shape=shape)

@@ -27,19 +27,27 @@ def assign_chunks(chunks: Sequence[Chunk], world_size: int) -> List[List[int]]:
     """Longest-processing-time-first on cost = lines * padded width (conv work is linear in
     both).  Returns, per rank, the indices of its chunks (ascending).  Deterministic: every
     rank computes the same assignment from the same widths."""
+    sizes = getattr(chunks, "sizes", None)               # a ChunkPlan: costs straight from its arrays
+    if sizes is not None:
+        return assign_by_cost(sizes * chunks.w_pads, world_size)
     return assign_by_cost([len(c.line_ids) * c.w_pad for c in chunks], world_size)
 
 
 def assign_by_cost(cost: Sequence[int], world_size: int) -> List[List[int]]:
-    """LPT: heaviest unit first, each to the currently least loaded rank (ties: lower rank)."""
-    order = sorted(range(len(cost)), key=lambda i: (-cost[i], i))
-    load = [0] * world_size
+    """LPT: heaviest unit first, each to the currently least loaded rank (ties: lower rank) - a heap of (load, rank)."""
+    import heapq
+    c = np.asarray(cost, dtype=np.int64)
+    order = np.argsort(-c, kind="stable").tolist()        # heaviest first, ties by index
+    cl = c.tolist()
+    heap = [(0, r) for r in range(world_size)]
     mine: List[List[int]] = [[] for _ in range(world_size)]
     for i in order:
-        r = min(range(world_size), key=lambda k: (load[k], k))
+        load, r = heap[0]
         mine[r].append(i)
-        load[r] += cost[i]
-    return [sorted(m) for m in mine]
+        heapq.heapreplace(heap, (load + cl[i], r))
+    for m in mine:
+        m.sort()
+    return mine
 
 
 # ---- transports: who carries the one all-gather ------------------------------------------------------------------
@@ -163,23 +171,60 @@ ROW_FAILED = -2          # length field of a payload row whose rank could not pr
 
 
 def _raise_together(got: np.ndarray, failure, transport, m_of: Sequence[int]) -> None:
-    """After the all-gather: if any rank flagged its rows, EVERY rank raises (the failing one its own exception)."""
+    """After the all-gather (padded rows: allgather_rows(compact=False)): if any rank flagged its rows, EVERY rank raises
+    (the failing one its own exception)."""
     if failure is not None:
         raise failure
     if got.size and bool(np.any(got[:, 1] == ROW_FAILED)):
-        bounds = np.concatenate([[0], np.cumsum(m_of)])
-        bad = [r for r in range(transport.world) if np.any(got[bounds[r]:bounds[r + 1], 1] == ROW_FAILED)]
+        m_max = got.shape[0] // transport.world
+        bad = [r for r in range(transport.world) if np.any(got[r * m_max:r * m_max + m_of[r], 1] == ROW_FAILED)]
         raise RuntimeError(f"rank(s) {bad} failed in their share of the page stream; no rank returns a partial result")
 
 
-def allgather_rows(transport, rows: np.ndarray, m_max: int, m_of: Sequence[int]) -> np.ndarray:
+def _strings_of_rows(got: np.ndarray, n: int, table) -> List[Optional[str]]:
+    """Padded payload rows [line id, length, symbols...] -> the n strings, in one vectorised decode (`table`: the
+    characters for label ids, None when the symbols are code points themselves)."""
+    from .ocr_engine.pytorch_ocr_engine import labels_to_strings
+    if got.shape[0] == 0:
+        return [None] * n
+    ids = got[:, 0]
+    if table is None:
+        table = _CodePoints()
+    row_of = np.full(n, -1, dtype=np.int64)               # payload row of every line (ids < 0: padding rows)
+    valid = np.flatnonzero(ids >= 0)
+    row_of[ids[valid]] = valid
+    if valid.size == n and bool(np.all(row_of >= 0)):     # the usual case: every line is there - decoded straight into line order
+        return labels_to_strings(got, got[:, 1], table, col0=2, rows=row_of)
+    texts: List[Optional[str]] = [None] * n
+    for i, t in zip(ids[valid].tolist(), labels_to_strings(got, got[:, 1], table, col0=2, rows=valid)):
+        texts[i] = t
+    return texts
+
+
+class _CodePoints:
+    """`characters` stand-in for rows that already hold code points: labels_to_strings takes its vectorised path with the
+    identity table."""
+    _cps = None
+
+
+def allgather_rows(transport, rows: np.ndarray, m_max: int, m_of: Sequence[int], compact: bool = True) -> np.ndarray:
     """ONE fixed-stride all-gather.  rows: int32 [m_r, stride] of this rank; every rank knows m_of (rows per rank) and
-    therefore m_max from the shared plan, so no sizes are exchanged.  Returns the ranks' rows back to back."""
+    therefore m_max from the shared plan, so no sizes are exchanged.  Returns the ranks' rows back to back; with
+    compact=False the padded [world * m_max, stride] array itself (rank r's rows start at r * m_max; padding rows have
+    id -1) - the callers below read it in place instead of copying 2 MB per call."""
     stride = rows.shape[1]
-    pay = np.full((m_max, stride), -1, dtype=np.int32)
-    pay[:rows.shape[0]] = rows
-    out = transport.allgather_i32(pay.reshape(-1)).reshape(transport.world, m_max, stride)
-    return np.concatenate([out[r, :m_of[r]] for r in range(transport.world)], axis=0) if m_max else np.zeros((0, stride), np.int32)
+    if m_max == 0:
+        return np.zeros((0, stride), np.int32)
+    if rows.shape[0] == m_max:
+        pay = np.ascontiguousarray(rows, dtype=np.int32)
+    else:
+        pay = np.full((m_max, stride), -1, dtype=np.int32)
+        pay[:rows.shape[0]] = rows
+    out = transport.allgather_i32(pay.reshape(-1)).reshape(transport.world * m_max, stride)
+    if not compact or all(m == m_max for m in m_of):
+        return out
+    keep = (np.arange(m_max)[None, :] < np.asarray(m_of)[:, None]).reshape(-1)       # one gather instead of a concatenation of slices
+    return out[keep]
 
 
 class ShardedLineOCR:
@@ -216,11 +261,11 @@ class ShardedLineOCR:
         chunks = plan_chunks([l.shape[1] for l in lines], self.max_input_horizontal_pixels, self.line_padding_px)
         parts = assign_chunks(chunks, tr.world)
         mine = [chunks[i] for i in parts[tr.rank]]
-        ids_of = [[i for ci in p for i in chunks[ci].line_ids] for p in parts]
-        m_of = [len(x) for x in ids_of]
+        m_of = [int(chunks.sizes[p].sum()) for p in parts]
+        ids_mine = [i for c in mine for i in c.line_ids]
         # transcriptions travel as code points; a frame emits at most one symbol, so the plan bounds a row's length
         cp_max = max([len(ch) for ch in self.characters], default=1)
-        stride = max([c.frames for c in chunks], default=0) * cp_max + 2
+        stride = (int((chunks.w_pads.max() // 2) // 2) if len(chunks) else 0) * cp_max + 2
         rows = np.full((m_of[tr.rank], stride), -1, dtype=np.int32)              # [line id, length, code points...]
         logits: List[object] = [None] * n
         coords: List[object] = [None] * n
@@ -228,7 +273,7 @@ class ShardedLineOCR:
         try:                                   # (a failing rank still takes part in the collective, with its rows flagged)
             if mine:
                 texts_mine, logits, coords = full(lines, mine, sparse_logits, tight_crop_logits)
-                for k, i in enumerate(ids_of[tr.rank]):
+                for k, i in enumerate(ids_mine):
                     cps = [ord(ch) for ch in texts_mine[i]]
                     if len(cps) > stride - 2:
                         raise RuntimeError(f"line {i}: transcription of {len(cps)} symbols exceeds the plan's bound {stride - 2}")
@@ -237,12 +282,9 @@ class ShardedLineOCR:
         except Exception as exc:              # noqa: BLE001 - re-raised below, after the collective
             failure = exc
             rows[:, 1] = ROW_FAILED
-        got = allgather_rows(tr, rows, max(m_of, default=0), m_of)
+        got = allgather_rows(tr, rows, max(m_of, default=0), m_of, compact=False)
         _raise_together(got, failure, tr, m_of)
-        texts: List[Optional[str]] = [None] * n
-        for row in got:
-            texts[int(row[0])] = "".join(chr(int(c)) for c in row[2:2 + row[1]])
-        return texts, logits, coords
+        return _strings_of_rows(got, n, None), logits, coords
 
     def _texts_from_labels(self, lines) -> List[str]:
         tr = self.transport
@@ -250,8 +292,8 @@ class ShardedLineOCR:
         parts = assign_chunks(chunks, tr.world)
         mine = parts[tr.rank]
         # payload geometry from the plan alone (identical on every rank): rows per rank, longest label row
-        m_of = [sum(len(chunks[i].line_ids) for i in p) for p in parts]
-        t_max = max([c.frames for c in chunks], default=0)
+        m_of = [int(chunks.sizes[p].sum()) for p in parts]
+        t_max = int((chunks.w_pads.max() // 2) // 2) if len(chunks) else 0
         rows = np.full((m_of[tr.rank], t_max + 2), -1, dtype=np.int32)       # [line id, length, labels...]
         # A rank that fails must not leave the others blocked in the collective: it still takes part, with its rows
         # flagged (length = ROW_FAILED), and every rank raises after the exchange.
@@ -271,13 +313,9 @@ class ShardedLineOCR:
         except Exception as exc:              # noqa: BLE001 - re-raised below, after the collective
             failure = exc
             rows[:, 1] = ROW_FAILED
-        got = allgather_rows(tr, rows, max(m_of, default=0), m_of)
+        got = allgather_rows(tr, rows, max(m_of, default=0), m_of, compact=False)
         _raise_together(got, failure, tr, m_of)
-        texts: List[Optional[str]] = [None] * len(lines)
-        from .ocr_engine.pytorch_ocr_engine import labels_to_strings
-        for i, t in zip(got[:, 0].tolist(), labels_to_strings(got[:, 2:], got[:, 1], self.characters)):
-            texts[i] = t
-        return texts
+        return _strings_of_rows(got, len(lines), self.characters)
 
 
 def engine_recogniser(engine) -> Callable:
@@ -306,6 +344,10 @@ def engine_recogniser(engine) -> Callable:
         from collections import deque
         pending = deque()
         try:
+            # the slots belong to the engine's own queue of launches in flight (process_lines_begin tickets of a page stream may
+            # be open): collect those first, so that launch j of this call can take slot j % depth
+            while getattr(engine, "_inflight", None):
+                engine._collect_oldest()
             from .ocr_engine.line_ocr_engine import pipeline_depth
             depth = pipeline_depth(engine)                # launches in flight, one engine slot each (as process_lines)
             for j, launch in enumerate(plan_launches(chunks, launch_target(engine))):
@@ -377,12 +419,9 @@ class ShardedSeq2SeqOCR:
         except Exception as exc:              # noqa: BLE001 - re-raised below, after the collective
             failure = exc
             rows[:, 1] = ROW_FAILED
-        got = allgather_rows(tr, rows, max(m_of, default=0), m_of)
+        got = allgather_rows(tr, rows, max(m_of, default=0), m_of, compact=False)
         _raise_together(got, failure, tr, m_of)
-        out: List[Optional[str]] = [None] * len(lines)
-        for row in got:
-            out[int(row[0])] = "".join(chr(int(c)) for c in row[2:2 + row[1]])
-        return out
+        return _strings_of_rows(got, len(lines), None)
 
 
 def seq2seq_recogniser(engine) -> Callable:
