@@ -117,9 +117,48 @@ def physical_cores():
         return os.cpu_count() or 1
 
 
+def kernel_trace_summary(workload, fl, n_lines, peak):
+    """From the committed rocprofv3 kernel trace of this bench (profiles/rNN_bench_<workload>_kernel_stats.txt, newest round):
+    the kernel with the longest average duration and the share of the sequence stage in the summed kernel time - the `roofline`
+    object names conv9, the largest kernel by FLOPs; under overlapping launches other kernels can last longer per call."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r[0-9][0-9]_bench_{workload}_kernel_stats.txt")))
+    if not files:
+        return None
+    rows = []
+    for ln in open(files[-1]):
+        m = re.match(r"\s*(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+(.*)", ln)
+        if m:
+            rows.append((int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4)), m.group(5).strip()))
+    if not rows:
+        return None
+    total = sum(r[1] for r in rows)
+    longest = max((r for r in rows if "pocr::" in r[4]), key=lambda r: r[2])
+    # algorithmic FLOPs of the conv kernels by their template signature (fused conv1+2: the ...true> at the end; conv9: BN = true)
+    sig = {"conv1+2": "10, 1, 1, 1, 2, 2, 1, false, 2, true, 3, 3, 1, 1, false, 2, true, true, true>",
+           "conv9": "5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false, 2, true, true, false>"}
+    name = next((k for k, v in sig.items() if v in longest[4]), None)
+    flops = None
+    if name == "conv9":
+        flops = fl["conv9"] * n_lines
+    elif name == "conv1+2":
+        flops = (fl["conv1"] + fl["conv2"]) * n_lines
+    seq = sum(r[1] for r in rows if "lstm_" in r[4])
+    out = {"source": os.path.relpath(files[-1], REPO),
+           "longest_kernel_in_trace": {"kernel": longest[4][:140], "layer": name, "avg_ms": round(longest[2] / 1e3, 4), "calls": longest[0],
+                                       "share_of_kernel_time": round(longest[1] / total, 4),
+                                       "frac": round(flops / (longest[2] * 1e-6) / 1e12 / peak, 4) if flops else None},
+           "sequence_stage_share_of_kernel_time": round(seq / total, 4)}
+    return out
+
+
 def cpu_baseline(spec, weights, crops, width, batch_size):
     """The oracle (PyTorch-CPU restatement of the reference path, parity-pinned against the imported reference) timed
-    on this box's host cores: a thread-count sweep on 64 lines, then ALL lines of the step at the best count."""
+    on this box's host cores.  A thread-count sweep on 64 lines; then, at the best count, the step's chunk BOTH ways - all its
+    lines in one forward pass (what the reference does with this batch_size) and the same lines 64 at a time (same padded
+    width, so the same per-line arithmetic; oneDNN's threading often prefers the smaller batch) - and the better median is the
+    baseline: the CPU's best on the chunk the GPU number is quoted on."""
     import torch
     from oracle import engine_oracle, model_oracle
     net = model_oracle.OracleNet(spec, weights)
@@ -132,39 +171,50 @@ def cpu_baseline(spec, weights, crops, width, batch_size):
         _best, labels = engine_oracle.greedy_ctc(nct)
         return [engine_oracle.labels_to_text(l, chars) for l in labels]
 
-    phys = physical_cores()
+    def rate(ids, pieces, reps):
+        """lines/s of `reps` timed passes over ids, each pass as len(ids) / pieces lines per forward (one discarded warm-up)."""
+        step = -(-len(ids) // pieces)
+        parts = [ids[k:k + step] for k in range(0, len(ids), step)]
+        for p in parts[:1]:
+            one_pass(p)
+        out = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for p in parts:
+                one_pass(p)
+            out.append(len(ids) / (time.perf_counter() - t0))
+        return out
+
+    phys, logical = physical_cores(), os.cpu_count() or 1
     sweep = {}
-    cands = sorted({c for c in (8, 16, 32, 64, phys) if c <= (os.cpu_count() or 1)})
+    cands = sorted({c for c in (8, 16, 32, 64, phys) if c <= logical})
     sample = list(range(min(64, len(crops))))
     t_sweep = time.perf_counter()
     for c in cands:                              # ascending; stop once more threads clearly lose (oversubscribed small convs)
-        if sweep and time.perf_counter() - t_sweep > 45.0:
+        if sweep and time.perf_counter() - t_sweep > 30.0:
             break
         torch.set_num_threads(c)
-        one_pass(sample)                         # warm-up (discarded)
-        t0 = time.perf_counter()
-        one_pass(sample)
-        sweep[c] = len(sample) / (time.perf_counter() - t0)
+        sweep[c] = rate(sample, 1, 1)[0]
         if sweep[c] < 0.8 * max(sweep.values()):
             break
     best = max(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    # one discarded warm-up, median of >= 5 timed repetitions.  The sample is bounded to ~25 s of CPU
-    # work: as many of the step's lines as five passes fit into that at the swept rate (all 256 on a box doing > 50 lines/s).
-    n_samp = int(min(len(crops), max(32, sweep[best] * 25.0 / 5.0)))
+    # bounded to ~25 s of CPU work: as many of the step's lines as four full passes fit into ~17 s at the swept rate (all 256 on
+    # a box doing > 60 lines/s), three timed passes each way (BASELINE.md section 4 asks for a warm-up and a median)
+    n_samp = int(min(len(crops), max(64, sweep[best] * 17.0 / 4.0) // 64 * 64)) if len(crops) >= 64 else len(crops)
     ids = list(range(n_samp))
-    one_pass(ids)
-    rates = []
-    for _ in range(5):
-        t0 = time.perf_counter()
-        one_pass(ids)
-        rates.append(len(ids) / (time.perf_counter() - t0))
-    med = float(np.median(rates))
-    return {"value": round(med, 2), "unit": "lines/s", "cores": int(best), "kind": "port",
-            "sample": f"{len(ids)} of the step's {len(crops)} 40x{width} crops as one chunk (W_pad {max_width + 64}): one discarded warm-up pass, "
-                      f"then the MEDIAN of 5 timed passes at the best thread count of a sweep on {len(sample)} lines (1 warm-up + 1 timed "
-                      f"pass per count); torch {torch.__version__} CPU fp32, {phys} physical cores / {os.cpu_count()} logical",
-            "passes_lines_per_s": [round(r, 2) for r in rates],
+    whole = rate(ids, 1, 3)
+    pieces = max(1, n_samp // 64)
+    by64 = rate(ids, pieces, 3) if pieces > 1 else list(whole)
+    med_whole, med_64 = float(np.median(whole)), float(np.median(by64))
+    med = max(med_whole, med_64)
+    return {"value": round(med, 2), "unit": "lines/s", "cores": int(best), "threads": int(best), "physical_cores": int(phys),
+            "logical_cpus": int(logical), "kind": "port",
+            "sample": f"{len(ids)} of the step's {len(crops)} 40x{width} crops, every forward pass padded to W_pad {max_width + 64} like the step's chunk: "
+                      f"median of 3 timed passes (one discarded warm-up) with all {len(ids)} lines in ONE forward pass = {med_whole:.1f} lines/s, as "
+                      f"{pieces} forward passes of 64 lines = {med_64:.1f} lines/s; `value` is the better of the two, at the best thread count "
+                      f"({best}) of a sweep on {len(sample)} lines; torch {torch.__version__} CPU fp32",
+            "whole_chunk_lines_per_s": [round(r, 2) for r in whole], "by_64_lines_per_s": [round(r, 2) for r in by64],
             "thread_sweep_lines_per_s": {str(k): round(v, 2) for k, v in sweep.items()}}
 
 
@@ -344,7 +394,11 @@ def main():
                    "characters": chars[:-1], "net_name": "bench"}, f)
     engine = PytorchEngineLineOCR(os.path.join(tmp.name, "ocr.json"), Dev(local_rank), batch_size=wl["batch_size"])
     eng = engine.model
-    n_slots = min(eng.num_slots, 2)          # launches in flight in the c2 / c4 loop (the engine has 4 slots; deeper pipelines measured slower)
+    # Launches in flight in the c2 / c4 step loop.  The product's process_lines keeps THREE in flight (pipeline_depth: a ragged
+    # stream's launches complete in pairs with two and the host assembles results in between); this loop runs one uniform chunk
+    # per step with nothing for the host to assemble, and two is its measured optimum (8.98 against 9.19 ms per step with three,
+    # profiles/r04_launch_timeline.txt) - `extra.c2_sparse`, `extra.c3` and `extra.c5` go through process_lines at the product's depth.
+    n_slots = min(eng.num_slots, 2)
     if os.environ.get("POCR_BENCH_SLOTS"):   # experiments
         n_slots = max(1, min(eng.num_slots, int(os.environ["POCR_BENCH_SLOTS"])))
 
@@ -720,15 +774,18 @@ def main():
                        "parallelism": f"chunk-sharded x{world}, one RCCL all-gather of labels per step (C ABI)"
                                       if transport is not None else "single GPU, no collective",
                        "collective": collective, "conv_arithmetic": SPLIT_NAME[split],
-                       "pipelining": f"{n_slots} launches in flight per GPU (separate HIP streams)"},
+                       "pipelining": (f"{n_slots} launches in flight per GPU (separate HIP streams) in this step loop - its measured optimum for one uniform "
+                                      "chunk per step; process_lines (extra.c2_sparse / c3 / c5) runs at the product's default of three")
+                                     if n_slots == 2 and args.workload in ("c2", "c4") else f"{n_slots} launches in flight per GPU (separate HIP streams)"},
         }
         result.update(shape_rccl_fields(result, rccl_fields, collective))
         if w_pad is not None:
             traffic = None          # HBM bytes per launch of the dominant kernel, from the committed PMC passes
             pmc_meta = {}
-            pmc_file = {2: "r04_pmc_summary.json", 3: "r02_pmc_summary.json", 0: "pmc_summary.json"}[split]
-            if not os.path.exists(os.path.join(REPO, "profiles", pmc_file)):
-                pmc_file = "r03_pmc_summary.json"
+            pmc_file = {2: "r05_pmc_summary.json", 3: "r02_pmc_summary.json", 0: "pmc_summary.json"}[split]
+            for older in ("r04_pmc_summary.json", "r03_pmc_summary.json"):
+                if not os.path.exists(os.path.join(REPO, "profiles", pmc_file)):
+                    pmc_file = older
             dom_sig = {2: "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false, 2, true, true",
                        3: "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false>", 0: "5, 1, 4, 4, 16, 1, 1, 2, true"}[split]
             try:
@@ -771,6 +828,10 @@ def main():
                 "mfma_pipe_frac": round(nm * dom_tf / (BF16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS), 4),
                 "vs_bf16x3_ceiling_416.7": round(dom_tf / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
                 "vs_fp32_mfma_peak_157.3": round(dom_tf / F32_MFMA_PEAK_TFLOPS, 4)}
+            if split == 2:
+                kt = kernel_trace_summary(args.workload, fl, n_lines, peak)
+                if kt:
+                    result["roofline"]["kernel_trace"] = kt
             if split:
                 # measured on this part, register-only loops of independent MFMAs, 2 waves per SIMD, at the package power cap:
                 # v_mfma_f32_16x16x32_f16 sustains 2432 TFLOP/s on zero operands and 2027 on random ones (tools/mfma_shape_probe.hip,
