@@ -35,6 +35,66 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *a, const fl
     if (row >= rows) return;
     const float *pa = a + (size_t)row * E;
     const float *pb = b ? b + (size_t)row * E : nullptr;
+    if ((E & 511) == 0 && E <= 1024) {
+        // E = 512 / 1024 (the encoder's widths): a lane owns whole channel OCTETS - 32-byte loads, and the P2 copy is written as the
+        // 16-byte h / l units the GEMM reads instead of two 2-byte stores per value (the kernel ran at 26 % of the HBM rate on c4:
+        // 0.8 ms per step for five passes over 53 248 rows, profiles/r04_bench_c4_kernel_stats.txt)
+        const int NV = E >> 9;
+        f32x4 v0[2], v1[2];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k >= NV) break;
+            const int e = (k * 64 + lane) * 8;
+            v0[k] = *reinterpret_cast<const f32x4 *>(pa + e); v1[k] = *reinterpret_cast<const f32x4 *>(pa + e + 4);
+            if (pb) { v0[k] += *reinterpret_cast<const f32x4 *>(pb + e); v1[k] += *reinterpret_cast<const f32x4 *>(pb + e + 4); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sum += v0[k][c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sum += v1[k][c];
+        }
+        if (go == 0) return;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float mean = sum / (float)E;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k >= NV) break;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float d0 = v0[k][c] - mean, d1 = v1[k][c] - mean; sq += d0 * d0; sq += d1 * d1; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        const float rstd = 1.0f / sqrtf(sq / (float)E + eps);
+        const float *ppe = pe ? pe + (size_t)(row_t ? row_t[row] : row % T) * E : nullptr;
+        float *py = y + (size_t)row * E;
+        unsigned rmax = 0u;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k >= NV) break;
+            const int e = (k * 64 + lane) * 8;
+            const f32x4 g0 = *reinterpret_cast<const f32x4 *>(gamma + e), g1 = *reinterpret_cast<const f32x4 *>(gamma + e + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(beta + e), b1 = *reinterpret_cast<const f32x4 *>(beta + e + 4);
+            f32x4 o0, o1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { o0[c] = (v0[k][c] - mean) * rstd * g0[c] + b0[c]; o1[c] = (v1[k][c] - mean) * rstd * g1[c] + b1[c]; }
+            if (ppe) { o0 += *reinterpret_cast<const f32x4 *>(ppe + e); o1 += *reinterpret_cast<const f32x4 *>(ppe + e + 4); }
+            *reinterpret_cast<f32x4 *>(py + e) = o0; *reinterpret_cast<f32x4 *>(py + e + 4) = o1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { range_note(rmax, o0[c]); range_note(rmax, o1[c]); }
+            if (y_p2) {
+                u32x2 h0, l0, h1, l1;
+                split2_quad(o0, h0, l0);
+                split2_quad(o1, h1, l1);
+                u32x4 *d = reinterpret_cast<u32x4 *>(static_cast<char *>(y_p2) + (size_t)row * E * 4 + p2_channel_bytes(e));
+                d[0] = (u32x4){h0[0], h0[1], h1[0], h1[1]};
+                d[4] = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+            }
+        }
+        range_publish(range_max, rmax, lane);
+        return;
+    }
     constexpr int MAXV = 16;                    // E <= 1024
     float v[MAXV];
     float sum = 0.f;

@@ -144,13 +144,14 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
     auto load_x = [&](int j, int s) {
         const int tl = max(Ti[j], 1);
         const int t = min(max(dir == 0 ? s : Ti[j] - 1 - s, 0), tl - 1);
-        const float *xp = a.xproj + (size_t)(row0[j] + t) * (8 * H) + (size_t)dir * 4 * H + (size_t)((lane >> 2) & 3) * H + ug * 16 + (lane & 3) * 4;
+        // (gate slot = gate ^ (line & 1): the two lines a 32-lane group of read_x covers then sit 16 banks apart instead of on the same ones)
+        const float *xp = a.xproj + (size_t)(row0[j] + t) * (8 * H) + (size_t)dir * 4 * H + (size_t)(((lane >> 2) & 3) ^ ((lane >> 4) & 1)) * H + ug * 16 + (lane & 3) * 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)xp,
                                          (__attribute__((address_space(3))) void *)(xl + (j * 4 + wave) * 256), 16, 0, 0);
     };
     auto read_x = [&](int j, float (&x)[4]) {              // thread (i, u): gate g of unit u of line i
 #pragma unroll
-        for (int g = 0; g < 4; ++g) x[g] = xl[(j * 4 + wave) * 256 + ((((lane >> 4) * 4 + g) * 4 + ((lane & 15) >> 2)) * 4) + (lane & 3)];
+        for (int g = 0; g < 4; ++g) x[g] = xl[(j * 4 + wave) * 256 + ((((lane >> 4) * 4 + (g ^ ((lane >> 4) & 1))) * 4 + ((lane & 15) >> 2)) * 4) + (lane & 3)];
     };
     // W_hh fragments of this unit group, resident for the whole layer (the step kernel re-reads them every step)
     const bool f16 = a.whh2 != nullptr;
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
     }
 #pragma unroll
     for (int j = 0; j < SL; ++j) load_x(j, 0);
-    const int src = (((i >> 2) * 16 + u) * 4) + (i & 3);      // D layout of the reduced gates (as lstm_step_kernel)
+    const int src = (((i >> 2) * 16 + u) * 4) + ((i & 3) ^ ((u >> 3) * 2));      // D layout of the reduced gates (as lstm_step_kernel), halves swapped for u >= 8 (below)
+    const int psw = (li >> 3) * 2;
 
 #if POCR_LSTM_RES_DBG
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;
@@ -282,7 +284,9 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
 #pragma unroll
                 for (int q = 0; q < QB; ++q) {
                     const int blk = min(wave + 4 * q, NB - 1);
-                    const f32x4 *pp = reinterpret_cast<const f32x4 *>(hpre + li * HP + blk * 32 + kq * 8);
+                    // landed kq-major (below): the 16-lane groups of a ds_read_b128 mix two kq values - with the row's natural order
+                    // their 16-byte units met on the same banks (LDS bank-conflict share 0.38, profiles/r04_pmc_summary.json)
+                    const f32x4 *pp = reinterpret_cast<const f32x4 *>(hpre + li * HP + (kq * 16 + blk * 2) * 4);
                     x0[q] = pp[0]; x1[q] = pp[1];
                 }
                 lstm_mfma_f16x2<KPW>(x0, x1, wave, w2, acc);
@@ -302,9 +306,13 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
                         for (int g = 0; g < 4; ++g)
                             acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][jj], bv[q][g][jj], acc[g], 0, 0, 0);
             }
+            // (the two halves of a lane's four values change places for lines 8..15: the transposed reads below then find lines u and u + 8 on different banks)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4 *>(&part[((wave * 4 + g) * 64 + lane) * 4]) = acc[g];
+            for (int g = 0; g < 4; ++g) {
+                float *pw = &part[((wave * 4 + g) * 64 + lane) * 4];
+                *reinterpret_cast<f32x2 *>(pw + psw) = (f32x2){acc[g][0], acc[g][1]};
+                *reinterpret_cast<f32x2 *>(pw + (psw ^ 2)) = (f32x2){acc[g][2], acc[g][3]};
+            }
             POCR_TICK(1);                                      // h loads + MFMAs
             // The previous slice-step's state store is published HERE, one slice-step late: its L2 acknowledgement has had this
             // step's wait + GEMM to arrive, and the barrier that orders everybody's acknowledgement is the one the LDS reduction
@@ -326,7 +334,8 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int piece = wave * 4 + q;                    // = the row of h (H = 256: 1 KB)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)piece * H + lane * 4),
+                        // LDS unit l of the row (lane-linear landing) = the row's unit (blk = (l & 15) >> 1, kq = l >> 4, half = l & 1)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)piece * H + ((((lane & 15) >> 1) * 8 + (lane >> 4) * 2 + (lane & 1)) * 4)),
                                                          (__attribute__((address_space(3))) void *)(hpre + piece * HP), 16, 0, 2 /* nt: served by L2, like the direct loads */);
                     }
                     have_pre = true;

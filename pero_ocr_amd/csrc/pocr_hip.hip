@@ -501,8 +501,6 @@ struct Slot {
     size_t lstm_err_off = 0;             // index (uint32) of the error words inside lstm_sync
     bool lstm_resident_used = false;     // this launch ran the resident kernel: collect checks the error word
     bool lstm_force_step = false;        // the repeat of a launch whose resident recurrence timed out: step kernels
-    hipEvent_t lstm_done = nullptr;      // recorded behind this slot's last resident launch: while it is pending, its workgroups count against the chip's capacity
-    int lstm_grid_pending = 0;           // workgroups of that launch
     uint32_t *lstm_err_host = nullptr;   // pinned copy of the error words
     DevBuf nf_flag;                      // set by frame_argmax_kernel when a winning logit is NaN / inf
     int32_t *nf_host = nullptr;          // pinned copy, read at collect time
@@ -1076,8 +1074,7 @@ int run_network(pocr_engine *e, Slot &s) {
     // for where the query is known to be optimistic); a launch that does not fit takes more slices per workgroup, then the
     // step kernels.
     auto resident_grid = [&](int sl) { return ((2 * ((n_sl + sl - 1) / sl) + 7) / 8) * ug_n * 8; };
-    // capacity of the instantiation that would be launched (they differ in registers and LDS), minus the workgroups of resident
-    // launches of OTHER slots that have not finished yet (three launches are in flight by default: their recurrences overlap)
+    // capacity of the instantiation that would be launched (they differ in registers and LDS)
     auto capacity = [&](int sl) {
         const int ki = Hh == 64 ? 0 : Hh == 128 ? 1 : 2, si = sl == 1 ? 0 : sl == 2 ? 1 : 2;
         int &cap = e->lstm_capacity[ki][si];
@@ -1095,15 +1092,10 @@ int run_network(pocr_engine *e, Slot &s) {
             cap = std::min(per_cu, 4) * e->n_cus;
             if (per_cu > 1) cap -= e->n_cus;
         }
-        int pending = 0;
-        for (int k = 0; k <= POCR_NUM_SLOTS; ++k) {
-            Slot &o = e->slot[k];
-            if (&o == &s || o.lstm_grid_pending == 0 || !o.lstm_done) continue;
-            if (hipEventQuery(o.lstm_done) == hipSuccess) o.lstm_grid_pending = 0;
-            else pending += o.lstm_grid_pending;
-        }
-        (void)hipGetLastError();                       // (hipErrorNotReady of the query is not an error)
-        return cap - pending;
+        // (Resident launches of OTHER slots still running are not subtracted: their workgroups retire within milliseconds and a
+        // later launch's clusters simply become resident then - every wait is bounded far above that.  Subtracting them was
+        // measured: the third launch of a page of long lines fell back to the step kernels, one page at a time 13.7 -> 19.1 ms of OCR.)
+        return cap;
     };
     while (SLn < 4 && resident_grid(SLn) > capacity(SLn)) SLn *= 2;
     const bool resident_shape = e->lstm_resident && (Hh == 64 || Hh == 128 || Hh == 256) && c.lstm_layers <= 8;
@@ -1175,11 +1167,6 @@ int run_network(pocr_engine *e, Slot &s) {
 #undef POCR_RES
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(s.lstm_err_host + 4 * l, s.lstm_sync.as<unsigned>() + s.lstm_err_off, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            if (l == c.lstm_layers - 1) {
-                if (!s.lstm_done) HIP_TRY(hipEventCreateWithFlags(&s.lstm_done, hipEventDisableTiming));
-                HIP_TRY(hipEventRecord(s.lstm_done, st));
-                s.lstm_grid_pending = (int)grid;
-            }
 #if POCR_LSTM_RES_DBG
             {
                 unsigned long long ph[6];
@@ -1871,7 +1858,6 @@ void pocr_destroy(pocr_engine *e) {
         if (s.range_host) (void)locked_host_free(s.range_host);
         s.lstm_sync.release();
         if (s.lstm_err_host) (void)locked_host_free(s.lstm_err_host);
-        if (s.lstm_done) (void)hipEventDestroy(s.lstm_done);
         if (s.host_in) (void)locked_host_free(s.host_in);
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);
