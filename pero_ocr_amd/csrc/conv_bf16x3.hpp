@@ -438,7 +438,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             const int e = tid + it * NTHR, c = e % 3, p = e / 3, wc = p % F1_PW, hr = p / F1_PW;
             const int hi = h0 - 2 + hr, wi = w0 - 2 + wc, xc = wi - ld.pad_left;
             pok[it] = e < F1_N && hi >= 0 && hi < src_h && wi >= 0 && wi < Win && xc >= 0 && xc < ld.width;
-            pb[it] = pok[it] ? src[((size_t)hi * ld.width + xc) * 3 + c] : (unsigned char)0;
+            // (unconditional loads from a clamped address, then a select: a conditional load is a branch, and the branches put one
+            // memory round trip after the other in front of every tile - the table look-ups below cost four of them)
+            const unsigned char got = *(pok[it] ? src + ((size_t)hi * ld.width + xc) * 3 + c : a.f1_crops);      // (the pool's first byte always exists)
+            pb[it] = pok[it] ? got : (unsigned char)0;
         }
         // conv1's weights (A operand) of all four channel tiles, its bias for this lane's channels 16 nt + 4 kq + r
         u32x4 xwh[4], xwl[4];
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int it = 0; it < F1_IT; ++it) {
             const int e = tid + it * NTHR;
-            const float v = pok[it] ? a.f1_lut[pb[it]] : 0.f;
+            const float v = a.f1_lut[pb[it]];            // (pb = 0 outside the crop, and entry 0 of the table is 0 / 255 = 0)
             if (e < F1_N) patch[e] = v;
         }
         if (tid < 4) patch[F1_N + tid] = 0.f;
