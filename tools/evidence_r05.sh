@@ -24,7 +24,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_c2 -o c2 -- python $R/be
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_c4 -o c4 -- python $R/bench.py --workload c4 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_c4_under_rocprof.json 2> $O/prof_c4.err
 # (kernel trace with ONE decoding loop at a time: side by side the loops share the HBM and a kernel's duration is no longer its own)
 POCR_S2S_DEPTH=1 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_s2s -o s2s -- python $R/tools/s2s_bench.py 2048 512 4 3 20 > $O/s2s_under_rocprof.json 2> $O/prof_s2s.err
-for grp in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
+for grp in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
   name=$(echo $grp | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $grp --kernel-trace -d $O/pmc -o pmc_$name -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_$name.out 2> $O/pmc_$name.err
 done
