@@ -54,6 +54,9 @@ __device__ unsigned long long g_conv_trace[1 << 18];
 #else
 #define POCR_TRACE_STAMP(k) do { } while (0)
 #endif
+#ifndef POCR_LDA_BUFFER
+#define POCR_LDA_BUFFER 0              // experiment (P2 input): the halo tile through bounds-checked buffer loads (padding = an offset beyond the descriptor) instead of conditional loads
+#endif
 #ifndef POCR_BF16X3_DBG
 #define POCR_BF16X3_DBG 0            // tools/conv_bench_bf16.hip: 1 no A reads, 2 no weight loads, 4 no A staging, 8 no barrier
 #endif
@@ -343,11 +346,21 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     const f32x4 *wt4 = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * (NT / 16) * WU;      // WU x 16 B per cout tile
     const size_t chunk_stride = (size_t)a.cout16 * WU, tap_stride = (size_t)nchunks * chunk_stride;
     f32x4 ra[A_LD], rb[B_LD];
+#if POCR_LDA_BUFFER
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)0xF0000000u, 0x00020000);
+    unsigned xbo[A_LD];
+#pragma unroll
+    for (int r = 0; r < A_LD; ++r) xbo[r] = (PRE_IN && a_ok[r]) ? (unsigned)(img_base * 4) + a_off[r] * 16u : 0xF0000000u;
+#endif
     auto ldA = [&](int chunk) {
 #pragma unroll
         for (int r = 0; r < A_LD; ++r) {
             if constexpr (PRE_IN) {
+#if POCR_LDA_BUFFER
+                ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)xbo[r], chunk * 128, 0));
+#else
                 ra[r] = a_ok[r] ? reinterpret_cast<const f32x4 *>(ximg)[a_off[r] + chunk * 8] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
                 continue;
             }
             const float *src = ximg + chunk * KC + a_off[r];

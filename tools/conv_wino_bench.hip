@@ -33,6 +33,9 @@ VP(x9_22, 5, 2, 2, 2, 1, 1, ACT_LEAKY, true, 2, false)     // 5x32 px x 64 ch, w
 VP(x9_41, 5, 4, 2, 4, 1, 1, ACT_LEAKY, true, 2, false)     // 5x64 px x 32 ch, waves 4 (px)
 VP(x9_42, 5, 4, 4, 4, 1, 1, ACT_LEAKY, true, 1, false)     // 5x64 px x 64 ch, waves 4 (px), NS 4: one workgroup per CU
 VP(x9_24, 5, 2, 4, 2, 1, 1, ACT_LEAKY, true, 1, false)     // 5x32 px x 128 ch, waves 2 x 2, NS 4
+// ... and with the weights straight from L2 (row-streaming loop): the waves that share channels request the SAME fragments - L1 serves the second
+VP(x9_r22, 5, 2, 2, 2, 1, 1, ACT_LEAKY, true, 2, true)     // 5x32 px x 64 ch, waves 2 (px) x 2 (ch)
+VP(x9_r41, 5, 4, 2, 4, 1, 1, ACT_LEAKY, true, 2, true)     // 5x64 px x 32 ch, waves 4 (px)
 template <int TH, int PH, int PW, int ACT, bool BN>
 static void wino(WinoArgs a, hipStream_t st) {
     a.tiles_n = (a.cout16 * 16) / 64;
@@ -203,7 +206,7 @@ int main(int argc, char **argv) {
                 out[px * s.cout + c] = f16val(raw[o]) + f16val(raw[o + 32]) * (1.0f / 2048.0f);
             }
     };
-    const int nvar = layer == 9 ? 6 : 2;
+    const int nvar = layer == 9 ? 8 : 2;
     for (int vi = 0; vi < nvar; ++vi) {
         WinoArgs a{};
         a.x = dx; a.wfrag = vi == 1 ? dw2 : dw; a.bias = db; a.bn_scale = ds; a.bn_shift = dh; a.y = vi ? dy2 : dy;
@@ -215,7 +218,7 @@ int main(int argc, char **argv) {
 #endif
         if (is_w) { a.x_bytes = (uint32_t)(xin * 4); a.wtiles = dwt; a.n_ptiles = (int)wt.size(); a.line_w = dlw; a.in_off = dio; a.out_off = doo; }
         auto run = [&]() {
-            if (vi >= 2) { switch (vi) { case 2: x9_22(a, st); break; case 3: x9_41(a, st); break; case 4: x9_42(a, st); break; default: x9_24(a, st); } }
+            if (vi >= 2) { switch (vi) { case 2: x9_22(a, st); break; case 3: x9_41(a, st); break; case 4: x9_42(a, st); break; case 5: x9_24(a, st); break; case 6: x9_r22(a, st); break; default: x9_r41(a, st); } }
             else if (!vi) {
                 switch (layer) { case 9: d9(a, st); break; case 8: d8(a, st); break; case 7: d7(a, st); break; case 6: case 5: d56(a, st); break; case 4: d4(a, st); break; default: d3(a, st); }
             } else {
@@ -254,7 +257,8 @@ int main(int argc, char **argv) {
         double maxref = 0, rmsref = 0, maxdiff = 0; size_t nnan = 0;
         for (int k = 0; k < NSAMP; ++k) { const double d = fabs((double)yy[samp[k]] - ref[k]); maxref = d > maxref ? d : maxref; rmsref += d * d; }
         if (vi) for (size_t k = 0; k < yout; ++k) { const double d = fabs((double)yw[k] - yd[k]); if (!(d == d)) ++nnan; else if (d > maxdiff) maxdiff = d; }
-        const char *vname[6] = {"direct f16x2 P2 (shipped)", "Winograd F(2,3) f16x2", "direct 5x32x64 2x2 LDS weights", "direct 5x64x32 4x1 LDS weights", "direct 5x64x64 4x1 NS4 1WG", "direct 5x32x128 2x2 NS4 1WG"};
+        const char *vname[8] = {"direct f16x2 P2 (shipped)", "Winograd F(2,3) f16x2", "direct 5x32x64 2x2 LDS weights", "direct 5x64x32 4x1 LDS weights", "direct 5x64x64 4x1 NS4 1WG", "direct 5x32x128 2x2 NS4 1WG",
+                                "direct 5x32x64 2x2 rows, L2 weights", "direct 5x64x32 4x1 rows, L2 weights"};
         printf("  %-34s avg %.3f ms best %.3f ms  %.1f TF(alg)", vname[vi], sum / reps, best, flops / (sum / reps * 1e-3) / 1e12);
         if (sustained > 0) printf("  sustained x%d: %.3f ms %.1f TF", sustained, sus, flops / (sus * 1e-3) / 1e12);
         printf("  vs float64: max %.2e rms %.2e", maxref, sqrt(rmsref / NSAMP));
