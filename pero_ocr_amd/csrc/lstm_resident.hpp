@@ -149,9 +149,10 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)xp,
                                          (__attribute__((address_space(3))) void *)(xl + (j * 4 + wave) * 256), 16, 0, 0);
     };
+    const int xb0 = wave * 256 + (lane >> 4) * 64 + (lane & 15) + 16 * ((lane >> 4) & 1);      // dword of gate slot 0 of thread (line, unit) in its wave's piece
     auto read_x = [&](int j, float (&x)[4]) {              // thread (i, u): gate g of unit u of line i
-#pragma unroll
-        for (int g = 0; g < 4; ++g) x[g] = xl[(j * 4 + wave) * 256 + ((((lane >> 4) * 4 + (g ^ ((lane >> 4) & 1))) * 4 + ((lane & 15) >> 2)) * 4) + (lane & 3)];
+        // gate slot = gate ^ (line & 1): two per-lane bases that differ in one address bit, constant offsets otherwise
+        x[0] = xl[j * 1024 + xb0]; x[1] = xl[j * 1024 + (xb0 ^ 16)]; x[2] = xl[j * 1024 + xb0 + 32]; x[3] = xl[j * 1024 + (xb0 ^ 16) + 32];
     };
     // W_hh fragments of this unit group, resident for the whole layer (the step kernel re-reads them every step)
     const bool f16 = a.whh2 != nullptr;
@@ -168,8 +169,8 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
     }
 #pragma unroll
     for (int j = 0; j < SL; ++j) load_x(j, 0);
-    const int src = (((i >> 2) * 16 + u) * 4) + ((i & 3) ^ ((u >> 3) * 2));      // D layout of the reduced gates (as lstm_step_kernel), halves swapped for u >= 8 (below)
-    const int psw = (li >> 3) * 2;
+    const int src = (((i >> 2) * 16 + u) * 4) + (i & 3);      // D layout of the reduced gates (as lstm_step_kernel); (lines u and u + 8 meet on a bank: a 2-way conflict
+                                                              // of sixteen 4-byte reads per step - swapping halves to avoid it cost the kernel its last free register)
 
 #if POCR_LSTM_RES_DBG
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;
@@ -306,13 +307,9 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
                         for (int g = 0; g < 4; ++g)
                             acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][jj], bv[q][g][jj], acc[g], 0, 0, 0);
             }
-            // (the two halves of a lane's four values change places for lines 8..15: the transposed reads below then find lines u and u + 8 on different banks)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float *pw = &part[((wave * 4 + g) * 64 + lane) * 4];
-                *reinterpret_cast<f32x2 *>(pw + psw) = (f32x2){acc[g][0], acc[g][1]};
-                *reinterpret_cast<f32x2 *>(pw + (psw ^ 2)) = (f32x2){acc[g][2], acc[g][3]};
-            }
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4 *>(&part[((wave * 4 + g) * 64 + lane) * 4]) = acc[g];
             POCR_TICK(1);                                      // h loads + MFMAs
             // The previous slice-step's state store is published HERE, one slice-step late: its L2 acknowledgement has had this
             // step's wait + GEMM to arrive, and the barrier that orders everybody's acknowledgement is the one the LDS reduction

@@ -296,3 +296,46 @@ def test_no_kernel_of_the_library_spills():
     assert len(scratch) >= 100, len(scratch)
     bad = [(nm, s) for nm, s in zip([x for x in names if x.startswith("_Z")], scratch) if s]
     assert max(scratch) == 0, bad[:5]
+
+
+def test_chunk_plan_is_a_lazy_sequence_with_the_plan_as_arrays():
+    """plan_chunks returns the plan as arrays (what a rank of a sharded pass reads) and makes `Chunk` objects on demand:
+    the arrays and the objects must say the same, slicing / iteration / equality behave like a list's, and the plan equals
+    the oracle's for widths with ties, a single line and more lines than a chunk holds."""
+    rng = np.random.RandomState(11)
+    for widths, limit in (([777], 3840), ([64] * 200, 3840), (rng.randint(1, 4000, 500).tolist(), 480 * 8), ([5000, 10, 10], 3840)):
+        plan = line_ocr_engine.plan_chunks(widths, limit)
+        ref = engine_oracle.chunk_plan(widths, limit)
+        assert len(plan) == len(ref) and [(c.line_ids, c.max_width) for c in plan] == [(i, m) for i, m in ref]
+        assert plan.sizes.tolist() == [len(c.line_ids) for c in plan] and plan.w_pads.tolist() == [c.w_pad for c in plan]
+        assert plan[-1] is plan[len(plan) - 1] and plan[0:2] == list(plan)[0:2] and plan == list(plan)
+        assert sorted(i for c in plan for i in c.line_ids) == list(range(len(widths)))
+    assert len(line_ocr_engine.plan_chunks([], 3840)) == 0
+    big = line_ocr_engine.plan_chunks([70000, 3, 100000], 3840)          # widths beyond 16 bits take the comparison sort
+    assert [c.line_ids for c in big] == [[2], [0], [1]]
+
+
+def test_labels_to_strings_paths():
+    """The vectorised decode (one take / UTF-32 decode / split) against the per-symbol loop: ragged lengths incl. empty lines and
+    padding rows (length -1), a row selection in another order, symbols starting at a column offset, multi-code-point entries
+    (loop path) and a character set that contains NUL (slice path)."""
+    from pero_ocr_amd.ocr_engine.pytorch_ocr_engine import labels_to_strings
+    rng = np.random.RandomState(5)
+    chars = [chr(0x100 + i) for i in range(40)]
+    labels = rng.randint(0, 40, size=(30, 17)).astype(np.int32)
+    lens = rng.randint(0, 18, size=30).astype(np.int32)
+    lens[3] = 0
+    want = ["".join(chars[c] for c in labels[i, :lens[i]]) for i in range(30)]
+    assert labels_to_strings(labels, lens, chars) == want
+    rows = np.array([7, 0, 29, 3], np.int64)
+    assert labels_to_strings(labels, lens, chars, rows=rows) == [want[i] for i in rows]
+    padded = np.full((32, 20), -1, np.int32)
+    padded[:30, 3:] = labels
+    plen = np.concatenate([lens, [-1, -1]]).astype(np.int32)
+    assert labels_to_strings(padded, plen, chars, col0=3) == want + ["", ""]
+    assert labels_to_strings(padded[:, ::1][:30], lens, chars, col0=3) == want
+    multi = chars[:-1] + ["ch"]                                         # an entry of two code points: the loop path
+    assert labels_to_strings(labels, lens, multi) == ["".join(multi[c] for c in labels[i, :lens[i]]) for i in range(30)]
+    nul = ["\\x00"] + chars[1:]                                          # NUL in the set: no split on it
+    assert labels_to_strings(labels, lens, nul) == ["".join(nul[c] for c in labels[i, :lens[i]]) for i in range(30)]
+    assert labels_to_strings(labels[:0], lens[:0], chars) == []
