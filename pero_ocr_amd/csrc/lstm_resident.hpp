@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
     }
 #pragma unroll
     for (int j = 0; j < SL; ++j) load_x(j, 0);
-    const int src = (((i >> 2) * 16 + u) * 4) + (i & 3);      // D layout of the reduced gates (as lstm_step_kernel); (lines u and u + 8 meet on a bank: a 2-way conflict
-                                                              // of sixteen 4-byte reads per step - swapping halves to avoid it cost the kernel its last free register)
+    const int src = (((i >> 2) * 16 + u) * 4) + ((i & 3) ^ ((u >> 3) * 2));      // D layout of the reduced gates (as lstm_step_kernel), halves swapped for u >= 8 (below)
+    const bool hi8 = li >= 8;
 
 #if POCR_LSTM_RES_DBG
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;
@@ -307,9 +307,12 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
                         for (int g = 0; g < 4; ++g)
                             acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][jj], bv[q][g][jj], acc[g], 0, 0, 0);
             }
+            // (lines 8..15 store their halves swapped - a select on the VALUES, the address stays one register: the transposed reads
+            // below then find lines u and u + 8 on different banks)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4 *>(&part[((wave * 4 + g) * 64 + lane) * 4]) = acc[g];
+                *reinterpret_cast<f32x4 *>(&part[((wave * 4 + g) * 64 + lane) * 4]) =
+                    hi8 ? (f32x4){acc[g][2], acc[g][3], acc[g][0], acc[g][1]} : acc[g];
             POCR_TICK(1);                                      // h loads + MFMAs
             // The previous slice-step's state store is published HERE, one slice-step late: its L2 acknowledgement has had this
             // step's wait + GEMM to arrive, and the barrier that orders everybody's acknowledgement is the one the LDS reduction
