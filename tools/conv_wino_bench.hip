@@ -57,16 +57,18 @@ static void trace_report() {
     hipLaunchKernelGGL(trace_copy_kernel, dim3(256), dim3(256), 0, 0, dp, nb * 8);
     CK(hipMemcpy(t.data(), dp, nb * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     CK(hipFree(dp));
-    unsigned long long tmin = ~0ull, tmax = 0; double ph[4] = {0, 0, 0, 0}; size_t ran = 0;
+    unsigned long long tmin = ~0ull, tmax = 0; double ph[4] = {0, 0, 0, 0}; size_t ran = 0; double lat = 0, latn = 0;
     for (size_t b = 0; b < nb; ++b) {
         const unsigned long long *q = &t[b * 8];
         if (!q[4]) continue;
         ++ran; tmin = std::min(tmin, q[0]); tmax = std::max(tmax, q[4]);
         for (int k = 0; k < 4; ++k) ph[k] += (double)(q[k + 1] - q[k]);
+        lat += (double)q[6]; latn += (double)q[7];
     }
     if (!ran) { printf("    trace: no stamps\n"); return; }
     printf("    trace (first %zu workgroups): span %.1f us; mean per workgroup: prologue %.2f us, main loop %.2f us, epilogue issue %.2f us, store drain %.2f us\n",
            ran, (tmax - tmin) * 0.01, ph[0] / ran * 0.01, ph[1] / ran * 0.01, ph[2] / ran * 0.01, ph[3] / ran * 0.01);
+    if (latn > 0) printf("    activation-load bursts: mean issue-to-data %.2f us over %.0f bursts\n", lat / latn * 0.01, latn);
 }
 #endif
 int main(int argc, char **argv) {

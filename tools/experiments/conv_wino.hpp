@@ -70,6 +70,12 @@ inline size_t wino_grid_blocks(const WinoArgs &a) {    // (conv_grid_blocks with
 #ifndef POCR_WINO_WSPREAD
 #define POCR_WINO_WSPREAD 0            // 1: the next chunk's weight loads spread over the units (two per unit) instead of four in each of the first three
 #endif
+#ifndef POCR_WINO_NSX
+#define POCR_WINO_NSX 2                // experiment: 1 = one channel tile per wave (half the accumulators and weights: frees registers; results of the other tile are garbage)
+#endif
+#ifndef POCR_WINO_DEPTH
+#define POCR_WINO_DEPTH 1              // chunks the transform's activation loads run ahead of their use (2 needs a second staging set: 32 registers)
+#endif
 #ifndef POCR_WINO_ROT
 #define POCR_WINO_ROT 0                // experiment: workgroup b starts its K loop at chunk (b >> 3) % nchunks (the CUs of an XCD then stream different weights at any time)
 #endif
@@ -79,7 +85,7 @@ inline size_t wino_grid_blocks(const WinoArgs &a) {    // (conv_grid_blocks with
 
 template <int TH, int POOLH, int POOLW, int ACT, bool BN>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WinoArgs a) {
-    constexpr int NS = 2, NROW = TH + 2, NT = 64, WU = 128;
+    constexpr int NS = POCR_WINO_NSX, NROW = TH + 2, NT = 64, WU = 128, DEP = POCR_WINO_DEPTH;
     constexpr int VROW = 8;                             // rows per plane in LDS: every wave transforms "its" row - wave j >= NROW a row of zeros nobody reads - so the loop has no branch
     constexpr int V_U = 4 * VROW * 128;                 // 16-byte units per V buffer: [plane 4][halo row][h | l][lane 64]
     constexpr int PST = 68, M_DW = 4 * TH * 16 * PST;   // epilogue image: [plane][row][pair] x 68 dwords (64 channels + 4: the four pair groups of a wave store to different banks)
@@ -153,8 +159,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #endif
 #endif
     }
-    u32x4 sh[4], sl[4];
-    auto ldX = [&](int chunk) {
+    unsigned long long lat_sum = 0; unsigned lat_n = 0; (void)lat_sum; (void)lat_n;
+    unsigned dummy = 0; (void)dummy;
+    u32x4 sh_[DEP][4], sl_[DEP][4];
+    auto ldX = [&](int chunk, int set = 0) {
+        u32x4 (&sh)[4] = sh_[set], (&sl)[4] = sl_[set];
+#if POCR_WINO_DBG & 8192
+        const unsigned long long ti0 = wall_clock64();   // how long does the ISSUE of the eight loads take (no wait for data)?
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #if POCR_WINO_DBG & 2
@@ -174,14 +186,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #endif
 #endif
         }
+#if POCR_WINO_DBG & 8192
+        asm volatile("" ::: "memory");
+        lat_sum += wall_clock64() - ti0; ++lat_n;
+#endif
+#if POCR_WINO_DBG & 1024
+        {   // how long does this burst of eight loads take from issue to the last byte?  (everything older is drained first)
+            const unsigned long long t0 = wall_clock64();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lat_sum += wall_clock64() - t0; ++lat_n;
+        }
+#endif
     };
     // v_fma_mix reads f16 halves in place (no unpacking) and writes a rounded f16 half in place (no packing).  Plane by plane, so
     // that few values are alive at a time: rebuild 2^11 x of the pixels a plane needs (one op per value), one add per value,
     // two ops per value for its h / l halves, two 16-byte LDS stores per plane.
-    auto xform = [&](int buf) {
+    auto xform = [&](int buf, int set = 0) {
+        u32x4 (&sh)[4] = sh_[set], (&sl)[4] = sl_[set];
         const float s_up = kF16x2Scale, s_dn = 1.0f / kF16x2Scale, s_neg = -kF16x2Scale;
         u32x4 *dst = lds + buf * V_U + wave * 128 + lane;
-#if POCR_WINO_DBG & 1
+#if POCR_WINO_DBG & 2048
+        // the loads are waited for and touched (one xor per register), but what goes to LDS are constants
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { dummy ^= sh[q][0] ^ sl[q][1]; dst[q * VROW * 128] = (u32x4){(unsigned)buf, 1u, 2u, 3u}; dst[q * VROW * 128 + 64] = (u32x4){(unsigned)buf, 5u, 6u, 7u}; }
+#elif POCR_WINO_DBG & 1
 #pragma unroll
         for (int q = 0; q < 4; ++q) { dst[q * VROW * 128] = sh[q]; dst[q * VROW * 128 + 64] = sl[q]; }
 #else
@@ -238,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WinoArgs a) {
     // the scalar offset: no 64-bit address registers per lane
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wfrag), 0, (int)min((size_t)12 * tap_stride * 16, (size_t)0x7fffffff), 0x00020000);
     const int wlane = lane * 16;
-    const int wbase = __builtin_amdgcn_readfirstlane((int)((((size_t)nt * 4 + nh * NS) * WU + (size_t)(k * 3) * tap_stride) * 16));
+    const int wbase = __builtin_amdgcn_readfirstlane((int)((((size_t)nt * 4 + nh * 2) * WU + (size_t)(k * 3) * tap_stride) * 16));
     constexpr int AH = POCR_WINO_AHEAD, RING = AH + 1;
     u32x4 bw[2][3][NS][2], ar[RING][2];
     auto ldW = [&](u32x4 (&dst)[NS][2], int chunk, int dy) {         // (past the last chunk: the last one again - read, never used)
@@ -271,11 +299,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #endif
     };
 
-    ldX(0);
+    ldX(0, 0);
+    if constexpr (DEP == 2) ldX(nchunks > 1 ? 1 : 0, 1);
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) ldW(bw[0][dy], 0, dy);
-    xform(0);
-    ldX(nchunks > 1 ? 1 : 0);
+    xform(0, 0);
+    ldX(min(DEP, nchunks - 1), 0);                     // DEP 1: chunk 1 into the only set; DEP 2: chunk 2 into set 0 (set 1 holds chunk 1)
     __syncthreads();
     POCR_TRACE_STAMP(1);
     // The two waves of a SIMD (w and w + 4: same plane, the two channel halves) run their transform - a burst of ~130 vector
@@ -318,8 +347,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WinoArgs a) {
                     if (j == XF) {
                         // the other buffer: its last readers passed the barrier of the previous chunk.  After the last chunk: a
                         // transform of the clamped re-read that nobody uses (keeps the loads in flight the same in every trip)
-                        xform(buf ^ 1);
-                        ldX(min(chunk + 2, nchunks - 1));
+                        // (two chunks per trip and chunk = c0 + u: the set of chunk + 1 is static, (u + 1) & 1, when c0 is even)
+                        xform(buf ^ 1, DEP == 2 ? (u + 1) & 1 : 0);
+                        ldX(min(chunk + 1 + DEP, nchunks - 1), DEP == 2 ? (u + 1) & 1 : 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -332,6 +362,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WinoArgs a) {
     if (nh == 0) main_loop(std::integral_constant<int, POCR_WINO_XF_A>{});
     else main_loop(std::integral_constant<int, POCR_WINO_XF_B>{});
     POCR_TRACE_STAMP(2);
+#if POCR_WINO_DBG & 2048
+    if (dummy == 0x12345u) a.y[tid] = 1.f;
+#endif
+#if (POCR_WINO_DBG & (1024 | 8192)) && defined(POCR_BF16X3_TRACE)
+    if (lane == 0 && wave == 2 && blockIdx.x < (1u << 15)) { g_conv_trace[blockIdx.x * 8 + 6] = lat_sum; g_conv_trace[blockIdx.x * 8 + 7] = lat_n; }
+#endif
 #if POCR_WINO_DBG & 16
     if (acc[0][0][0] == 123.456f) a.y[tid] = acc[1][1][1] + acc2[2][0][0];
     return;
