@@ -256,6 +256,7 @@ def default_contract_region(engine, eng, crops, n_lines, width, wl, spec, weight
         json.dump({"line_px_height": spec.height, "line_vertical_scale": 1.0, "checkpoint": "weights_peaked.pocrw",
                    "characters": chars[:-1], "net_name": "bench"}, f)
     peaked = PytorchEngineLineOCR(os.path.join(tmp.name, "ocr_peaked.json"), Dev(local_rank), batch_size=wl["batch_size"])
+    peaked.model.fallback_ready(wait=True)
     out["head_x8"] = timed(peaked)
     out["value"] = out["head_x8"]["value"]
     del peaked
@@ -394,6 +395,7 @@ def main():
                    "characters": chars[:-1], "net_name": "bench"}, f)
     engine = PytorchEngineLineOCR(os.path.join(tmp.name, "ocr.json"), Dev(local_rank), batch_size=wl["batch_size"])
     eng = engine.model
+    eng.fallback_ready(wait=True)      # the range guard's bf16x3 engine is built on a thread behind pocr_create: not inside a timed region
     # Launches in flight in the c2 / c4 step loop.  The product's process_lines keeps THREE in flight (pipeline_depth: a ragged
     # stream's launches complete in pairs with two and the host assembles results in between); this loop runs one uniform chunk
     # per step with nothing for the host to assemble, and two is its measured optimum (8.98 against 9.19 ms per step with three,

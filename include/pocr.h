@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define POCR_ABI_VERSION 12
+#define POCR_ABI_VERSION 13
 #define POCR_NUM_SLOTS 4
 
 typedef struct pocr_engine pocr_engine;
@@ -83,12 +83,20 @@ int pocr_conv_split(void);
 /* f16x2 range guard (ABI 11).  The default arithmetic represents an fp32 operand as two f16 planes: fp32's precision, f16's
  * range.  Every kernel that produces such an operand records the largest |value| it wrote; a launch in which one reached
  * 65504 (or was not finite), or in which a whole activation tensor lay below 2^-13, is re-run - same lines, same requests,
- * transparently, at collect time - on the bf16x3 kernels (fp32's range) of a second engine created on first use.  Replaces
+ * transparently, at collect time - on the bf16x3 kernels (fp32's range) of a second engine.  Replaces
  * plain fp32 of pero_ocr/ocr_engine/pytorch_ocr_engine.py:61-69.  Returns the number of launches re-run so far.
  * The sequence-to-sequence engine does the same at pocr_s2s_decode (encoder and decoding loop again on the second engine, ABI 12);
- * POCR_CONV_SPLIT=3 selects bf16x3 for everything.  Memory: the second engine holds its own weights (~90 MB) and, for every slot
- * it has served, activation buffers of that launch's size - only once a launch has left the range. */
+ * POCR_CONV_SPLIT=3 selects bf16x3 for everything.
+ * The second engine is built by a thread that pocr_create starts (ABI 13; ~0.2 s of host work laying the weights out again, off
+ * every caller's path; POCR_FALLBACK_EAGER=0: built by the first launch that needs it, which then waits ~0.1 s for it).
+ * Memory: a second copy of the weights (~90 MB for the recogniser of BASELINE.json) from creation on, and, for every slot the
+ * second engine has served, activation buffers of that launch's size (17.6 MB per line at W_pad 576: 4.5 GB for a 256-line
+ * launch) - those only once a launch of that slot has left the range.  What a re-run costs a caller: tools/fallback_cost.py. */
 int64_t pocr_range_fallbacks(pocr_engine *e);
+/* 1: the fall-back engine is there; 0: its builder is still running (wait != 0: block until it has finished); -1: this engine has
+ * none (bf16x3 / fp32 arithmetic, POCR_FALLBACK_EAGER=0 before the first fall-back, or the build failed: it is then repeated by
+ * the first launch that needs it, where the error is reported). */
+int pocr_fallback_ready(pocr_engine *e, int32_t wait);
 /* Resident BiLSTM recurrence (ABI 12).  One launch per layer hands the hidden state from step to step between co-resident
  * workgroups (torch.nn.LSTM of the reference's model, pero_ocr/ocr_engine/pytorch_ocr_engine.py:66-69); every wait is bounded.  A launch
  * in which a hand-off timed out (not all of a cluster's workgroups became resident: other tenants on the chip) is repeated - same

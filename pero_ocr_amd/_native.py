@@ -14,7 +14,7 @@ import numpy as np
 from .netspec import NetSpec
 
 LIB_NAME = "libpocr_hip.so"
-ABI_VERSION = 12
+ABI_VERSION = 13
 UNIQUE_ID_BYTES = 128
 STAGE_NAMES = ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv8", "conv9",
                "agg", "lstm", "head", "ctc", "total")
@@ -61,6 +61,7 @@ SYMBOLS = {
     "pocr_conv_split": (C.c_int, []),
     "pocr_range_fallbacks": (C.c_int64, [C.c_void_p]),
     "pocr_lstm_timeouts": (C.c_int64, [C.c_void_p]),
+    "pocr_fallback_ready": (C.c_int, [C.c_void_p, C.c_int32]),
     "pocr_set_embed_id": (C.c_int, [C.c_void_p, C.c_int32]),
     "pocr_device_count": (C.c_int, []),
     "pocr_run_batch": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, _f32p, _i32p, _i32p, _i32p]),
@@ -443,6 +444,11 @@ class NativeEngine:
     def lstm_timeouts(self) -> int:
         """Launches repeated on the step kernels after a hand-off timeout of the resident recurrence (include/pocr.h: pocr_lstm_timeouts)."""
         return int(self._lib.pocr_lstm_timeouts(self._h))
+
+    def fallback_ready(self, wait: bool = False) -> int:
+        """1: the bf16x3 fall-back engine of the range guard is there, 0: still being built behind pocr_create (wait=True
+        blocks until it is), -1: this engine has none (include/pocr.h: pocr_fallback_ready)."""
+        return int(self._lib.pocr_fallback_ready(self._h, 1 if wait else 0))
 
     def device_synchronize(self):
         if self._lib.pocr_device_synchronize(self._h):

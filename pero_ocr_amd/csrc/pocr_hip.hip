@@ -565,12 +565,15 @@ struct pocr_engine {
     int lstm_skip = 0, lstm_skip_len = 0;
     int64_t lstm_timeouts = 0;       // launches repeated on the step kernels after a timeout (pocr_lstm_timeouts)
     int lstm_spin_limit = 1 << 22;   // POCR_LSTM_SPIN_LIMIT at creation (tests force the timeout path with a tiny limit)
-    bool warned_nonfinite = false, warned_placement = false;
+    bool warned_nonfinite = false, warned_placement = false, warned_range = false;
     bool fuse12 = false;             // conv1 inside conv2's prologue (P2 only; POCR_NO_FUSE12=1: conv1 as its own launch, its activation in HBM)
     bool conv2_tile8 = false;        // the fused conv1+2 kernel as 8 x 16 tiles, three workgroups per CU (networks without a recurrence)
     DevBuf conv1_w2;                 // conv1's weights as f16x2 fragments (Conv1Args::w1x2)
-    pocr_engine *shadow = nullptr;   // f16x2 range guard: the same network on bf16x3 (fp32's range), created when a launch first leaves f16's range
+    pocr_engine *shadow = nullptr;   // f16x2 range guard: the same network on bf16x3 (fp32's range); built by shadow_builder behind pocr_create
+                                     // (POCR_FALLBACK_EAGER=0: when a launch first leaves f16's range)
     std::mutex shadow_mu;            // creation of / launches on the fall-back engine (decoding loops of several slots run on worker threads)
+    std::thread shadow_builder;      // holds shadow_mu while it builds: a fall-back that comes earlier waits for it instead of building twice
+    std::atomic<int> shadow_state{0};        // 0 not asked for, 1 being built in the background, 2 there, -1 the background build failed (built again on demand, where the error can be reported)
     std::vector<float> weights_host; // the weight blob (kept for the fall-back engine; f16x2 engines only)
     int64_t range_fallbacks = 0;     // launches re-run on the fall-back engine
     bool is_shadow = false;
@@ -1803,10 +1806,33 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         const char *env = getenv("POCR_NO_PAD_SKIP");
         e->pad_skip = !(env && atoi(env) != 0);
     }
-    if (g_f16_weight_overflow.exchange(false))
+    if (conv_split() == 2 && g_f16_weight_overflow.exchange(false))
         return bail(fail("a convolution / projection weight lies outside f16's range (|w| > 65504 or not finite): the default f16x2 "
                          "arithmetic cannot represent it - set POCR_CONV_SPLIT=3 (bf16x3, fp32's range)"));
-    if (conv_split() == 2) e->weights_host.assign(weights, weights + n_floats);      // for the fall-back engine of the range guard
+    if (conv_split() == 2) {
+        e->weights_host.assign(weights, weights + n_floats);      // for the fall-back engine of the range guard
+        // The fall-back engine is built now, on a thread of its own, so that the first launch that needs it does not pay for it
+        // (weights laid out a second time: ~0.2 s of host work, a second copy of the weights in HBM; its activation buffers are
+        // still allocated by the first re-run of each slot).  POCR_FALLBACK_EAGER=0: build it when it is first needed.
+        const char *env = getenv("POCR_FALLBACK_EAGER");
+        if (!(env && atoi(env) == 0)) {
+            e->shadow_state.store(1);
+            e->shadow_builder = std::thread([e] {
+                std::lock_guard<std::mutex> lock(e->shadow_mu);
+                if (e->shadow) return;                  // a launch needed it before this thread ran (ensure_shadow built it)
+                SplitScope scope(3);
+                pocr_engine *sh = nullptr;
+                if (hipSetDevice(e->device) == hipSuccess &&
+                    pocr_create(&e->cfg, e->weights_host.data(), e->weights_host.size(), e->device, &sh) == 0) {
+                    sh->is_shadow = true;
+                    e->shadow = sh;
+                    e->shadow_state.store(2);
+                } else {
+                    e->shadow_state.store(-1);
+                }
+            });
+        }
+    }
     *out = e;
     return 0;
 }
@@ -1816,6 +1842,7 @@ static void comm_release(pocr_engine *e);
 void pocr_destroy(pocr_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    if (e->shadow_builder.joinable()) e->shadow_builder.join();
     (void)locked_device_sync();
     if (e->shadow) { pocr_destroy(e->shadow); e->shadow = nullptr; }
     if (e->comm.active()) comm_release(e);
@@ -2111,15 +2138,30 @@ static int sync_and_guard(pocr_engine *e, int32_t slot);
 // (17.6 MB per staged line at W_pad 576); an engine whose launches stay in range never pays for either
 static int ensure_shadow(pocr_engine *e, int verdict, int which) {
     if (e->weights_host.empty()) return fail("internal error: range guard without a retained weight blob");
+    if (!e->warned_range) {
+        e->warned_range = true;
+        fprintf(stderr, "NOTE: a launch left the range of the default f16x2 arithmetic (%s in activation set %d); it and any later such launch "
+                        "are re-run on bf16x3 (fp32's range, ~0.6x the speed).  POCR_CONV_SPLIT=3 selects bf16x3 for everything.\n",
+                verdict == 1 ? "|x| >= 65504 or not finite" : verdict == 2 ? "a whole tensor below 2^-13" : "POCR_FORCE_RANGE_FALLBACK", which);
+    }
     if (e->shadow) return 0;
-    fprintf(stderr, "NOTE: a launch left the range of the default f16x2 arithmetic (%s in activation set %d); it and any later such launch "
-                    "are re-run on bf16x3 (fp32's range, ~0.6x the speed).  POCR_CONV_SPLIT=3 selects bf16x3 for everything.\n",
-            verdict == 1 ? "|x| >= 65504 or not finite" : "a whole tensor below 2^-13", which);
     pocr_engine *sh = nullptr;
     if (pocr_create(&e->cfg, e->weights_host.data(), e->weights_host.size(), e->device, &sh)) return 1;
     sh->is_shadow = true;
     e->shadow = sh;
+    e->shadow_state.store(2);
     return 0;
+}
+// 1: the fall-back engine exists; 0: it is being built (wait != 0: block until it is there or has failed); -1: this engine has
+// none (not f16x2, or POCR_FALLBACK_EAGER=0 and no launch needed it yet, or the background build failed)
+int pocr_fallback_ready(pocr_engine *e, int32_t wait) {
+    if (!e) return -1;
+    while (wait && e->shadow_state.load() == 1) {           // the builder holds shadow_mu from its first instruction to its last
+        { std::lock_guard<std::mutex> lock(e->shadow_mu); }
+        std::this_thread::yield();
+    }
+    const int st = e->shadow_state.load();
+    return st == 2 ? 1 : st == 1 ? 0 : -1;
 }
 static int run_fallback(pocr_engine *e, int32_t slot, int verdict, int which) {
     Slot &s = e->slot[slot];

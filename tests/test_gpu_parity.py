@@ -1266,13 +1266,59 @@ def test_range_guard_reruns_on_bf16x3():
                 assert np.all(rows < T_i)
                 assert np.allclose(data[lo:hi], dense[i, rows, c], atol=1e-6)
         eng.close()
-    # a network that stays in range never takes the fall-back
+    # a network that stays in range never takes the fall-back; the fall-back engine is nevertheless there - built by a thread
+    # behind pocr_create, so that a launch that does need it does not wait for it (pocr_fallback_ready)
     eng = _native.NativeEngine(spec, netspec.pack_weights(spec, base), 0)
+    assert eng.fallback_ready() in (0, 1)
     eng.slot_stage_ragged(0, pool, offs, widths, [384] * len(crops), 32)
     eng.slot_launch(0, want_logits=True)
     eng.slot_collect(0)
     assert eng.range_fallbacks() == 0
+    assert eng.fallback_ready(wait=True) == 1
     eng.close()
+    eng = _native.NativeEngine(spec, netspec.pack_weights(spec, base), 0)
+    eng.close()                                # closing while the builder may still run: joined, nothing leaks or crashes
+
+
+def test_range_guard_fallback_built_on_demand():
+    """POCR_FALLBACK_EAGER=0: no second engine (and no second copy of the weights) until a launch leaves the range; the first
+    one that does builds it and is re-run as before (a process of its own: the library reads its switches once)."""
+    if _native.conv_split() != 2:
+        pytest.skip("the range guard belongs to the f16x2 arithmetic")
+    code = r"""
+import numpy as np
+from pero_ocr_amd import _native, netspec, synth
+spec = netspec.NetSpec(num_classes=100)
+base = netspec.generate_weights(spec, 5)
+crops = synth.make_crops(5, [200, 96])
+pool = np.concatenate([c.reshape(-1) for c in crops])
+offs = np.array([0, crops[0].size], np.int64)
+widths = np.array([200, 96], np.int32)
+def run(w):
+    eng = _native.NativeEngine(spec, netspec.pack_weights(spec, w), 0)
+    assert eng.fallback_ready(wait=True) == -1
+    eng.slot_stage_ragged(0, pool, offs, widths, [256, 256], 32)
+    eng.slot_launch(0, want_logits=True, want_argmax=True)
+    out = eng.slot_collect(0)
+    state = (eng.range_fallbacks(), eng.fallback_ready())
+    eng.close()
+    return out[0], state
+ref, state = run(base)
+assert state == (0, -1), state
+w = dict(base)
+w["conv4.weight"] = base["conv4.weight"] * np.float32(2.0 ** 17); w["conv4.bias"] = base["conv4.bias"] * np.float32(2.0 ** 17)
+w["conv5.weight"] = base["conv5.weight"] * np.float32(2.0 ** -17)
+got, state = run(w)
+assert state == (1, 1), state
+err = float(np.max(np.abs(got - ref)))
+assert err < 1e-3, err
+print("on demand ok", err)
+"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=dict(os.environ, POCR_FALLBACK_EAGER="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "on demand ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_resident_recurrence_equals_the_step_kernels(monkeypatch):
