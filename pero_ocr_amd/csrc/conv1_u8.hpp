@@ -31,7 +31,7 @@ struct Conv1Args {
     const int64_t *out_off;
     int32_t H, n_ptiles;
     int32_t src_h;               // rows the crops really have (0: = H); rows [src_h, H) are zero padding (layout network pages)
-    const void *w1x2;            // F16X2: [cout/16 = 4][plane h, l][lane] x 8 f16: k = 8 (lane >> 4) + j, cout = 16 s + (lane & 15), zero for k >= 27
+    const void *w1x2;            // F16X2: [cout/16 = 4][plane h, l][lane] x 8 f16: k = 8 (lane >> 4) + j, cout = 16 s + (lane & 15); k = 27: the bias (its input is the constant 1), zero for k > 27
     unsigned *range_max;         // f16x2 range guard (conv_igemm.hpp: range_publish) or NULL
 };
 
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
             v = a.lut[src[((size_t)hi * ld.width + xc) * 3 + c]];
         halo[e] = v;
     }
-    if (tid < 4) halo[NH + tid] = 0.f;
+    if (tid < 4) halo[NH + tid] = (F16X2 && tid == 0) ? 1.f : 0.f;        // the tail conv1_x_frag expects: the bias slot's constant 1, zeros
     // weights of this wave's 16 output channels and the per-lane halo offsets of its MFMA k slots
     f32x4 wb[2];
     int koff[2][4];
@@ -77,13 +77,12 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
         }
     }
     u32x4 xwh = {0u, 0u, 0u, 0u}, xwl = {0u, 0u, 0u, 0u};
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    int koff8[8];
+    Conv1Slots koff8 = {};
     if constexpr (F16X2) {        // (conv_bf16x3.hpp: conv1_mma_f16x2 - weights are the A operand, a lane gets channels 16 wave + 4 kq + r of pixel li)
         xwh = reinterpret_cast<const u32x4 *>(a.w1x2)[(wave * 2 + 0) * 64 + lane];
         xwl = reinterpret_cast<const u32x4 *>(a.w1x2)[(wave * 2 + 1) * 64 + lane];
-        bias4 = *reinterpret_cast<const f32x4 *>(a.bias + 16 * wave + 4 * kq);
-        conv1_koff(koff8, kq, HW);
+        // (the bias rides in k slot 27 of the weights: conv_bf16x3.hpp, conv1_koff)
+        conv1_koff(koff8, kq, HW, NH);
     }
     __syncthreads();
     const float bias = a.bias[wave * 16 + li];
@@ -97,13 +96,11 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
             if constexpr (F16X2) {
                 u32x4 xh, xl;
-                conv1_x_frag(halo, base, koff8, NH, xh, xl);
+                conv1_x_frag(halo, base, koff8, NH, true, xh, xl);
                 const f32x4 d = conv1_mma_f16x2(xh, xl, xwh, xwl);
                 const int ho = h0 + th, wc = w0 + mw * 16 + li;
                 if (ho >= a.H || wc >= Wp) continue;
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float t = d[r] + bias4[r]; v[r] = t > 0.f ? t : 0.f; range_note(rmax, v[r]); }
+                const f32x4 v = conv1_relu_note(d, rmax);
                 if constexpr (P2OUT) {
                     u32x2 hh, ll;
                     split2_quad(v, hh, ll);

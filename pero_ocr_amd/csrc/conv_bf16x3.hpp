@@ -48,6 +48,12 @@
 #ifndef POCR_STA_TAP
 #define POCR_STA_TAP (NTAP / 2)        // tap after which the next chunk's halo tile (requested at tap 0) is written to the other LDS buffer
 #endif
+#ifndef POCR_CONV_STAGGER
+#define POCR_CONV_STAGGER 0          // experiment: units of 8128 cycles by which the second workgroup of a CU starts late (first dispatch round only)
+#endif
+#ifndef POCR_CONV_STAGGER_BLOCKS
+#define POCR_CONV_STAGGER_BLOCKS 512
+#endif
 #ifdef POCR_BF16X3_TRACE               // tools/conv_ablate.hip: per-workgroup phase stamps (100 MHz wall clock) + where it ran
 __device__ unsigned long long g_conv_trace[1 << 18];
 #define POCR_TRACE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < (1u << 15)) g_conv_trace[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
@@ -124,6 +130,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define POCR_MFMA_F16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
 constexpr float kF16x2Scale = 2048.0f;
 
+// x -> (h, l): h = f16(x), l = f16((x - h) * 2^11), round to nearest even.  (Tried: l = f16(fma(h, -2^11, 2^11 x)) on v_fma_mixlo /
+// v_fma_mixhi in inline asm, 8 instead of 12 vector instructions per four values, bit-identical in isolation - but the compiler does
+// not track the sub-dword write hazard of those instructions inside an asm block: next to stores the results were right, an MFMA that
+// consumed them at once read stale low planes (the recurrence lost its l plane); written in C++ the compiler picks v_pk_fma_f32 and
+// the same 12 instructions.  No measurable time in any layer either way: dropped.)
 __device__ __forceinline__ void split2_quad(const f32x4 p, u32x2 &hi, u32x2 &lo) {
     const f32x2 a = {p[0], p[1]}, b = {p[2], p[3]};
     const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);       // round to nearest even
@@ -151,25 +162,51 @@ __device__ __forceinline__ size_t p2_channel_bytes(int c) { return (size_t)(c >>
 // are three MFMAs (w_h x_l, w_h x_h, w_l x_h) instead of eight fp32 ones.  The WEIGHTS are the MFMA's A operand (rows =
 // channels) and the pixels its B operand, so a lane ends up with four consecutive channels 4 (lane >> 4) + r of ONE pixel
 // (lane & 15) - the shape the NHWC / P2 stores want, no transpose.  `patch` holds the normalised input (fp32, [row][col][c],
-// PW pixels per row), `base` the element of tap (0, 0) / channel 0 of this lane's pixel, koff[j] the offset of the lane's
-// k slot 8 (lane >> 4) + j (-1: k >= 27 -> the zero at zero_idx).  Shared by conv1_u8_kernel and by conv2's fused prologue
+// PW pixels per row), `base` the element of tap (0, 0) / channel 0 of this lane's pixel, Conv1Slots the lane's
+// k slots 8 (lane >> 4) + j.  Shared by conv1_u8_kernel and by conv2's fused prologue
 // (conv3x3_bf16x3_kernel FUSE1), which therefore give the same bits.
-__device__ __forceinline__ void conv1_koff(int (&koff)[8], int kq, int PW) {
+// k slot 27 carries the BIAS: its input is the constant 1 and its weight the bias (split like a weight), so the MFMAs add it and
+// the epilogue does not; slots 28..31 have zero weights.  Patch layout behind the n_patch pixels' values: [one : 1.0][zeros].
+// Index of slot k = 8 kq + j of a pixel whose tap (0,0) element is patch[base]: base * sel[j] + off[j] (one v_mad per slot):
+// k < 27: sel 1, off = the tap's offset; k = 27: sel 0, off = tail (the constant 1); k > 27: sel 0, off = tail + 1 (a zero).
+constexpr int kConv1Tail = 4;                           // floats behind the patch: [0] = 1.0, [1..3] = 0
+struct Conv1Slots { int sel[8], off[8]; bool has_one; };
+__device__ __forceinline__ void conv1_koff(Conv1Slots &ks, int kq, int PW, int tail) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = 8 * kq + j, tap = k / 3, c = k - 3 * tap;
-        koff[j] = k < 27 ? ((tap / 3) * PW + tap % 3) * 3 + c : -1;
+        ks.sel[j] = k < 27 ? 1 : 0;
+        ks.off[j] = k < 27 ? ((tap / 3) * PW + tap % 3) * 3 + c : k == 27 ? tail : tail + 1;
     }
+    ks.has_one = kq == 3;                               // (k = 27 is slot j = 3 of the lanes with kq = 3)
 }
-__device__ __forceinline__ void conv1_x_frag(const float *patch, int base, const int (&koff)[8], int zero_idx, u32x4 &xh, u32x4 &xl) {
+// for a pixel whose output must be ZERO (outside the image: the consumer's padding) pass one = false and a base whose 3 x 3 x 3
+// neighbourhood is zeros: its inputs and its bias slot are then zero, and so is what the MFMAs return
+__device__ __forceinline__ void conv1_x_frag(const float *patch, int base, const Conv1Slots &ks, int tail, bool one, u32x4 &xh, u32x4 &xl) {
     float x[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = patch[koff[j] >= 0 ? base + koff[j] : zero_idx];
+    for (int j = 0; j < 8; ++j) {
+        int idx = base * ks.sel[j] + ks.off[j];
+        if (j == 3) idx = (ks.has_one && !one) ? tail + 1 : idx;
+        x[j] = patch[idx];
+    }
     u32x2 h0, l0, h1, l1;
     split2_quad((f32x4){x[0], x[1], x[2], x[3]}, h0, l0);
     split2_quad((f32x4){x[4], x[5], x[6], x[7]}, h1, l1);
     xh = (u32x4){h0[0], h0[1], h1[0], h1[1]};
     xl = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+}
+// ReLU of four conv1 outputs (bias already inside) + the f16x2 range note of non-negative values: their bit patterns order like
+// signed integers (-0 = INT_MIN never wins; v_max_f32 turns a NaN into 0 as the compare-and-select before did)
+__device__ __forceinline__ f32x4 conv1_relu_note(const f32x4 d, unsigned &m) {
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaxf(d[r], 0.f);
+    int mm = (int)m;
+    mm = max(max(mm, __builtin_bit_cast(int, v[0])), __builtin_bit_cast(int, v[1]));
+    mm = max(max(mm, __builtin_bit_cast(int, v[2])), __builtin_bit_cast(int, v[3]));
+    m = (unsigned)mm;
+    return v;
 }
 __device__ __forceinline__ f32x4 conv1_mma_f16x2(u32x4 xh, u32x4 xl, u32x4 wh, u32x4 wl) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -245,7 +282,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     constexpr bool GEMM2 = !BDIR && NTAP == 1 && SPL == 2 && POCR_GEMM_PIPE && POCR_BF16X3_DBG == 0;
     constexpr int A_BUFS = (BDIR || GEMM2) ? 2 : 1;
     constexpr int F1_PW = HW + 2, F1_N = (HH + 2) * F1_PW * 3;            // FUSE1: conv1's input patch ([row][col][c] floats) behind the A buffers
-    constexpr int F1_U = FUSE1 ? (F1_N + 4 + 3) / 4 : 0;
+    constexpr int F1_Z = kConv1Tail + (2 * F1_PW + 3) * 3;            // the patch's tail + a zero 3 x 3 x 3 neighbourhood (conv1_x_frag)
+    constexpr int F1_U = FUSE1 ? (F1_N + F1_Z + 3) / 4 : 0;
     __shared__ u32x4 lds[(BDIR ? 2 * A_U : A_BUFS * A_U + 2 * B_F4) + F1_U];      // one scalar type (unsigned) for every access: no type punning
     u32x4 *ldsA = lds;
     u32x4 *ldsB = lds + A_BUFS * A_U;
@@ -253,6 +291,14 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     const int wm = wave % WM, wn = wave / WM;
 
     POCR_TRACE_STAMP(0);
+#if POCR_CONV_STAGGER
+    {   // (experiment) de-phase the workgroups that share a CU: the one whose LDS allocation does not start at 0 begins late
+        unsigned la;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(la));
+        if ((la & 0xffu) != 0u && blockIdx.x < POCR_CONV_STAGGER_BLOCKS)
+            for (int q = 0; q < POCR_CONV_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 #ifdef POCR_BF16X3_TRACE
     if (threadIdx.x == 0 && blockIdx.x < (1u << 15)) {
         unsigned hw, xcc;
@@ -456,14 +502,12 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             const unsigned char got = *(pok[it] ? src + ((size_t)hi * ld.width + xc) * 3 + c : a.f1_crops);      // (the pool's first byte always exists)
             pb[it] = pok[it] ? got : (unsigned char)0;
         }
-        // conv1's weights (A operand) of all four channel tiles, its bias for this lane's channels 16 nt + 4 kq + r
+        // conv1's weights (A operand) of all four channel tiles (its bias rides in k slot 27: conv1_koff)
         u32x4 xwh[4], xwl[4];
-        f32x4 bias1[4];
 #pragma unroll
         for (int nt1 = 0; nt1 < 4; ++nt1) {
             xwh[nt1] = reinterpret_cast<const u32x4 *>(a.f1_w)[(nt1 * 2 + 0) * 64 + lane];
             xwl[nt1] = reinterpret_cast<const u32x4 *>(a.f1_w)[(nt1 * 2 + 1) * 64 + lane];
-            bias1[nt1] = *reinterpret_cast<const f32x4 *>(a.f1_bias + 16 * nt1 + 4 * kq);
         }
 #pragma unroll
         for (int it = 0; it < F1_IT; ++it) {
@@ -471,9 +515,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             const float v = a.f1_lut[pb[it]];            // (pb = 0 outside the crop, and entry 0 of the table is 0 / 255 = 0)
             if (e < F1_N) patch[e] = v;
         }
-        if (tid < 4) patch[F1_N + tid] = 0.f;
-        int koff8[8];
-        conv1_koff(koff8, kq, F1_PW);
+        // behind the patch: the constant 1 of the bias slot, then zeros - among them a whole 3 x 3 x 3 neighbourhood for the
+        // pixels outside the image (conv2's zero padding: their inputs AND their bias slot are zero, so the MFMAs give 0)
+        if (tid < F1_Z) patch[F1_N + tid] = tid == 0 ? 1.f : 0.f;
+        Conv1Slots koff8;
+        conv1_koff(koff8, kq, F1_PW, F1_N);
         unsigned f1max = 0u;                            // range guard of conv1's activation (never stored in this mode)
         __syncthreads();
         // the waves share the pixel tiles (16 halo pixels each), every wave computes all 64 channels of its tiles
@@ -482,16 +528,13 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             const int mt = wave + it * NWAVE;
             if (mt >= NPPAD / 16) break;
             const int px = mt * 16 + li, pa = min(px, NP - 1);
-            u32x4 xh, xl;
-            conv1_x_frag(patch, ((pa / HW) * F1_PW + pa % HW) * 3, koff8, F1_N, xh, xl);
             const int hi = h0 - 1 + pa / HW, wi = w0 - 1 + pa % HW;
             const bool inside = px < NP && hi >= 0 && hi < a.H && wi >= 0 && wi < Win;      // outside the image: conv2's zero padding
+            u32x4 xh, xl;
+            conv1_x_frag(patch, inside ? ((pa / HW) * F1_PW + pa % HW) * 3 : F1_N + kConv1Tail, koff8, F1_N, inside, xh, xl);
 #pragma unroll
             for (int nt1 = 0; nt1 < 4; ++nt1) {
-                const f32x4 d = conv1_mma_f16x2(xh, xl, xwh[nt1], xwl[nt1]);
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float t = d[r] + bias1[nt1][r]; v[r] = (inside && t > 0.f) ? t : 0.f; range_note(f1max, v[r]); }
+                const f32x4 v = conv1_relu_note(conv1_mma_f16x2(xh, xl, xwh[nt1], xwl[nt1]), f1max);
                 u32x2 hh, ll;
                 split2_quad(v, hh, ll);
                 // channels 16 nt1 + 4 kq .. + 3: chunk nt1 >> 1, octet 2 (nt1 & 1) + (kq >> 1), half kq & 1

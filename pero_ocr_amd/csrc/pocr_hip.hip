@@ -1618,9 +1618,10 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const int k = 8 * (lane >> 4) + j, co = 16 * sgrp + (lane & 15);
-                        if (k >= 27 || co >= L.cout) continue;
+                        if (k > 27 || co >= L.cout) continue;
                         uint16_t pl[2];
-                        split_weight(w[((size_t)co * 3 + k % 3) * 9 + k / 3], 2, pl);
+                        // k = 27: the bias, multiplied by the constant 1 the kernels put into that slot (conv_bf16x3.hpp: conv1_koff)
+                        split_weight(k == 27 ? b[co] : w[((size_t)co * 3 + k % 3) * 9 + k / 3], 2, pl);
                         w2[(((size_t)sgrp * 2 + 0) * 64 + lane) * 8 + j] = pl[0];
                         w2[(((size_t)sgrp * 2 + 1) * 64 + lane) * 8 + j] = pl[1];
                     }
