@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
         const int hi = h0 - 1 + hr, wi = w0 - 1 + wc, xc = wi - ld.pad_left;
         float v = 0.f;
         if (hi >= 0 && hi < src_h && wi >= 0 && wi < Wp && xc >= 0 && xc < ld.width)
-            v = a.lut[src[((size_t)hi * ld.width + xc) * 3 + c]];
+            v = F16X2 ? (float)src[((size_t)hi * ld.width + xc) * 3 + c] * (1.0f / 256.0f)      // byte / 256: the 256 / 255 sits in the f16x2 weights (conv_bf16x3.hpp: conv1_x_frag)
+                      : a.lut[src[((size_t)hi * ld.width + xc) * 3 + c]];
         halo[e] = v;
     }
     if (tid < 4) halo[NH + tid] = (F16X2 && tid == 0) ? 1.f : 0.f;        // the tail conv1_x_frag expects: the bias slot's constant 1, zeros
@@ -95,9 +96,9 @@ __global__ __launch_bounds__(256) void conv1_u8_kernel(Conv1Args a) {
             const int base = (th * HW + mw * 16 + li) * 3;     // halo element of tap (0,0), channel 0 for this lane's pixel
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
             if constexpr (F16X2) {
-                u32x4 xh, xl;
-                conv1_x_frag(halo, base, koff8, NH, true, xh, xl);
-                const f32x4 d = conv1_mma_f16x2(xh, xl, xwh, xwl);
+                u32x4 xh;
+                conv1_x_frag(halo, base, koff8, NH, true, xh);
+                const f32x4 d = conv1_mma_f16x2(xh, xwh, xwl);
                 const int ho = h0 + th, wc = w0 + mw * 16 + li;
                 if (ho >= a.H || wc >= Wp) continue;
                 const f32x4 v = conv1_relu_note(d, rmax);

@@ -48,6 +48,9 @@
 #ifndef POCR_STA_TAP
 #define POCR_STA_TAP (NTAP / 2)        // tap after which the next chunk's halo tile (requested at tap 0) is written to the other LDS buffer
 #endif
+#ifndef POCR_F1_HACK
+#define POCR_F1_HACK 0               // experiments on the fused conv1+2 kernel (wrong results): 8 no conv1 prologue, 16 no epilogue
+#endif
 #ifndef POCR_CONV_STAGGER
 #define POCR_CONV_STAGGER 0          // experiment: units of 8128 cycles by which the second workgroup of a CU starts late (first dispatch round only)
 #endif
@@ -182,7 +185,7 @@ __device__ __forceinline__ void conv1_koff(Conv1Slots &ks, int kq, int PW, int t
 }
 // for a pixel whose output must be ZERO (outside the image: the consumer's padding) pass one = false and a base whose 3 x 3 x 3
 // neighbourhood is zeros: its inputs and its bias slot are then zero, and so is what the MFMAs return
-__device__ __forceinline__ void conv1_x_frag(const float *patch, int base, const Conv1Slots &ks, int tail, bool one, u32x4 &xh, u32x4 &xl) {
+__device__ __forceinline__ void conv1_x_frag(const float *patch, int base, const Conv1Slots &ks, int tail, bool one, u32x4 &xh) {
     float x[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -190,11 +193,11 @@ __device__ __forceinline__ void conv1_x_frag(const float *patch, int base, const
         if (j == 3) idx = (ks.has_one && !one) ? tail + 1 : idx;
         x[j] = patch[idx];
     }
-    u32x2 h0, l0, h1, l1;
-    split2_quad((f32x4){x[0], x[1], x[2], x[3]}, h0, l0);
-    split2_quad((f32x4){x[4], x[5], x[6], x[7]}, h1, l1);
-    xh = (u32x4){h0[0], h0[1], h1[0], h1[1]};
-    xl = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+    // the inputs are the PIXEL BYTES / 256 (and the constant 1): exact in f16, so there is no low plane to make - the 256 / 255 that
+    // is missing from the reference's float32(x) / 255 (pytorch_ocr_engine.py:61) sits in the weights (pocr_create)
+    const f16x2 p0 = __builtin_convertvector((f32x2){x[0], x[1]}, f16x2), p1 = __builtin_convertvector((f32x2){x[2], x[3]}, f16x2);
+    const f16x2 p2 = __builtin_convertvector((f32x2){x[4], x[5]}, f16x2), p3 = __builtin_convertvector((f32x2){x[6], x[7]}, f16x2);
+    xh = (u32x4){__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1), __builtin_bit_cast(unsigned, p2), __builtin_bit_cast(unsigned, p3)};
 }
 // ReLU of four conv1 outputs (bias already inside) + the f16x2 range note of non-negative values: their bit patterns order like
 // signed integers (-0 = INT_MIN never wins; v_max_f32 turns a NaN into 0 as the compare-and-select before did)
@@ -208,11 +211,10 @@ __device__ __forceinline__ f32x4 conv1_relu_note(const f32x4 d, unsigned &m) {
     m = (unsigned)mm;
     return v;
 }
-__device__ __forceinline__ f32x4 conv1_mma_f16x2(u32x4 xh, u32x4 xl, u32x4 wh, u32x4 wl) {
+__device__ __forceinline__ f32x4 conv1_mma_f16x2(u32x4 xh, u32x4 wh, u32x4 wl) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc2 = POCR_MFMA_F16(wh, xl, z);
+    const f32x4 acc2 = POCR_MFMA_F16(wl, xh, z);
     const f32x4 acc = POCR_MFMA_F16(wh, xh, z);
-    acc2 = POCR_MFMA_F16(wl, xh, acc2);
     f32x4 d;
 #pragma unroll
     for (int r = 0; r < 4; ++r) d[r] = __builtin_fmaf(acc2[r], 1.0f / kF16x2Scale, acc[r]);
@@ -488,19 +490,18 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         const LineDesc ld = a.f1_lines[img];
         const uint8_t *src = a.f1_crops + ld.offset;
         const int src_h = a.f1_src_h > 0 ? a.f1_src_h : a.H;
-        // conv1's input patch, as conv1_u8_kernel stages it, one more ring of pixels (all byte loads first, then the table look-ups)
+        // conv1's input patch, as conv1_u8_kernel stages it, one more ring of pixels: the crop's BYTES as floats (conv1_x_frag)
         constexpr int F1_IT = (F1_N + NTHR - 1) / NTHR;
         unsigned char pb[F1_IT];
-        bool pok[F1_IT];
 #pragma unroll
         for (int it = 0; it < F1_IT; ++it) {
             const int e = tid + it * NTHR, c = e % 3, p = e / 3, wc = p % F1_PW, hr = p / F1_PW;
             const int hi = h0 - 2 + hr, wi = w0 - 2 + wc, xc = wi - ld.pad_left;
-            pok[it] = e < F1_N && hi >= 0 && hi < src_h && wi >= 0 && wi < Win && xc >= 0 && xc < ld.width;
+            const bool pok = e < F1_N && hi >= 0 && hi < src_h && wi >= 0 && wi < Win && xc >= 0 && xc < ld.width;
             // (unconditional loads from a clamped address, then a select: a conditional load is a branch, and the branches put one
-            // memory round trip after the other in front of every tile - the table look-ups below cost four of them)
-            const unsigned char got = *(pok[it] ? src + ((size_t)hi * ld.width + xc) * 3 + c : a.f1_crops);      // (the pool's first byte always exists)
-            pb[it] = pok[it] ? got : (unsigned char)0;
+            // memory round trip after the other in front of every tile)
+            const unsigned char got = *(pok ? src + ((size_t)hi * ld.width + xc) * 3 + c : a.f1_crops);      // (the pool's first byte always exists)
+            pb[it] = pok ? got : (unsigned char)0;
         }
         // conv1's weights (A operand) of all four channel tiles (its bias rides in k slot 27: conv1_koff)
         u32x4 xwh[4], xwl[4];
@@ -512,8 +513,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int it = 0; it < F1_IT; ++it) {
             const int e = tid + it * NTHR;
-            const float v = a.f1_lut[pb[it]];            // (pb = 0 outside the crop, and entry 0 of the table is 0 / 255 = 0)
-            if (e < F1_N) patch[e] = v;
+            if (e < F1_N) patch[e] = (float)pb[it] * (1.0f / 256.0f);     // (0 outside the crop)
         }
         // behind the patch: the constant 1 of the bias slot, then zeros - among them a whole 3 x 3 x 3 neighbourhood for the
         // pixels outside the image (conv2's zero padding: their inputs AND their bias slot are zero, so the MFMAs give 0)
@@ -527,14 +527,17 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         for (int it = 0; it < (NPPAD / 16 + NWAVE - 1) / NWAVE; ++it) {      // (unrolled: the iterations are independent chains gather -> MFMA -> split -> LDS)
             const int mt = wave + it * NWAVE;
             if (mt >= NPPAD / 16) break;
+#if POCR_F1_HACK & 8
+            if (a.n >= 0) break;                        // (experiment: no conv1 at all)
+#endif
             const int px = mt * 16 + li, pa = min(px, NP - 1);
             const int hi = h0 - 1 + pa / HW, wi = w0 - 1 + pa % HW;
             const bool inside = px < NP && hi >= 0 && hi < a.H && wi >= 0 && wi < Win;      // outside the image: conv2's zero padding
-            u32x4 xh, xl;
-            conv1_x_frag(patch, inside ? ((pa / HW) * F1_PW + pa % HW) * 3 : F1_N + kConv1Tail, koff8, F1_N, inside, xh, xl);
+            u32x4 xh;
+            conv1_x_frag(patch, inside ? ((pa / HW) * F1_PW + pa % HW) * 3 : F1_N + kConv1Tail, koff8, F1_N, inside, xh);
 #pragma unroll
             for (int nt1 = 0; nt1 < 4; ++nt1) {
-                const f32x4 v = conv1_relu_note(conv1_mma_f16x2(xh, xl, xwh[nt1], xwl[nt1]), f1max);
+                const f32x4 v = conv1_relu_note(conv1_mma_f16x2(xh, xwh[nt1], xwl[nt1]), f1max);
                 u32x2 hh, ll;
                 split2_quad(v, hh, ll);
                 // channels 16 nt1 + 4 kq .. + 3: chunk nt1 >> 1, octet 2 (nt1 & 1) + (kq >> 1), half kq & 1
@@ -831,6 +834,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             else acc[m][n] += acc2[m][n];
         }
     // ---- epilogue (identical to conv_igemm_kernel: same D layout)
+#if POCR_F1_HACK & 16
+    if (FUSE1 && a.n >= 0) return;                      // (experiment: no epilogue)
+#endif
     const int Wo = Win, Wout = Wo / POOLW;
     unsigned rmax = 0u;                                 // f16x2 range guard (conv_igemm.hpp: range_note)
 #pragma unroll

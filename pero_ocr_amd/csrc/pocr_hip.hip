@@ -1620,8 +1620,11 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
                         const int k = 8 * (lane >> 4) + j, co = 16 * sgrp + (lane & 15);
                         if (k > 27 || co >= L.cout) continue;
                         uint16_t pl[2];
-                        // k = 27: the bias, multiplied by the constant 1 the kernels put into that slot (conv_bf16x3.hpp: conv1_koff)
-                        split_weight(k == 27 ? b[co] : w[((size_t)co * 3 + k % 3) * 9 + k / 3], 2, pl);
+                        // k = 27: the bias, multiplied by the constant 1 the kernels put into that slot (conv_bf16x3.hpp: conv1_koff);
+                        // k < 27: w * 256 / 255 - the kernels feed pixel BYTE / 256 (exact in f16: no low plane of the input, two
+                        // MFMAs instead of three, no table look-up), so what is missing from the reference's float32(x) / 255.0
+                        // (pytorch_ocr_engine.py:61) moves into the weight: w * fl(k / 255) against fl(w / 255) * k, 2^-23 relative apart
+                        split_weight(k == 27 ? b[co] : w[((size_t)co * 3 + k % 3) * 9 + k / 3] / 255.0f * 256.0f, 2, pl);
                         w2[(((size_t)sgrp * 2 + 0) * 64 + lane) * 8 + j] = pl[0];
                         w2[(((size_t)sgrp * 2 + 1) * 64 + lane) * 8 + j] = pl[1];
                     }
