@@ -48,8 +48,8 @@
 #ifndef POCR_STA_TAP
 #define POCR_STA_TAP (NTAP / 2)        // tap after which the next chunk's halo tile (requested at tap 0) is written to the other LDS buffer
 #endif
-#ifndef POCR_F1_HACK
-#define POCR_F1_HACK 0               // experiments on the fused conv1+2 kernel (wrong results): 8 no conv1 prologue, 16 no epilogue
+#ifndef POCR_EPI_T
+#define POCR_EPI_T 1                 // f16x2 kernels that write P2: weights as the MFMA's A operand, so a lane ends up with four consecutive channels of one pixel (the epilogue below "TR")
 #endif
 #ifndef POCR_CONV_STAGGER
 #define POCR_CONV_STAGGER 0          // experiment: units of 8128 cycles by which the second workgroup of a CU starts late (first dispatch round only)
@@ -221,6 +221,19 @@ __device__ __forceinline__ f32x4 conv1_mma_f16x2(u32x4 xh, u32x4 wh, u32x4 wl) {
     return d;
 }
 
+// One product block of the convolution loops: `act` the pixels' fragment, `w` the weights'.  The two operands of
+// v_mfma_f32_16x16x32_f16 have the same fragment layout, so which of them is "A" only decides the layout of the RESULT:
+// TR = false: D[pixel 4 kq + r][channel li] (a lane holds four pixels of one channel), TR = true: D[channel 4 kq + r][pixel li]
+// (four consecutive channels of one pixel = one 8-byte piece of each P2 plane: no transpose in front of the stores).
+constexpr int conv_stage_units(int TH, int TW, int POOLH, int POOLW, int NT) {      // 16-byte units of conv_epilogue_staged's staging area
+    return ((TH / POOLH) * (TW / POOLW) * (NT * 4 + 32) + 15) / 16;
+}
+template <bool TR>
+__device__ __forceinline__ f32x4 mfma_conv_f16(u32x4 act, u32x4 w, f32x4 c) {
+    if constexpr (TR) return POCR_MFMA_F16(w, act, c);
+    else return POCR_MFMA_F16(act, w, c);
+}
+
 // Issue-order template for the scheduler (LDS-weights loop): the G operand reads of a step spread evenly between its TOT MFMAs.
 template <int G, int TOT, int... I>
 __device__ __forceinline__ void sched_template_lds(std::integer_sequence<int, I...>) {
@@ -237,6 +250,90 @@ __device__ __forceinline__ void sched_group_dir() {
 template <int G, int TOT, int NV, int... I>
 __device__ __forceinline__ void sched_template_dir(std::integer_sequence<int, I...>) {
     (sched_group_dir<G, TOT, NV, I>(), ...);
+}
+
+// ---- The epilogue of the kernels whose MFMAs leave the result as [channel][pixel] (mfma_conv_f16<true>): lane (li, kq) holds
+// channels 4 kq .. + 3 of pixel li of every 16-pixel tile, i.e. 8-byte pieces of each P2 plane.  Stored from there, a wave
+// instruction writes sixteen 32-byte segments of sixteen different lines - and the partial-line writes, not the bytes, were what
+// the stores cost (the same bytes as full lines: conv3 -13 %, conv5 -9 %, the others -2..3 %, tools/conv_wino_bench.hip).  So the
+// tile's output is put together in LDS (`stage`: the A buffers, free behind the main loop; a pixel = its NT channels in P2 order + 32
+// bytes of padding, so that the 8-byte writes of a wave fall on all banks) and leaves as whole 128-byte lines, 16 bytes per lane.
+// bias_p / scale_p / shift_p: the channel tile's NT constants (LDS or global); yline: the line's output image; TWO barriers inside.
+template <int TH, int MWW, int NS, int WM, int POOLH, int POOLW, int ACT, bool BN, int NT, int TW>
+__device__ __forceinline__ void conv_epilogue_staged(const f32x4 (&acc)[TH * MWW][NS], const f32x4 (&acc2)[TH * MWW][NS], const float *bias_p,
+                                                     const float *scale_p, const float *shift_p, char *stage, float *yline, int h0, int w0, int Win,
+                                                     int Ho, int out_stride, int nt, unsigned &rmax) {
+    constexpr int NTHR = 256, TWO = TW / POOLW, NPX = (TH / POOLH) * TWO, UPP = NT / 4, PBP = NT * 4 + 32;
+    constexpr unsigned kOut = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int wm = wave % WM, wn = wave / WM;
+    (void)lane;
+        const int Wo = Win, Wout = Wo / POOLW;
+        const unsigned pix_bytes = (unsigned)out_stride * 4u;
+        const size_t img_bytes = (size_t)(Ho / POOLH) * Wout * pix_bytes;
+        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yline, 0, (int)(img_bytes < kOut ? img_bytes : kOut - 1), 0x00020000);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const int cgl = wn * NS + n;                              // 16-channel group inside the channel tile
+            const int cl = cgl * 16 + 4 * kq;                         // this lane's channels cl + r
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(bias_p + cl);
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (BN) { sc = *reinterpret_cast<const f32x4 *>(scale_p + cl); sh = *reinterpret_cast<const f32x4 *>(shift_p + cl); }
+            // byte of the lane's h piece inside a staged pixel: chunk cgl >> 1, half (cgl & 1) * 32, + 8 kq; the l piece 64 further
+            const unsigned piece = (unsigned)(cgl >> 1) * 128u + (unsigned)(cgl & 1) * 32u + (unsigned)kq * 8u;
+#pragma unroll
+            for (int th = 0; th < TH; th += POOLH) {
+#pragma unroll
+                for (int mw = 0; mw < MWW; ++mw) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t = apply_act(acc[th * MWW + mw][n][r] + acc2[th * MWW + mw][n][r] * (1.0f / kF16x2Scale) + bias[r], ACT);
+                        if constexpr (BN) t = t * sc[r] + sh[r];
+                        if constexpr (POOLH == 2) {
+                            float u2 = apply_act(acc[(th + 1) * MWW + mw][n][r] + acc2[(th + 1) * MWW + mw][n][r] * (1.0f / kF16x2Scale) + bias[r], ACT);
+                            if constexpr (BN) u2 = u2 * sc[r] + sh[r];
+                            t = fmaxf(t, u2);
+                        }
+                        if constexpr (POOLW == 2)          // the other pixel of the pair sits in the neighbouring lane
+                            t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true)));
+                        v[r] = t;
+                    }
+                    if constexpr (ACT == ACT_RELU && !BN) {    // non-negative: bit patterns order like signed integers
+                        int mm = (int)rmax;
+                        mm = max(max(mm, __builtin_bit_cast(int, v[0])), __builtin_bit_cast(int, v[1]));
+                        mm = max(max(mm, __builtin_bit_cast(int, v[2])), __builtin_bit_cast(int, v[3]));
+                        rmax = (unsigned)mm;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) range_note(rmax, v[r]);
+                    }
+                    u32x2 hh, ll;
+                    split2_quad(v, hh, ll);
+                    // staged pixel (row th / POOLH, column ((wm MWW + mw) 16 + li) / POOLW)
+                    const int sp = (th / POOLH) * TWO + ((wm * MWW + mw) * 16 + li) / POOLW;
+                    if (POOLW == 1 || (li & 1) == 0) {
+                        u32x2 *d = reinterpret_cast<u32x2 *>(stage + (unsigned)sp * PBP + piece);
+                        d[0] = hh; d[8] = ll;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // 16-byte unit g of the tile = (pixel g / UPP, unit g % UPP): a wave instruction stores 64 consecutive units = whole pixels
+        const unsigned tile_off = (unsigned)(h0 / POOLH) * (unsigned)Wout * pix_bytes + (unsigned)(w0 / POOLW) * pix_bytes + (unsigned)nt * (NT * 4u);
+        const int rows_ok = Ho / POOLH - h0 / POOLH, cols_ok = Wout - w0 / POOLW;      // staged rows / columns inside the image
+#pragma unroll
+        for (int it = 0; it < (NPX * UPP + NTHR - 1) / NTHR; ++it) {
+            const int g = it * NTHR + tid, sp = g / UPP, unit = g % UPP, row = sp / TWO, col = sp % TWO;
+            const bool ok = ((NPX * UPP) % NTHR == 0 || sp < NPX) && row < rows_ok && col < cols_ok;
+            const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + (unsigned)sp * PBP + (unsigned)unit * 16u);
+            // (a branch around the store, NOT an out-of-range offset for the lanes outside the image: with the tile's position in the
+            // scalar offset such stores were not always dropped - rare wrong low planes in ANOTHER launch's activations, seen only with
+            // three launches in flight: tools/three_in_flight.py)
+            if (ok) __builtin_amdgcn_raw_buffer_store_b128(val, yrsrc, (int)((unsigned)(row * Wout + col) * pix_bytes + (unsigned)unit * 16u), (int)tile_off, 0);
+        }
+        __syncthreads();                                             // (the staging area is the next tile's A buffer again)
 }
 
 // WM waves split the pixel tile (column strips), 4 / WM waves split the output channels; the B tile (weights of one
@@ -265,6 +362,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     static_assert(!(PRE_IN && UPCAT), "the layout network keeps fp32 activations");
     // SPL = planes per operand: 3 = bf16x3 (six MFMAs per 32-deep product block), 2 = f16x2 (three)
     static_assert(SPL == 2 || SPL == 3, "operand split: 3 bf16 planes or 2 f16 planes");
+    constexpr bool TR = SPL == 2 && PRE_OUT && POCR_EPI_T != 0;      // result layout [channel][pixel] (mfma_conv_f16) and the epilogue written for it
     constexpr int NWAVE = 4, WN = NWAVE / WM, KC = 32, NTAP = KH * KW, WU = SPL * 64, NMF = SPL == 3 ? 6 : 3;
     static_assert(MW % WM == 0, "column strips must divide among the M waves");
     constexpr int TW = 16 * MW, MWW = MW / WM, MS = TH * MWW, NT = NS * WN * 16, NTHR = 256;
@@ -286,7 +384,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     constexpr int F1_PW = HW + 2, F1_N = (HH + 2) * F1_PW * 3;            // FUSE1: conv1's input patch ([row][col][c] floats) behind the A buffers
     constexpr int F1_Z = kConv1Tail + (2 * F1_PW + 3) * 3;            // the patch's tail + a zero 3 x 3 x 3 neighbourhood (conv1_x_frag)
     constexpr int F1_U = FUSE1 ? (F1_N + F1_Z + 3) / 4 : 0;
-    __shared__ u32x4 lds[(BDIR ? 2 * A_U : A_BUFS * A_U + 2 * B_F4) + F1_U];      // one scalar type (unsigned) for every access: no type punning
+    __shared__ u32x4 lds[(BDIR ? 2 * A_U : A_BUFS * A_U + 2 * B_F4) + F1_U];      // one scalar type (unsigned) for every access: no type punning      // one scalar type (unsigned) for every access: no type punning
     u32x4 *ldsA = lds;
     u32x4 *ldsB = lds + A_BUFS * A_U;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
@@ -527,9 +625,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         for (int it = 0; it < (NPPAD / 16 + NWAVE - 1) / NWAVE; ++it) {      // (unrolled: the iterations are independent chains gather -> MFMA -> split -> LDS)
             const int mt = wave + it * NWAVE;
             if (mt >= NPPAD / 16) break;
-#if POCR_F1_HACK & 8
-            if (a.n >= 0) break;                        // (experiment: no conv1 at all)
-#endif
             const int px = mt * 16 + li, pa = min(px, NP - 1);
             const int hi = h0 - 1 + pa / HW, wi = w0 - 1 + pa % HW;
             const bool inside = px < NP && hi >= 0 && hi < a.H && wi >= 0 && wi < Win;      // outside the image: conv2's zero padding
@@ -579,11 +674,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                         const int m = r * MWW + mw;
                         u32x4 (&bc)[NS][2] = bw[par][dy];
 #pragma unroll
-                        for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(al, bc[n][0], acc2[m][n]);
+                        for (int n = 0; n < NS; ++n) acc2[m][n] = mfma_conv_f16<TR>(al, bc[n][0], acc2[m][n]);
 #pragma unroll
-                        for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_F16(ah, bc[n][0], acc[m][n]);
+                        for (int n = 0; n < NS; ++n) acc[m][n] = mfma_conv_f16<TR>(ah, bc[n][0], acc[m][n]);
 #pragma unroll
-                        for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(ah, bc[n][1], acc2[m][n]);
+                        for (int n = 0; n < NS; ++n) acc2[m][n] = mfma_conv_f16<TR>(ah, bc[n][1], acc2[m][n]);
                     }
                     __builtin_amdgcn_sched_barrier(0);   // units stay in source order: reads of unit q + AH, then the MFMAs of unit q
                 }
@@ -621,11 +716,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             }
             const u32x4 ah = af[m & 1][0], al = af[m & 1][1];
 #pragma unroll
-            for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(al, bh[n], acc2[m][n]);
+            for (int n = 0; n < NS; ++n) acc2[m][n] = mfma_conv_f16<TR>(al, bh[n], acc2[m][n]);
 #pragma unroll
-            for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_F16(ah, bh[n], acc[m][n]);
+            for (int n = 0; n < NS; ++n) acc[m][n] = mfma_conv_f16<TR>(ah, bh[n], acc[m][n]);
 #pragma unroll
-            for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(ah, bl[n], acc2[m][n]);
+            for (int n = 0; n < NS; ++n) acc2[m][n] = mfma_conv_f16<TR>(ah, bl[n], acc2[m][n]);
             __builtin_amdgcn_sched_barrier(0);
             if (m == (MS - 1) / 2) {
                 // (unconditional: after the last chunk the other buffer has no reader, and the clamped re-read keeps the
@@ -718,11 +813,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                         const u32x4 ah = APRE ? apre[tap & 1][m][0] : Ab[o], al = APRE ? apre[tap & 1][m][1] : Ab[o + PS];
 #endif
 #pragma unroll
-                        for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(al, bc[n][0], acc2[m][n]);
+                        for (int n = 0; n < NS; ++n) acc2[m][n] = mfma_conv_f16<TR>(al, bc[n][0], acc2[m][n]);
 #pragma unroll
-                        for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_F16(ah, bc[n][0], acc[m][n]);
+                        for (int n = 0; n < NS; ++n) acc[m][n] = mfma_conv_f16<TR>(ah, bc[n][0], acc[m][n]);
 #pragma unroll
-                        for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(ah, bc[n][1], acc2[m][n]);
+                        for (int n = 0; n < NS; ++n) acc2[m][n] = mfma_conv_f16<TR>(ah, bc[n][1], acc2[m][n]);
                     } else {
 #if POCR_BF16X3_DBG & 1
                     const u32x4 ah = bc[0][0] ^ (unsigned)m, am = bc[0][1] ^ (unsigned)m, al = bc[0][SPL - 1] ^ (unsigned)m;     // no LDS reads
@@ -787,11 +882,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                 if constexpr (SPL == 2) {           // bm = the scaled low plane of the weights
                     const u32x4 ah = Ab[o], al = Ab[o + PS];
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(al, bh[n], acc2[m][n]);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = mfma_conv_f16<TR>(al, bh[n], acc2[m][n]);
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_F16(ah, bh[n], acc[m][n]);
+                    for (int n = 0; n < NS; ++n) acc[m][n] = mfma_conv_f16<TR>(ah, bh[n], acc[m][n]);
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_F16(ah, bm[n], acc2[m][n]);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = mfma_conv_f16<TR>(ah, bm[n], acc2[m][n]);
                     continue;
                 }
                 const u32x4 ah = Ab[o], am = Ab[o + PS], al = Ab[o + (SPL - 1) * PS];
@@ -826,6 +921,79 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 
     }
     POCR_TRACE_STAMP(2);
+    if constexpr (TR) {
+        // ---- epilogue for the [channel][pixel] result layout: lane (li, kq) holds channels 4 kq .. + 3 of pixel li of every 16-pixel
+        // tile.  No transpose, no branches: the two 8-byte pieces of a pixel (h plane, l plane: p2_channel_bytes) go out as buffer stores
+        // whose offset is pushed out of range for pixels outside the image.  (conv_rows.hpp sends the tile through LDS and stores whole
+        // lines - conv_epilogue_staged; this kernel keeps the direct stores: it serves conv2 with conv1 in its prologue, whose pooled
+        // output is a quarter of its input, and the layers of POCR_CONV_ROWS=0.)
+        const int Wo = Win, Wout = Wo / POOLW;
+        const unsigned pix_bytes = (unsigned)a.out_stride * 4u;
+        const size_t img_bytes = (size_t)(a.Ho / POOLH) * Wout * pix_bytes;
+        constexpr unsigned kOut = 0x80000000u;
+        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + out_base, 0, (int)(img_bytes < kOut ? img_bytes : kOut - 1), 0x00020000);
+        unsigned rmax = 0u;
+        unsigned lane_off[MWW];
+#pragma unroll
+        for (int mw = 0; mw < MWW; ++mw) {
+            const int col = w0 + (wm * MWW + mw) * 16 + li;
+            const bool ok = POOLW == 2 ? ((li & 1) == 0 && col + 1 < Wo) : col < Wo;
+            lane_off[mw] = ok ? (unsigned)(col / POOLW) * pix_bytes + (unsigned)kq * 8u : kOut;
+        }
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const int cg = nt * (NT / 16) + wn * NS + n;              // 16-channel group; this lane: channels 16 cg + 4 kq + r
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.bias + cg * 16 + 4 * kq);
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (BN) { sc = *reinterpret_cast<const f32x4 *>(a.bn_scale + cg * 16 + 4 * kq); sh = *reinterpret_cast<const f32x4 *>(a.bn_shift + cg * 16 + 4 * kq); }
+            const unsigned chan_off = (unsigned)(cg >> 1) * 128u + (unsigned)(cg & 1) * 32u;      // p2_channel_bytes(16 cg); the lane's 4 kq channels: + 8 kq (lane_off)
+#pragma unroll
+            for (int th = 0; th < TH; th += POOLH) {
+                const int ho = (h0 + th) / POOLH;
+                const bool row_ok = h0 + th < a.Ho;
+                const unsigned row_off = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)ho * (unsigned)Wout * pix_bytes + chan_off));     // (wave-uniform: said explicitly, or the store becomes a loop over lanes)
+#pragma unroll
+                for (int mw = 0; mw < MWW; ++mw) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t = apply_act(acc[th * MWW + mw][n][r] + acc2[th * MWW + mw][n][r] * (1.0f / kF16x2Scale) + bias[r], ACT);
+                        if constexpr (BN) t = t * sc[r] + sh[r];
+                        if constexpr (POOLH == 2) {
+                            float u = apply_act(acc[(th + 1) * MWW + mw][n][r] + acc2[(th + 1) * MWW + mw][n][r] * (1.0f / kF16x2Scale) + bias[r], ACT);
+                            if constexpr (BN) u = u * sc[r] + sh[r];
+                            t = fmaxf(t, u);
+                        }
+                        if constexpr (POOLW == 2)              // the other pixel of the pair sits in the neighbouring lane
+                            t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true)));
+                        v[r] = t;
+                    }
+                    if constexpr (ACT == ACT_RELU && !BN) {   // non-negative: bit patterns order like signed integers (conv1_relu_note)
+                        int mm = (int)rmax;
+                        mm = max(max(mm, __builtin_bit_cast(int, v[0])), __builtin_bit_cast(int, v[1]));
+                        mm = max(max(mm, __builtin_bit_cast(int, v[2])), __builtin_bit_cast(int, v[3]));
+                        rmax = (unsigned)mm;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) range_note(rmax, v[r]);
+                    }
+                    u32x2 hh, ll;
+                    split2_quad(v, hh, ll);
+                    if (row_ok && lane_off[mw] != kOut) {          // (a branch, not an out-of-range offset: conv_epilogue_staged)
+                        __builtin_amdgcn_raw_buffer_store_b64(hh, yrsrc, (int)lane_off[mw], (int)row_off, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(ll, yrsrc, (int)(lane_off[mw] + 64u), (int)row_off, 0);
+                    }
+                }
+            }
+        }
+        range_publish(a.range_max, rmax, lane);
+#ifdef POCR_BF16X3_TRACE
+        POCR_TRACE_STAMP(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        POCR_TRACE_STAMP(4);
+#endif
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < MS; ++m)
 #pragma unroll
@@ -834,9 +1002,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             else acc[m][n] += acc2[m][n];
         }
     // ---- epilogue (identical to conv_igemm_kernel: same D layout)
-#if POCR_F1_HACK & 16
-    if (FUSE1 && a.n >= 0) return;                      // (experiment: no epilogue)
-#endif
     const int Wo = Win, Wout = Wo / POOLW;
     unsigned rmax = 0u;                                 // f16x2 range guard (conv_igemm.hpp: range_note)
 #pragma unroll

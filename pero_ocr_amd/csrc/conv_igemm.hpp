@@ -127,6 +127,9 @@ struct ConvArgs {
     // |output| of this launch; NULL = off.  The host decides at collect time whether the launch left f16's range.
     unsigned *range_max;
     unsigned *f1_range;      // the same for conv1's activation when conv2 computes it in its prologue (FUSE1)
+    // persistent kernels (conv_rows.hpp): the number of (channel tile, pixel tile) blocks of the layer = conv_grid_blocks(); the launch's
+    // grid is smaller and every workgroup walks blocks blockIdx.x, + gridDim.x, ...  0: one block per workgroup (gridDim.x blocks)
+    int32_t nblocks;
 };
 
 // number of workgroups for a conv launch (must match the block -> tile mapping in the kernel)

@@ -21,6 +21,7 @@
 #include "conv_igemm.hpp"
 #include "conv1_u8.hpp"
 #include "conv_bf16x3.hpp"
+#include "conv_rows.hpp"
 #include "gemm_f16x2.hpp"
 #include "ctc.hpp"
 #include "encoder.hpp"
@@ -212,6 +213,53 @@ int launch_conv(Kern kern, int TH, int TW, int NT, int nthreads, ConvArgs a, hip
     return 0;
 }
 
+// conv_rows.hpp: the 3x3 f16x2 / P2 layers with the result layout [channel][pixel] and the output tile leaving through LDS as
+// whole lines; same bits as the kernels of conv_bf16x3.hpp.  The kernel can also run PERSISTENTLY - a grid of two workgroups per
+// CU, each walking the blocks blockIdx.x, + gridDim.x, ... with the next tile's first chunk requested under the epilogue (needs an
+// even number of 32-channel chunks and a mapping that keeps a workgroup on one channel tile: 1 tile, or 2 / 4 / 8 with a grid that
+// is a multiple of 64).  Which layer takes which form was measured on a c2 chunk alone (profiles/r05_conv_rows.txt; ms, old kernel /
+// rows / rows persistent): conv3 0.657 / 0.603 / 0.555, conv4 0.95 / 0.92 / 0.97, conv5 0.544 / 0.507 / 0.527, conv6 0.943 / 0.926 /
+// 0.962, conv7 0.92 / 0.945 / 0.966, conv8 0.977 / 0.974 / 0.972, conv9 1.815 / 1.79 / 1.83 - the two workgroups of a CU already cover
+// each other's prologue, so persistence pays only where the prologue is a third of a tile (conv3).
+// POCR_CONV_ROWS_MASK / POCR_CONV_PERSIST_MASK: bit i = conv(i + 1) (defaults 0x1BC: all but conv7; 0x4: conv3); POCR_CONV_ROWS=0: none.
+thread_local int g_conv_layer = -1;                     // index of the layer being launched (run_network)
+inline int conv_rows_mode() {                           // 0: conv_bf16x3.hpp, 1: conv_rows.hpp, 2: conv_rows.hpp persistent
+    static const int rows_mask = [] {
+        if (const char *e = getenv("POCR_CONV_ROWS")) if (atoi(e) == 0) return 0;
+        const char *m = getenv("POCR_CONV_ROWS_MASK");
+        return m ? (int)strtol(m, nullptr, 0) : 0x1BC;
+    }();
+    static const int pers_mask = [] { const char *m = getenv("POCR_CONV_PERSIST_MASK"); return m ? (int)strtol(m, nullptr, 0) : 0x4; }();
+    const int l = g_conv_layer;
+    if (l < 0 || l > 30) return rows_mask ? 1 : 0;
+    return !((rows_mask >> l) & 1) ? 0 : ((pers_mask >> l) & 1) ? 2 : 1;
+}
+template <class Kern>
+int launch_conv_rows(Kern kern, int TH, int TW, int NT, ConvArgs a, hipStream_t st) {
+    if (!a.tiles) {
+        a.tiles_w = (a.Wo + TW - 1) / TW;
+        a.tiles_h = (a.Ho + TH - 1) / TH;
+    }
+    a.tiles_n = (a.cout16 * 16) / NT;
+    static const int xcd_g_env = getenv("POCR_XCD_G") ? atoi(getenv("POCR_XCD_G")) : 1;
+    if (a.xcd_g == 0) a.xcd_g = xcd_g_env;
+    const size_t blocks = conv_grid_blocks(a);
+    if (blocks == 0) return 0;
+    if (blocks > 0x7fffffffull) return fail("conv grid too large (%zu blocks)", blocks);
+    static const int n_cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int tn = a.tiles_n;
+    const bool one_tile = tn == 1 || (tn >= 2 && tn <= 8 && (tn & (tn - 1)) == 0);
+    size_t grid = blocks;
+    if (one_tile && ((a.cin / 32) & 1) == 0) {
+        const size_t cap = conv_rows_mode() == 2 ? (size_t)(n_cus * 2) / 64 * 64 : 0;
+        if (cap >= 64 && cap < blocks) grid = cap;
+    }
+    a.nblocks = (int32_t)blocks;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // tile configurations (KH,KW,PADH,PADW, TH,MW,NS,NWAVE,KC, POOLH,POOLW, ACT,BN, STAGER, PIPE)
 // PI = PIPE_INTERLEAVED (unrolled taps, MFMA-interleaved staging, see conv_igemm.hpp); PP = PIPE_PLAIN.
 #define POCR_CONV(name, KH, KW, PH, PW, TH, MW, NS, NWAVE, KC, POOLH, POOLW, ACT, BN, STG, PIPE)                       \
@@ -292,6 +340,16 @@ POCR_CONV3(conv9_b3,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true, 2)    // 512->
 // writes fp32 features for the sequence model.
 #define POCR_CONVP(name, TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW, BDIR)                                        \
     int name(ConvArgs a, hipStream_t st) {                                                                         \
+        if constexpr (BDIR) {                                                                                      \
+            if constexpr (NS == 1) {            /* (the persistent form of the 128-channel tiles does not fit the registers) */ \
+                if (conv_rows_mode() == 2 && !a.x2)                                                                \
+                    return launch_conv_rows(conv3x3_rows_kernel<TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW, true>, TH, 16 * MW, \
+                                            NS * (4 / WM) * 16, a, st);                                            \
+            }                                                                                                      \
+            if (conv_rows_mode() >= 1 && !a.x2)                                                                    \
+                return launch_conv_rows(conv3x3_rows_kernel<TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW, false>, TH, 16 * MW, \
+                                        NS * (4 / WM) * 16, a, st);                                                \
+        }                                                                                                          \
         return launch_conv(conv3x3_bf16x3_kernel<TH, MW, NS, WM, POOLH, POOLW, ACT, BN, MINW, BDIR, 3, 3, 1, 1, false, 2, true, true>, \
                            TH, 16 * MW, NS * (4 / WM) * 16, 256, a, st);                                           \
     }
@@ -784,6 +842,7 @@ int run_network(pocr_engine *e, Slot &s) {
             a.x = s.act[i - 1].as<float>(); a.cin = L.cin;
             if (i == 8) { a.bn_scale = e->bn_scale.as<float>(); a.bn_shift = e->bn_shift.as<float>(); }
             if (e->p2) {
+                g_conv_layer = i;                       // (conv_rows_mode: which form of the kernel this layer takes)
                 switch (i) {
                     case 1:
                         if (e->fuse12) {

@@ -15,3 +15,15 @@ def test_first_call_of_fresh_engines_under_load():
     out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "stress_first_job.py"), "12", "3"], capture_output=True, text=True, timeout=300)
     last = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert out.returncode == 0 and last, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_three_launches_in_flight_on_fresh_engines_are_bit_identical():
+    """The activations of a launch do not depend on what the other two slots run at the same time - checked on FRESH engines, where a
+    store of a convolution that was masked by an out-of-range buffer offset (not by a branch) once left wrong low planes in another
+    launch's activations: only with three launches in flight, only in the first round after pocr_create (tools/three_in_flight.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("three_in_flight", os.path.join(REPO, "tools", "three_in_flight.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(4) == 0

@@ -10,6 +10,7 @@
 #include <vector>
 #include "../pero_ocr_amd/csrc/conv_igemm.hpp"
 #include "../pero_ocr_amd/csrc/conv_bf16x3.hpp"
+#include "../pero_ocr_amd/csrc/conv_rows.hpp"
 #include "experiments/conv_wino.hpp"
 using namespace pocr;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -28,6 +29,25 @@ VP(d7, 10, 1, 1, 1, 2, 1, ACT_RELU, false, 2, true)
 VP(d56, 10, 1, 1, 1, 1, 1, ACT_RELU, false, 2, true)
 VP(d4, 10, 1, 1, 1, 2, 2, ACT_RELU, false, 2, true)
 VP(d3, 10, 1, 1, 1, 1, 1, ACT_RELU, false, 2, true)
+// the persistent form of the shipped configurations (conv_rows.hpp); POCR_ROWS_WGS = workgroups per CU (default 2)
+template <class K>
+static void launch_rows(K kern, int TH, int TW, int NT, ConvArgs a, hipStream_t st) {
+    a.tiles_w = (a.Wo + TW - 1) / TW; a.tiles_h = (a.Ho + TH - 1) / TH; a.tiles_n = (a.cout16 * 16) / NT;
+    const size_t blocks = conv_grid_blocks(a);
+    static const int wgs = getenv("POCR_ROWS_WGS") ? atoi(getenv("POCR_ROWS_WGS")) : 2;
+    size_t grid = blocks;
+    if (wgs > 0 && (size_t)(256 * wgs) < blocks) grid = 256 * wgs;
+    a.nblocks = (int)blocks;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, st, a);
+}
+#define RP(NAME, TH, MW, NS, WM, PH, PW, ACT, BN, MINW) static void NAME(ConvArgs a, hipStream_t st) { \
+    launch_rows(conv3x3_rows_kernel<TH, MW, NS, WM, PH, PW, ACT, BN, MINW, true>, TH, 16 * MW, NS * (4 / WM) * 16, a, st); }
+RP(r9, 5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2)
+RP(r8, 5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2)
+RP(r7, 10, 1, 1, 1, 2, 1, ACT_RELU, false, 2)
+RP(r56, 10, 1, 1, 1, 1, 1, ACT_RELU, false, 2)
+RP(r4, 10, 1, 1, 1, 2, 2, ACT_RELU, false, 2)
+RP(r3, 10, 1, 1, 1, 1, 1, ACT_RELU, false, 2)
 // experiment: the direct kernel with its waves splitting PIXELS, weights shared through LDS (fewer bytes from L2 per output)
 VP(x9_22, 5, 2, 2, 2, 1, 1, ACT_LEAKY, true, 2, false)     // 5x32 px x 64 ch, waves 2 (px) x 2 (ch)
 VP(x9_41, 5, 4, 2, 4, 1, 1, ACT_LEAKY, true, 2, false)     // 5x64 px x 32 ch, waves 4 (px)
@@ -49,7 +69,7 @@ static float f16val(uint16_t b) { _Float16 v; memcpy(&v, &b, 2); return (float)v
 __global__ void trace_copy_kernel(unsigned long long *out, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { out[i] = g_conv_trace[i]; g_conv_trace[i] = 0; }
 }
-static void trace_report() {
+static void trace_report(bool rows = false) {
     const size_t nb = 1u << 15;
     std::vector<unsigned long long> t(nb * 8);
     unsigned long long *dp;
@@ -57,6 +77,14 @@ static void trace_report() {
     hipLaunchKernelGGL(trace_copy_kernel, dim3(256), dim3(256), 0, 0, dp, nb * 8);
     CK(hipMemcpy(t.data(), dp, nb * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     CK(hipFree(dp));
+    if (rows) {      // conv_rows.hpp: per workgroup [0] start, [1] sum of main loops, [2] sum of epilogues, [3] sum of everything else, [4] end, [6] tiles
+        double tm = 0, te = 0, to = 0, tiles = 0, span = 0; size_t ran = 0;
+        for (size_t b = 0; b < nb; ++b) { const unsigned long long *q = &t[b * 8]; if (!q[4]) continue; ++ran; tm += q[1]; te += q[2]; to += q[3]; tiles += q[6]; span += q[4] - q[0]; }
+        if (!ran) { printf("    trace: no stamps\n"); return; }
+        printf("    trace (%zu workgroups, %.1f tiles each, %.1f us each): mean per tile: main loop %.2f us, epilogue %.2f us, between tiles %.2f us\n",
+               ran, tiles / ran, span / ran * 0.01, tm / tiles * 0.01, te / tiles * 0.01, to / tiles * 0.01);
+        return;
+    }
     unsigned long long tmin = ~0ull, tmax = 0; double ph[4] = {0, 0, 0, 0}; size_t ran = 0; double lat = 0, latn = 0;
     for (size_t b = 0; b < nb; ++b) {
         const unsigned long long *q = &t[b * 8];
@@ -69,6 +97,33 @@ static void trace_report() {
     printf("    trace (first %zu workgroups): span %.1f us; mean per workgroup: prologue %.2f us, main loop %.2f us, epilogue issue %.2f us, store drain %.2f us\n",
            ran, (tmax - tmin) * 0.01, ph[0] / ran * 0.01, ph[1] / ran * 0.01, ph[2] / ran * 0.01, ph[3] / ran * 0.01);
     if (latn > 0) printf("    activation-load bursts: mean issue-to-data %.2f us over %.0f bursts\n", lat / latn * 0.01, latn);
+    // Do the workgroups that share a CU run in phase?  Per CU (XCC id, HW_ID bits 8..15): starts sorted in time; for every workgroup the
+    // distance from its start to the latest start of ANOTHER workgroup on that CU, as a fraction of its own duration (0 = started
+    // together: their VALU phases - prologue, epilogue - coincide and cannot hide behind each other's MFMA phase; 0.5 = alternating)
+    {
+        std::vector<std::pair<unsigned, size_t>> key;
+        for (size_t b = 0; b < nb; ++b) if (t[b * 8 + 4]) key.push_back({(unsigned)((t[b * 8 + 5] >> 32) << 8 | ((t[b * 8 + 5] >> 8) & 0xff)), b});
+        std::sort(key.begin(), key.end(), [&](const auto &x, const auto &y) { return x.first != y.first ? x.first < y.first : t[x.second * 8] < t[y.second * 8]; });
+        size_t hist[10] = {0}, ncu = 0, cnt = 0; double both_main = 0, any = 0;
+        for (size_t i = 0; i < key.size();) {
+            size_t j = i; while (j < key.size() && key[j].first == key[i].first) ++j;
+            ++ncu;
+            for (size_t k = i + 1; k < j; ++k) {
+                const unsigned long long *q = &t[key[k].second * 8], *pq = &t[key[k - 1].second * 8];
+                const double dur = (double)(q[3] - q[0]);
+                if (pq[3] <= q[0] || dur <= 0) continue;            // the previous one had ended: not co-resident
+                const double f = (double)(q[0] - pq[0]) / dur;
+                ++hist[std::min(9, (int)(f * 10))]; ++cnt;
+                // time both are inside their main loops, relative to this one's main loop
+                const double lo = (double)std::max(q[1], pq[1]), hi = (double)std::min(q[2], pq[2]);
+                both_main += std::max(0.0, hi - lo); any += (double)(q[2] - q[1]);
+            }
+            i = j;
+        }
+        printf("    phase of co-resident workgroups (%zu CUs, %zu pairs): start offset / own duration, deciles:", ncu, cnt);
+        for (int k = 0; k < 10; ++k) printf(" %.2f", cnt ? (double)hist[k] / cnt : 0.0);
+        printf("; share of a main loop spent next to the neighbour's main loop %.2f\n", any > 0 ? both_main / any : 0.0);
+    }
 }
 #endif
 int main(int argc, char **argv) {
@@ -208,7 +263,7 @@ int main(int argc, char **argv) {
                 out[px * s.cout + c] = f16val(raw[o]) + f16val(raw[o + 32]) * (1.0f / 2048.0f);
             }
     };
-    const int nvar = layer == 9 ? 8 : 2;
+    const int nvar = layer == 9 ? 9 : 3;
     for (int vi = 0; vi < nvar; ++vi) {
         WinoArgs a{};
         a.x = dx; a.wfrag = vi == 1 ? dw2 : dw; a.bias = db; a.bn_scale = ds; a.bn_shift = dh; a.y = vi ? dy2 : dy;
@@ -220,7 +275,8 @@ int main(int argc, char **argv) {
 #endif
         if (is_w) { a.x_bytes = (uint32_t)(xin * 4); a.wtiles = dwt; a.n_ptiles = (int)wt.size(); a.line_w = dlw; a.in_off = dio; a.out_off = doo; }
         auto run = [&]() {
-            if (vi >= 2) { switch (vi) { case 2: x9_22(a, st); break; case 3: x9_41(a, st); break; case 4: x9_42(a, st); break; case 5: x9_24(a, st); break; case 6: x9_r22(a, st); break; default: x9_r41(a, st); } }
+            if (vi == 2) { switch (layer) { case 9: r9(a, st); break; case 8: r8(a, st); break; case 7: r7(a, st); break; case 6: case 5: r56(a, st); break; case 4: r4(a, st); break; default: r3(a, st); } }
+            else if (vi >= 3) { switch (vi) { case 3: x9_22(a, st); break; case 4: x9_41(a, st); break; case 5: x9_42(a, st); break; case 6: x9_24(a, st); break; case 7: x9_r22(a, st); break; default: x9_r41(a, st); } }
             else if (!vi) {
                 switch (layer) { case 9: d9(a, st); break; case 8: d8(a, st); break; case 7: d7(a, st); break; case 6: case 5: d56(a, st); break; case 4: d4(a, st); break; default: d3(a, st); }
             } else {
@@ -234,11 +290,14 @@ int main(int argc, char **argv) {
             }
         };
         CK(hipMemsetAsync(a.y, 0xff, yout * 4, st));
+#ifdef POCR_BF16X3_TRACE
+        { unsigned long long *dp; CK(hipMalloc(&dp, (size_t)(1u << 18) * 8)); hipLaunchKernelGGL(trace_copy_kernel, dim3(256), dim3(256), 0, st, dp, (size_t)1u << 18); CK(hipStreamSynchronize(st)); CK(hipFree(dp)); }   // (stamps of the previous variant's timing runs)
+#endif
         run();
         CK(hipStreamSynchronize(st)); CK(hipGetLastError());
         readback(a.y, vi ? yw : yd);
 #ifdef POCR_BF16X3_TRACE
-        trace_report();
+        trace_report(vi == 2);
 #endif
         for (int w = 0; w < 2; ++w) run();
         float best = 1e30f, sum = 0;
@@ -259,7 +318,7 @@ int main(int argc, char **argv) {
         double maxref = 0, rmsref = 0, maxdiff = 0; size_t nnan = 0;
         for (int k = 0; k < NSAMP; ++k) { const double d = fabs((double)yy[samp[k]] - ref[k]); maxref = d > maxref ? d : maxref; rmsref += d * d; }
         if (vi) for (size_t k = 0; k < yout; ++k) { const double d = fabs((double)yw[k] - yd[k]); if (!(d == d)) ++nnan; else if (d > maxdiff) maxdiff = d; }
-        const char *vname[8] = {"direct f16x2 P2 (shipped)", "Winograd F(2,3) f16x2", "direct 5x32x64 2x2 LDS weights", "direct 5x64x32 4x1 LDS weights", "direct 5x64x64 4x1 NS4 1WG", "direct 5x32x128 2x2 NS4 1WG",
+        const char *vname[9] = {"direct f16x2 P2 (shipped)", "Winograd F(2,3) f16x2", "direct, persistent (conv_rows.hpp)", "direct 5x32x64 2x2 LDS weights", "direct 5x64x32 4x1 LDS weights", "direct 5x64x64 4x1 NS4 1WG", "direct 5x32x128 2x2 NS4 1WG",
                                 "direct 5x32x64 2x2 rows, L2 weights", "direct 5x64x32 4x1 rows, L2 weights"};
         printf("  %-34s avg %.3f ms best %.3f ms  %.1f TF(alg)", vname[vi], sum / reps, best, flops / (sum / reps * 1e-3) / 1e12);
         if (sustained > 0) printf("  sustained x%d: %.3f ms %.1f TF", sustained, sus, flops / (sus * 1e-3) / 1e12);

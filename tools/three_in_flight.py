@@ -1,0 +1,56 @@
+"""Three launches in flight on one engine, fresh engines: the activations of the middle launch must equal those of the same lines
+run alone, bit for bit.  (Found a store that was masked by an out-of-range buffer offset instead of a branch: rare wrong low planes
+in another launch's activations, only with three launches in flight, only in the first round after the engine's creation.)
+    python tools/three_in_flight.py [trials=6]        exit code 1 if any trial differs"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pero_ocr_amd import _native, netspec, synth  # noqa: E402
+
+
+def pack(ws, seed):
+    crops = synth.make_crops(seed, ws, 40)
+    pool = np.concatenate([c.reshape(-1) for c in crops])
+    offs = np.concatenate([[0], np.cumsum([c.size for c in crops])[:-1]]).astype(np.int64)
+    wp = -(-max(ws) // 32) * 32 + 64
+    return pool, offs, np.array(ws, np.int32), [wp] * len(ws)
+
+
+def run(eng, sl, P):
+    eng.slot_stage_ragged(sl, *P, 32)
+    eng.slot_launch(sl, want_logits=True, want_argmax=True)
+
+
+def main(trials=6):
+    chars = synth.make_charset(99)
+    spec = netspec.NetSpec(num_classes=len(chars) + 1)
+    weights = netspec.pack_weights(spec, netspec.generate_weights(spec, 20260928))
+    A = pack([790, 783, 779, 760, 750, 745, 730], 1)
+    S = pack([722, 714, 706, 700, 690, 686, 680], 2)
+    B = pack([653, 643, 636, 630, 620, 610, 600], 3)
+    bad = 0
+    for trial in range(trials):
+        eng = _native.NativeEngine(spec, weights, 0)
+        run(eng, 0, S)
+        ref_logits = eng.slot_collect(0)[0].copy()
+        ref = [eng.debug_read(k) for k in range(12)]
+        for rep in range(2):
+            run(eng, 0, A); run(eng, 2, B); run(eng, 1, S)
+            eng.slot_collect(0); eng.slot_collect(2)
+            ls = eng.slot_collect(1)[0]
+            got = [eng.debug_read(k) for k in range(12)]
+            first = next((k for k in range(12) if not np.array_equal(got[k], ref[k])), None)
+            if first is not None or not np.array_equal(ls, ref_logits):
+                bad += 1
+                n = int(np.count_nonzero(got[first] != ref[first])) if first is not None else 0
+                print(f"trial {trial} round {rep}: first differing activation {first} ({n} values), logits equal {np.array_equal(ls, ref_logits)}")
+        eng.close()
+    print(f"three launches in flight, {trials} fresh engines x 2 rounds: {bad} rounds differ from the lines run alone")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 6))
