@@ -48,6 +48,9 @@
 #ifndef POCR_STA_TAP
 #define POCR_STA_TAP (NTAP / 2)        // tap after which the next chunk's halo tile (requested at tap 0) is written to the other LDS buffer
 #endif
+#ifndef POCR_FUSE1_STAGED
+#define POCR_FUSE1_STAGED 0          // 1: conv2 with conv1 in its prologue sends its pooled tile through LDS as whole lines too (measured: 1.183 against 1.174 ms - its output is a quarter of its input; off)
+#endif
 #ifndef POCR_EPI_T
 #define POCR_EPI_T 1                 // f16x2 kernels that write P2: weights as the MFMA's A operand, so a lane ends up with four consecutive channels of one pixel (the epilogue below "TR")
 #endif
@@ -921,10 +924,19 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 
     }
     POCR_TRACE_STAMP(2);
+    if constexpr (TR && FUSE1 && POCR_FUSE1_STAGED != 0) {
+        // ---- conv2 with conv1 in its prologue: the pooled tile out through LDS as whole lines (conv_epilogue_staged; the A buffers are free)
+        unsigned rmax = 0u;
+        __syncthreads();
+        conv_epilogue_staged<TH, MWW, NS, WM, POOLH, POOLW, ACT, BN, NT, TW>(acc, acc2, a.bias + nt * NT, BN ? a.bn_scale + nt * NT : nullptr,
+                                                                             BN ? a.bn_shift + nt * NT : nullptr, reinterpret_cast<char *>(lds),
+                                                                             a.y + out_base, h0, w0, Win, a.Ho, a.out_stride, nt, rmax);
+        range_publish(a.range_max, rmax, lane);
+        return;
+    }
     if constexpr (TR) {
         // ---- epilogue for the [channel][pixel] result layout: lane (li, kq) holds channels 4 kq .. + 3 of pixel li of every 16-pixel
-        // tile.  No transpose, no branches: the two 8-byte pieces of a pixel (h plane, l plane: p2_channel_bytes) go out as buffer stores
-        // whose offset is pushed out of range for pixels outside the image.  (conv_rows.hpp sends the tile through LDS and stores whole
+        // tile.  No transpose: the two 8-byte pieces of a pixel (h plane, l plane: p2_channel_bytes) go out as buffer stores.  (conv_rows.hpp sends the tile through LDS and stores whole
         // lines - conv_epilogue_staged; this kernel keeps the direct stores: it serves conv2 with conv1 in its prologue, whose pooled
         // output is a quarter of its input, and the layers of POCR_CONV_ROWS=0.)
         const int Wo = Win, Wout = Wo / POOLW;
