@@ -331,9 +331,10 @@ __device__ __forceinline__ void conv_epilogue_staged(const f32x4 (&acc)[TH * MWW
             const int g = it * NTHR + tid, sp = g / UPP, unit = g % UPP, row = sp / TWO, col = sp % TWO;
             const bool ok = ((NPX * UPP) % NTHR == 0 || sp < NPX) && row < rows_ok && col < cols_ok;
             const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + (unsigned)sp * PBP + (unsigned)unit * 16u);
-            // (a branch around the store, NOT an out-of-range offset for the lanes outside the image: with the tile's position in the
-            // scalar offset such stores were not always dropped - rare wrong low planes in ANOTHER launch's activations, seen only with
-            // three launches in flight: tools/three_in_flight.py)
+            // (a branch around the store, NOT an out-of-range offset for the lanes outside the image: stores masked that way - mark
+            // 0x80000000 or 0x7FFF0000, the tile's position in the scalar offset - left rare wrong low planes in the activations of a
+            // launch running at the same time, 5-6 of 6 fresh engines with three launches in flight (tools/three_in_flight.py); why
+            // is not understood.  Loads masked by the mark - the halo's zero padding - pass every bit-identity test.)
             if (ok) __builtin_amdgcn_raw_buffer_store_b128(val, yrsrc, (int)((unsigned)(row * Wout + col) * pix_bytes + (unsigned)unit * 16u), (int)tile_off, 0);
         }
         __syncthreads();                                             // (the staging area is the next tile's A buffer again)

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_rows_kernel(ConvArgs a) {
     const unsigned total = a.nblocks > 0 ? (unsigned)a.nblocks : gridDim.x;
     const int nchunks = a.cin / KC;
     const bool chain = (nchunks & 1) == 0;              // (uniform) tile-to-tile prefetch possible
-    constexpr unsigned kOut = 0x80000000u;
+    constexpr unsigned kOut = 0x7FFF0000u;              // out-of-range mark of a load (with the chunk's scalar offset on top it stays below 2^31 and above any line image)
 
     // virtual block -> (channel tile, pixel tile), as conv3x3_bf16x3_kernel; false: no such tile
     const int tn = a.tiles_n;

@@ -10,6 +10,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pero_ocr_amd import _native, netspec, synth  # noqa: E402
 
+if os.environ.get("POCR_TMP_LIB"):                      # (experiments: a variant build of the library)
+    _lib = os.path.abspath(os.environ["POCR_TMP_LIB"])
+    _native.lib_path = lambda: _lib
+
 
 def pack(ws, seed):
     crops = synth.make_crops(seed, ws, 40)
