@@ -137,8 +137,9 @@ def kernel_trace_summary(workload, fl, n_lines, peak):
     longest = max((r for r in rows if "pocr::" in r[4]), key=lambda r: r[2])
     # algorithmic FLOPs of the conv kernels by their template signature (fused conv1+2: the ...true> at the end; conv9: BN = true)
     sig = {"conv1+2": "10, 1, 1, 1, 2, 2, 1, false, 2, true, 3, 3, 1, 1, false, 2, true, true, true>",
-           "conv9": "5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false, 2, true, true, false>"}
-    name = next((k for k, v in sig.items() if v in longest[4]), None)
+           "conv9": "5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false, 2, true, true, false>",
+           "conv9 ": "conv3x3_rows_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, false>"}        # (round 5: conv3 .. conv9 on csrc/conv_rows.hpp)
+    name = next((k.strip() for k, v in sig.items() if v in longest[4]), None)
     flops = None
     if name == "conv9":
         flops = fl["conv9"] * n_lines
@@ -808,7 +809,9 @@ def main():
             conv_ms = sum(ms[k] for k in fl)
             step_ms = 1e3 * elapsed / args.steps
             conv_tf = sum(fl.values()) * n_lines / (step_ms * 1e-3) / 1e12
-            kname = (f"conv3x3_bf16x3_kernel<TH5,MW1,NS2,leaky+BN,{SPLIT_NAME[split]}>" if split else "conv_igemm_kernel<3x3,TH5,NT256,leaky+BN>")
+            rows_kernel = split == 2 and os.environ.get("POCR_CONV_ROWS", "1") != "0"          # (csrc/conv_rows.hpp: the default f16x2 / P2 mode)
+            kname = ("conv3x3_rows_kernel<TH5,MW1,NS2,leaky+BN,f16x2> (csrc/conv_rows.hpp)" if rows_kernel else
+                     f"conv3x3_bf16x3_kernel<TH5,MW1,NS2,leaky+BN,{SPLIT_NAME[split]}>" if split else "conv_igemm_kernel<3x3,TH5,NT256,leaky+BN>")
             nm = MFMA_PER_BLOCK[split]
             result["roofline"] = {
                 "bound": "mfma", "kernel": f"{kname} ({dom}, 512->512 @5x{w_pad // 4})",

@@ -219,15 +219,15 @@ int launch_conv(Kern kern, int TH, int TW, int NT, int nthreads, ConvArgs a, hip
 // even number of 32-channel chunks and a mapping that keeps a workgroup on one channel tile: 1 tile, or 2 / 4 / 8 with a grid that
 // is a multiple of 64).  Which layer takes which form was measured on a c2 chunk alone (profiles/r05_conv_rows.txt; ms, old kernel /
 // rows / rows persistent): conv3 0.657 / 0.603 / 0.555, conv4 0.95 / 0.92 / 0.97, conv5 0.544 / 0.507 / 0.527, conv6 0.943 / 0.926 /
-// 0.962, conv7 0.92 / 0.945 / 0.966, conv8 0.977 / 0.974 / 0.972, conv9 1.815 / 1.79 / 1.83 - the two workgroups of a CU already cover
+// 0.962, conv7 0.92 / 0.945 / 0.966 (0.96 either way in the evidence run, within the boxes' spread), conv8 0.977 / 0.974 / 0.972, conv9 1.815 / 1.79 / 1.83 - the two workgroups of a CU already cover
 // each other's prologue, so persistence pays only where the prologue is a third of a tile (conv3).
-// POCR_CONV_ROWS_MASK / POCR_CONV_PERSIST_MASK: bit i = conv(i + 1) (defaults 0x1BC: all but conv7; 0x4: conv3); POCR_CONV_ROWS=0: none.
+// POCR_CONV_ROWS_MASK / POCR_CONV_PERSIST_MASK: bit i = conv(i + 1) (defaults 0x1FC: conv3 .. conv9; 0x4: conv3); POCR_CONV_ROWS=0: none.
 thread_local int g_conv_layer = -1;                     // index of the layer being launched (run_network)
 inline int conv_rows_mode() {                           // 0: conv_bf16x3.hpp, 1: conv_rows.hpp, 2: conv_rows.hpp persistent
     static const int rows_mask = [] {
         if (const char *e = getenv("POCR_CONV_ROWS")) if (atoi(e) == 0) return 0;
         const char *m = getenv("POCR_CONV_ROWS_MASK");
-        return m ? (int)strtol(m, nullptr, 0) : 0x1BC;
+        return m ? (int)strtol(m, nullptr, 0) : 0x1FC;
     }();
     static const int pers_mask = [] { const char *m = getenv("POCR_CONV_PERSIST_MASK"); return m ? (int)strtol(m, nullptr, 0) : 0x4; }();
     const int l = g_conv_layer;
