@@ -48,6 +48,9 @@
 #ifndef POCR_STA_TAP
 #define POCR_STA_TAP (NTAP / 2)        // tap after which the next chunk's halo tile (requested at tap 0) is written to the other LDS buffer
 #endif
+#ifndef POCR_STAGE_PAD
+#define POCR_STAGE_PAD 16            // bytes of padding behind a staged pixel (conv_epilogue_staged): pixel stride = 4 dwords mod 64 banks
+#endif
 #ifndef POCR_FUSE1_STAGED
 #define POCR_FUSE1_STAGED 0          // 1: conv2 with conv1 in its prologue sends its pooled tile through LDS as whole lines too (measured: 1.183 against 1.174 ms - its output is a quarter of its input; off)
 #endif
@@ -229,7 +232,7 @@ __device__ __forceinline__ f32x4 conv1_mma_f16x2(u32x4 xh, u32x4 wh, u32x4 wl) {
 // TR = false: D[pixel 4 kq + r][channel li] (a lane holds four pixels of one channel), TR = true: D[channel 4 kq + r][pixel li]
 // (four consecutive channels of one pixel = one 8-byte piece of each P2 plane: no transpose in front of the stores).
 constexpr int conv_stage_units(int TH, int TW, int POOLH, int POOLW, int NT) {      // 16-byte units of conv_epilogue_staged's staging area
-    return ((TH / POOLH) * (TW / POOLW) * (NT * 4 + 32) + 15) / 16;
+    return ((TH / POOLH) * (TW / POOLW) * (NT * 4 + POCR_STAGE_PAD) + 15) / 16;
 }
 template <bool TR>
 __device__ __forceinline__ f32x4 mfma_conv_f16(u32x4 act, u32x4 w, f32x4 c) {
@@ -266,7 +269,7 @@ template <int TH, int MWW, int NS, int WM, int POOLH, int POOLW, int ACT, bool B
 __device__ __forceinline__ void conv_epilogue_staged(const f32x4 (&acc)[TH * MWW][NS], const f32x4 (&acc2)[TH * MWW][NS], const float *bias_p,
                                                      const float *scale_p, const float *shift_p, char *stage, float *yline, int h0, int w0, int Win,
                                                      int Ho, int out_stride, int nt, unsigned &rmax) {
-    constexpr int NTHR = 256, TWO = TW / POOLW, NPX = (TH / POOLH) * TWO, UPP = NT / 4, PBP = NT * 4 + 32;
+    constexpr int NTHR = 256, TWO = TW / POOLW, NPX = (TH / POOLH) * TWO, UPP = NT / 4, PBP = NT * 4 + POCR_STAGE_PAD;
     constexpr unsigned kOut = 0x80000000u;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const int wm = wave % WM, wn = wave / WM;
