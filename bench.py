@@ -789,7 +789,8 @@ def main():
             for older in ("r04_pmc_summary.json", "r03_pmc_summary.json"):
                 if not os.path.exists(os.path.join(REPO, "profiles", pmc_file)):
                     pmc_file = older
-            dom_sig = {2: "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false, 2, true, true",
+            rows_on = os.environ.get("POCR_CONV_ROWS", "1") != "0"     # (csrc/conv_rows.hpp runs conv9 in the default mode)
+            dom_sig = {2: "rows_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, false>" if rows_on else "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false, 2, true, true",
                        3: "bf16x3_kernel<5, 1, 2, 1, 1, 1, 2, true, 2, true, 3, 3, 1, 1, false>", 0: "5, 1, 4, 4, 16, 1, 1, 2, true"}[split]
             try:
                 pmc = json.load(open(os.path.join(REPO, "profiles", pmc_file)))
