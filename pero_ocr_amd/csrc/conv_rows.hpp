@@ -1,18 +1,23 @@
-// conv_rows.hpp — the recogniser's 3x3 convolutions (conv3 .. conv9 in the default f16x2 / P2 mode) as a PERSISTENT kernel:
-// a workgroup walks pixel tiles of ONE channel tile, and the step from a tile to the next one is an ordinary chunk step of
-// the halo-row streaming loop (conv_bf16x3.hpp "ROWS": same fragments, same MFMAs in the same order - the two kernels give
-// the same bits).
-//
-// Why: with one tile per workgroup every tile starts with a chain of memory round trips that nothing hides - tile descriptor
-// -> line descriptors -> the first halo tile and the first weight fragments -> LDS -> barrier: 4.5-5.3 us per tile in EVERY
-// layer (tools/conv_wino_bench.hip, phase stamps: conv3 5.2 of 13.8 us, conv4 4.8 of 18, conv5 5.3 of 22, conv6-8 ~4.6 of
-// 30, conv9 4.4 of 55), during which only the other workgroup of the CU feeds the matrix pipe (MFMA busy 0.59 in conv3).
-// Here the descriptors of tile t + 1 are scalar loads issued when tile t starts; chunk 0 of tile t + 1 is requested between the
-// main loop and the epilogue of tile t and lands while the epilogue computes and stores (result layout [channel][pixel]:
-// conv_bf16x3.hpp mfma_conv_f16<true>; buffer stores, no branches); the weight stream wraps to chunk 0 in the last chunk by
-// itself (same channel tile), so the next tile starts with one LDS write and one barrier.  Requires an even number of
-// 32-channel chunks (the weight-set parity then lines up: cin = 64, 128, 256, 512) and a block -> tile mapping that keeps a
-// workgroup on one channel tile (pocr_hip.hip: launch_conv_rows).
+// conv_rows.hpp — the recogniser's 3x3 convolutions conv3 .. conv9 in the default f16x2 / P2 mode (round 5).  The main loop is the
+// halo-row streaming loop of conv_bf16x3.hpp ("ROWS": same fragments, same MFMAs in the same order - the two kernels give the same
+// bits; tools/conv_wino_bench.hip and the GPU suite check that); what is different is everything around it, from taking the
+// one-tile kernel apart (profiles/r05_conv_rows.txt):
+//   * the weights are the MFMA's A operand (mfma_conv_f16<true>): the result is [channel][pixel], a lane holds four consecutive
+//     channels of one pixel, and the tile's output is put together in LDS and stored as whole 128-byte lines (conv_epilogue_staged:
+//     the epilogue's 32-byte pieces had cost conv3 a third of its time - the number of partial-line writes, not their bytes);
+//   * weights and activations come by buffer loads: one per-lane offset register each, (tap, chunk) as a scalar offset - no 64-bit
+//     vector address arithmetic in the loop (196-240 registers against 250); halo pixels outside the image carry an out-of-range
+//     mark and read as zeros.  STORES are never masked that way (conv_epilogue_staged says why);
+//   * channel constants (bias, batch-norm scale / shift) wait in LDS.
+// PERS = true is the PERSISTENT form: a grid of two workgroups per CU, each walking pixel tiles of ONE channel tile.  With one tile
+// per workgroup every tile starts with a chain of round trips that nothing inside the workgroup hides - tile descriptor -> line
+// descriptors -> first halo tile and weight fragments -> LDS -> barrier: 4.5-5.3 us per tile in every layer (conv3 5.2 of 13.8 us,
+// conv9 4.4 of 55).  Here the descriptors of tile t + 1 are scalar loads issued when tile t starts, chunk 0 of tile t + 1 is requested
+// between the main loop and the epilogue of tile t and lands while the epilogue runs, and the weight stream wraps to chunk 0 in the
+// last chunk by itself (same channel tile): the next tile starts with one LDS write and one barrier.  It needs an even number of
+// 32-channel chunks (the weight-set parity then lines up: cin = 64 .. 512) and a block -> tile mapping that keeps a workgroup on one
+// channel tile (pocr_hip.hip: launch_conv_rows).  Measured: the prologue disappears from the stamps and the main loop grows by as much -
+// the two workgroups of a CU had covered each other's prologue already; conv3 alone gains 8 % (shipped), the deeper layers lose 2-4 %.
 #pragma once
 #include "conv_bf16x3.hpp"
 
