@@ -1435,3 +1435,51 @@ def test_resident_recurrence_cross_xcd_protocol(tmp_path):
         outs.append(np.load(path))
     for k in ("logits", "amax", "labels", "lens"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("height", [40, 48])
+def test_conv_rows_kernels_are_bit_identical_to_the_one_tile_kernels(height, tmp_path):
+    """csrc/conv_rows.hpp (conv3 .. conv9 of the default mode: result laid out [channel][pixel], output tiles through LDS as whole
+    lines, buffer loads, optionally a persistent tile walk) against the conv_bf16x3.hpp kernels it replaces (POCR_CONV_ROWS=0): every
+    layer's activation, the logits and the labels bit for bit - ragged rows with empty / 1-pixel / maximum-width crops, tight and
+    generous paddings (padding-column skipping on both sides), a line height that is not a multiple of the tiles, and with every
+    layer in the persistent form.  The library reads these switches once: one process per mode.
+    Reference computation: aten::conv2d (+ ReLU / LeakyReLU / max_pool2d / batch_norm), transformer.py:51-72,86-144."""
+    if _native.conv_split() != 2:
+        pytest.skip("conv_rows.hpp belongs to the f16x2 arithmetic")
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+from pero_ocr_amd import _native, netspec, synth
+height, out = int(sys.argv[1]), sys.argv[2]
+spec = netspec.NetSpec(num_classes=61, height=height)
+weights = netspec.pack_weights(spec, netspec.generate_weights(spec, 77))
+widths = [300, 0, 1, 17, 640, 96, 33, 511, 64, 1000, 200, 5, 3840, 722, 714]
+crops = synth.make_crops(21, widths, height)
+pool = np.concatenate([c.reshape(-1) for c in crops])
+offs = np.concatenate([[0], np.cumsum([c.size for c in crops])[:-1]]).astype(np.int64)
+cases = [([-(-max(w, 1) // 32) * 32 + 64 for w in widths], 32), ([3904] * len(widths), 32)]
+res = {}
+eng = _native.NativeEngine(spec, weights, 0)
+for ci, (w_pads, pad_left) in enumerate(cases):
+    eng.slot_stage_ragged(0, pool, offs, np.array(widths, np.int32), w_pads, pad_left)
+    eng.slot_launch(0, want_logits=True, want_argmax=True)
+    logits, amax, labels, lens = eng.slot_collect(0)
+    for k in range(10):
+        res[f"c{ci}_a{k}"] = eng.debug_read(k)
+    res[f"c{ci}_logits"] = logits; res[f"c{ci}_amax"] = amax; res[f"c{ci}_labels"] = labels; res[f"c{ci}_lens"] = lens
+eng.close()
+np.savez(out, **res)
+"""
+    outs = {}
+    for mode, env in (("one_tile", {"POCR_CONV_ROWS": "0"}), ("rows", {}), ("rows_persistent", {"POCR_CONV_PERSIST_MASK": "0x7C"})):
+        out = os.path.join(str(tmp_path), mode + ".npz")
+        r = subprocess.run([sys.executable, "-c", code, str(height), out], cwd=REPO, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = np.load(out)
+    ref = outs["one_tile"]
+    for mode in ("rows", "rows_persistent"):
+        for k in ref.files:
+            assert np.array_equal(ref[k], outs[mode][k]), f"{mode}: {k} differs from the one-tile kernels"
