@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import json
 import os
+import threading
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -27,6 +28,17 @@ import numpy as np
 from scipy import sparse
 
 from .softmax import softmax
+
+# The reference prints its warnings (line_ocr_engine.py:125-127); here engines run on several threads (page stream: front workers
+# next to the recogniser's thread, sharded ranks' helpers), and concurrent print() calls race inside CPython 3.10's TextIOWrapper -
+# freed pending-bytes objects, i.e. arbitrary heap contents, reach the output (seen in tools/stress_resident.py: binary junk between
+# the warnings of three threads, none with one lock around print).
+_PRINT_LOCK = threading.Lock()
+
+
+def print_warning(text: str) -> None:
+    with _PRINT_LOCK:
+        print(text)
 
 SPARSE_PROB_THRESHOLD = 0.0001     # line_ocr_engine.py:170
 
@@ -341,8 +353,8 @@ class BaseEngineLineOCR:
 
         for chunk in chunks:
             if chunk.max_width + 2 * pad > chunk.w_pad:
-                print(f"WARNING: Line too long for OCR engine. Cropping from {chunk.max_width + 2 * pad} px "
-                      f"down to {chunk.w_pad}.")
+                print_warning(f"WARNING: Line too long for OCR engine. Cropping from {chunk.max_width + 2 * pad} px "
+                              f"down to {chunk.w_pad}.")
         if not hasattr(self, "_submit_launch"):          # engines without the asynchronous ragged path: chunk after chunk
             for chunk in chunks:
                 scatter(chunk.line_ids, *self._recognise_chunk(lines, chunk, want_logits=not no_logits))

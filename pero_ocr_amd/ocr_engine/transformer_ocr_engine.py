@@ -30,7 +30,7 @@ import numpy as np
 from scipy import sparse
 
 from .. import _native, netspec
-from .line_ocr_engine import (BaseEngineLineOCR, SPARSE_PROB_THRESHOLD, ceil32, merge_transcriptions_and_logits)
+from .line_ocr_engine import (BaseEngineLineOCR, SPARSE_PROB_THRESHOLD, ceil32, merge_transcriptions_and_logits, print_warning)
 from .pytorch_ocr_engine import _device_index
 from .softmax import softmax
 
@@ -242,8 +242,8 @@ class TransformerEngineLineOCR(BaseEngineLineOCR):
         batches = plan_batches([l.shape[1] for l in lines], self.max_input_horizontal_pixels, self.max_line_width, pad)
         for b in batches:
             if b.max_width + 2 * pad > b.w_batch:
-                print(f"WARNING: Line too long for OCR engine. Cropping from {b.max_width + 2 * pad} px "
-                      f"down to {b.w_batch}.")
+                print_warning(f"WARNING: Line too long for OCR engine. Cropping from {b.max_width + 2 * pad} px "
+                              f"down to {b.w_batch}.")
         transcriptions: List[Optional[str]] = [None] * n
         logits_out: List[object] = [None] * n
         coords_out: List[Optional[list]] = [None] * n

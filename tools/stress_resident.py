@@ -23,6 +23,15 @@ class Dev:
 
 
 def main():
+    # (the engines warn about over-long lines with print(): three threads printing at once race inside CPython 3.10's TextIOWrapper -
+    #  freed pending-bytes objects, i.e. arbitrary heap contents, end up in the output.  One lock around print keeps the log readable.)
+    import builtins
+    _print, _lock = builtins.print, threading.Lock()
+
+    def locked_print(*a, **k):
+        with _lock:
+            _print(*a, **k)
+    builtins.print = locked_print
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     n_threads = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     chars = synth.make_charset(99)
