@@ -51,6 +51,9 @@ RP(r3, 10, 1, 1, 1, 1, 1, ACT_RELU, false, 2)
 // experiment: 5 x 16 x 64 tiles, three workgroups per CU (POCR_ROWS_ALT=1)
 RP(r56_5, 5, 1, 1, 1, 1, 1, ACT_RELU, false, 3)
 RP(r4_4, 4, 1, 1, 1, 2, 2, ACT_RELU, false, 3)
+// experiment: the 5-row layers on 5 x 32 x 64 tiles (a wave: ten 16-pixel strips x 16 channels, like the 10 x 16 x 64 tile) (POCR_ROWS_ALT=2)
+RP(r9_w, 5, 2, 1, 1, 1, 1, ACT_LEAKY, true, 2)
+RP(r8_w, 5, 2, 1, 1, 1, 1, ACT_LEAKY, false, 2)
 // experiment: the direct kernel with its waves splitting PIXELS, weights shared through LDS (fewer bytes from L2 per output)
 VP(x9_22, 5, 2, 2, 2, 1, 1, ACT_LEAKY, true, 2, false)     // 5x32 px x 64 ch, waves 2 (px) x 2 (ch)
 VP(x9_41, 5, 4, 2, 4, 1, 1, ACT_LEAKY, true, 2, false)     // 5x64 px x 32 ch, waves 4 (px)
@@ -278,8 +281,11 @@ int main(int argc, char **argv) {
 #endif
         if (is_w) { a.x_bytes = (uint32_t)(xin * 4); a.wtiles = dwt; a.n_ptiles = (int)wt.size(); a.line_w = dlw; a.in_off = dio; a.out_off = doo; }
         auto run = [&]() {
-            static const bool alt = getenv("POCR_ROWS_ALT") && atoi(getenv("POCR_ROWS_ALT"));
-            if (vi == 2 && alt && (layer == 3 || layer == 5 || layer == 6)) r56_5(a, st);
+            static const int altv = getenv("POCR_ROWS_ALT") ? atoi(getenv("POCR_ROWS_ALT")) : 0;
+            const bool alt = altv == 1;
+            if (vi == 2 && altv == 2 && layer == 9) r9_w(a, st);
+            else if (vi == 2 && altv == 2 && layer == 8) r8_w(a, st);
+            else if (vi == 2 && alt && (layer == 3 || layer == 5 || layer == 6)) r56_5(a, st);
             else if (vi == 2 && alt && layer == 4) r4_4(a, st);
             else if (vi == 2) { switch (layer) { case 9: r9(a, st); break; case 8: r8(a, st); break; case 7: r7(a, st); break; case 6: case 5: r56(a, st); break; case 4: r4(a, st); break; default: r3(a, st); } }
             else if (vi >= 3) { switch (vi) { case 3: x9_22(a, st); break; case 4: x9_41(a, st); break; case 5: x9_42(a, st); break; case 6: x9_24(a, st); break; case 7: x9_r22(a, st); break; default: x9_r41(a, st); } }
