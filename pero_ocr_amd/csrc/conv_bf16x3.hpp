@@ -21,62 +21,21 @@
 #include <stdint.h>
 #include <utility>
 #include "conv_igemm.hpp"
-#ifndef POCR_BF16X3_SCHED
-#define POCR_BF16X3_SCHED 1            // issue-order templates (sched_group_barrier) in the main loops: -2 ... -9 % per layer, same arithmetic
-#endif
-#ifndef POCR_BDIR_SETS
-#define POCR_BDIR_SETS 3               // register sets of weight fragments in the direct-weights loop: the set of step s + SETS - 1 is requested while step s computes
-#endif
-#ifndef POCR_CONV_ROWSTREAM
-#define POCR_CONV_ROWSTREAM 1          // 3x3 / f16x2 / direct-weights layers: halo-row streaming main loop (below); 0 = the tap-by-tap loop
-#endif
-#ifndef POCR_ROW_AHEAD
-#define POCR_ROW_AHEAD 2               // row streaming: A fragments requested this many (row, strip) units before the MFMAs that use them
-#endif
-#ifndef POCR_ROW_LDA_Q
-#define POCR_ROW_LDA_Q 3               // row streaming: the next chunk's halo tile is requested after this unit of the chunk's first group (after the
-#endif                                 // weight requests of units 0..2: vmcnt counts in order, so a load issued BEFORE them must land before the next group starts)
-#ifndef POCR_ROW_STA_DX
-#define POCR_ROW_STA_DX 2              // ... and written to the other LDS buffer after this group (2 = right before the chunk's barrier)
-#endif
-#ifndef POCR_GEMM_PIPE
-#define POCR_GEMM_PIPE 1               // 1x1 (GEMM mode) f16x2 layers with LDS weights: double-buffered A and B tiles, one barrier per 32-deep chunk
-#endif
-#ifndef POCR_BDIR_APRE
-#define POCR_BDIR_APRE 1               // tap-by-tap direct-weights loop, f16x2, MS <= 4: A fragments read one tap ahead
-#endif
-#ifndef POCR_STA_TAP
-#define POCR_STA_TAP (NTAP / 2)        // tap after which the next chunk's halo tile (requested at tap 0) is written to the other LDS buffer
-#endif
-#ifndef POCR_STAGE_PAD
-#define POCR_STAGE_PAD 16            // bytes of padding behind a staged pixel (conv_epilogue_staged): pixel stride = 4 dwords mod 64 banks
-#endif
-#ifndef POCR_FUSE1_STAGED
-#define POCR_FUSE1_STAGED 0          // 1: conv2 with conv1 in its prologue sends its pooled tile through LDS as whole lines too (measured: 1.183 against 1.174 ms - its output is a quarter of its input; off)
-#endif
-#ifndef POCR_EPI_T
-#define POCR_EPI_T 1                 // f16x2 kernels that write P2: weights as the MFMA's A operand, so a lane ends up with four consecutive channels of one pixel (the epilogue below "TR")
-#endif
-#ifndef POCR_CONV_STAGGER
-#define POCR_CONV_STAGGER 0          // experiment: units of 8128 cycles by which the second workgroup of a CU starts late (first dispatch round only)
-#endif
-#ifndef POCR_CONV_STAGGER_BLOCKS
-#define POCR_CONV_STAGGER_BLOCKS 512
-#endif
-#ifdef POCR_BF16X3_TRACE               // tools/conv_ablate.hip: per-workgroup phase stamps (100 MHz wall clock) + where it ran
-__device__ unsigned long long g_conv_trace[1 << 18];
-#define POCR_TRACE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < (1u << 15)) g_conv_trace[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
-#else
-#define POCR_TRACE_STAMP(k) do { } while (0)
-#endif
-#ifndef POCR_LDA_BUFFER
-#define POCR_LDA_BUFFER 0              // experiment (P2 input): the halo tile through bounds-checked buffer loads (padding = an offset beyond the descriptor) instead of conditional loads
-#endif
-#ifndef POCR_BF16X3_DBG
-#define POCR_BF16X3_DBG 0            // tools/conv_bench_bf16.hip: 1 no A reads, 2 no weight loads, 4 no A staging, 8 no barrier
-#endif
 
 namespace pocr {
+
+// Tuning constants of the loops below (each was a compile-time knob while it was being measured: profiles/r02_conv_bf16x3_bench.txt,
+// r03_conv_rowstream.txt, r05_conv_rows.txt; the losing settings and the ablation / trace switches were removed in round 6).
+constexpr int kBdirSets = 3;     // register sets of weight fragments in the direct-weights loop: the set of step s + kBdirSets - 1 is requested while step s computes
+constexpr int kRowAhead = 2;     // row streaming: A fragments requested this many (row, strip) units before the MFMAs that use them
+constexpr int kRowLdaQ = 3;      // row streaming: the next chunk's halo tile is requested after this unit of the chunk's first group (after the weight
+                                 // requests of units 0..2: vmcnt counts in order, so a load issued BEFORE them must land before the next group starts)
+constexpr int kRowStaDx = 2;     // ... and written to the other LDS buffer after this group (2 = right before the chunk's barrier)
+constexpr int kStagePad = 16;    // bytes of padding behind a staged pixel (conv_epilogue_staged): pixel stride = 4 dwords mod 64 banks
+// Fixed design choices that used to be switches: issue-order templates (sched_group_barrier) in the main loops (-2 ... -9 % per layer); the
+// halo-row streaming loop for the 3x3 / f16x2 / direct-weights layers; double-buffered A and B tiles in the 1x1 (GEMM mode) f16x2 layers
+// with LDS weights; A fragments read one tap ahead in the tap-by-tap direct-weights loop (f16x2, MS <= 4); the next chunk's halo tile
+// written to the other LDS buffer after tap NTAP / 2; f16x2 kernels that write P2 take the weights as the MFMA's A operand ("TR").
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -102,7 +61,10 @@ __device__ __forceinline__ void split3_bf16(const f32x4 &p, const f32x4 &q, u32x
     }
 }
 
-#define POCR_MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+template <class TA, class TB>
+__device__ __forceinline__ f32x4 mfma16_bf16(const TA a, const TB b, const f32x4 c) {       // operands: any 16-byte vector of eight bf16
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 // split of one float4 (4 consecutive channels) into three pairs of packed bf16 (8 bytes per plane)
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -136,7 +98,10 @@ __device__ __forceinline__ void split3_quad(const f32x4 p, u32x2 &hi, u32x2 &mid
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-#define POCR_MFMA_F16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
+template <class TA, class TB>
+__device__ __forceinline__ f32x4 mfma16_f16(const TA a, const TB b, const f32x4 c) {        // operands: any 16-byte vector of eight f16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 constexpr float kF16x2Scale = 2048.0f;
 
 // x -> (h, l): h = f16(x), l = f16((x - h) * 2^11), round to nearest even.  (Tried: l = f16(fma(h, -2^11, 2^11 x)) on v_fma_mixlo /
@@ -219,8 +184,8 @@ __device__ __forceinline__ f32x4 conv1_relu_note(const f32x4 d, unsigned &m) {
 }
 __device__ __forceinline__ f32x4 conv1_mma_f16x2(u32x4 xh, u32x4 wh, u32x4 wl) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 acc2 = POCR_MFMA_F16(wl, xh, z);
-    const f32x4 acc = POCR_MFMA_F16(wh, xh, z);
+    const f32x4 acc2 = mfma16_f16(wl, xh, z);
+    const f32x4 acc = mfma16_f16(wh, xh, z);
     f32x4 d;
 #pragma unroll
     for (int r = 0; r < 4; ++r) d[r] = __builtin_fmaf(acc2[r], 1.0f / kF16x2Scale, acc[r]);
@@ -232,12 +197,12 @@ __device__ __forceinline__ f32x4 conv1_mma_f16x2(u32x4 xh, u32x4 wh, u32x4 wl) {
 // TR = false: D[pixel 4 kq + r][channel li] (a lane holds four pixels of one channel), TR = true: D[channel 4 kq + r][pixel li]
 // (four consecutive channels of one pixel = one 8-byte piece of each P2 plane: no transpose in front of the stores).
 constexpr int conv_stage_units(int TH, int TW, int POOLH, int POOLW, int NT) {      // 16-byte units of conv_epilogue_staged's staging area
-    return ((TH / POOLH) * (TW / POOLW) * (NT * 4 + POCR_STAGE_PAD) + 15) / 16;
+    return ((TH / POOLH) * (TW / POOLW) * (NT * 4 + kStagePad) + 15) / 16;
 }
 template <bool TR>
 __device__ __forceinline__ f32x4 mfma_conv_f16(u32x4 act, u32x4 w, f32x4 c) {
-    if constexpr (TR) return POCR_MFMA_F16(w, act, c);
-    else return POCR_MFMA_F16(act, w, c);
+    if constexpr (TR) return mfma16_f16(w, act, c);
+    else return mfma16_f16(act, w, c);
 }
 
 // Issue-order template for the scheduler (LDS-weights loop): the G operand reads of a step spread evenly between its TOT MFMAs.
@@ -269,7 +234,7 @@ template <int TH, int MWW, int NS, int WM, int POOLH, int POOLW, int ACT, bool B
 __device__ __forceinline__ void conv_epilogue_staged(const f32x4 (&acc)[TH * MWW][NS], const f32x4 (&acc2)[TH * MWW][NS], const float *bias_p,
                                                      const float *scale_p, const float *shift_p, char *stage, float *yline, int h0, int w0, int Win,
                                                      int Ho, int out_stride, int nt, unsigned &rmax) {
-    constexpr int NTHR = 256, TWO = TW / POOLW, NPX = (TH / POOLH) * TWO, UPP = NT / 4, PBP = NT * 4 + POCR_STAGE_PAD;
+    constexpr int NTHR = 256, TWO = TW / POOLW, NPX = (TH / POOLH) * TWO, UPP = NT / 4, PBP = NT * 4 + kStagePad;
     constexpr unsigned kOut = 0x80000000u;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const int wm = wave % WM, wn = wave / WM;
@@ -334,11 +299,22 @@ __device__ __forceinline__ void conv_epilogue_staged(const f32x4 (&acc)[TH * MWW
             const int g = it * NTHR + tid, sp = g / UPP, unit = g % UPP, row = sp / TWO, col = sp % TWO;
             const bool ok = ((NPX * UPP) % NTHR == 0 || sp < NPX) && row < rows_ok && col < cols_ok;
             const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + (unsigned)sp * PBP + (unsigned)unit * 16u);
-            // (a branch around the store, NOT an out-of-range offset for the lanes outside the image: stores masked that way - mark
-            // 0x80000000 or 0x7FFF0000, the tile's position in the scalar offset - left rare wrong low planes in the activations of a
-            // launch running at the same time, 5-6 of 6 fresh engines with three launches in flight (tools/three_in_flight.py); why
-            // is not understood.  Loads masked by the mark - the halo's zero padding - pass every bit-identity test.)
+            // A branch around the store, NOT an out-of-range offset for the lanes outside the image.  Masked that way the stores are
+            // dropped correctly (tools/masked_store_probe.hip) - but without a branch between consecutive stores the scheduler puts the
+            // next store's address arithmetic into the data register the previous one just freed:
+            //     buffer_store_dwordx4 v[2:5], v22, s[4:7], s11 offen ; v_lshrrev_b32 v2, 5, v1
+            // and on gfx950 a store of more than 64 bits WITH an SGPR offset still needs one wait state before a VALU write of its data
+            // registers (without the offset: two); LLVM's hazard recogniser pads only the second case.  Under load the store then writes the
+            // LATER value of v2: wrong dwords in this kernel's own output, 1.8 % of the stores in tools/store_hazard_probe.hip, every fresh
+            // engine in tools/three_in_flight.py (round 5's "rare wrong low planes ... why is not understood").  The branching form never has
+            // a VALU write of a data register behind a store; tests/test_host.py::test_no_kernel_has_the_store_data_hazard scans every
+            // kernel of the built library for the pair.  Loads masked by the mark - the halo's zero padding - have no data registers to
+            // lose and read zeros.  profiles/r06_store_hazard.txt.
+#if POCR_EPI_MASKED_STORE        // (tools/masked_store_repro.sh builds this variant into tools/bin to study the effect; never shipped)
+            __builtin_amdgcn_raw_buffer_store_b128(val, yrsrc, (int)(ok ? (unsigned)(row * Wout + col) * pix_bytes + (unsigned)unit * 16u : kOut), (int)tile_off, 0);
+#else
             if (ok) __builtin_amdgcn_raw_buffer_store_b128(val, yrsrc, (int)((unsigned)(row * Wout + col) * pix_bytes + (unsigned)unit * 16u), (int)tile_off, 0);
+#endif
         }
         __syncthreads();                                             // (the staging area is the next tile's A buffer again)
 }
@@ -363,13 +339,13 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     // ReLU, from the uint8 crops: conv1_u8.hpp) for the pixels of its own halo tile straight into the two A buffers in LDS.
     // conv1's output (1.5 GB per 256-line launch, written at 2.9 TB/s and read back by conv2) then does not exist; the price
     // is conv1 recomputed on the halo overlap, 168 extra MFMAs per workgroup against 2160.
-    static_assert(!FUSE1 || (PRE_IN && BDIR && KH == 3 && KW == 3 && SPL == 2 && POCR_CONV_ROWSTREAM), "FUSE1 rides on the row-streaming P2 loop");
+    static_assert(!FUSE1 || (PRE_IN && BDIR && KH == 3 && KW == 3 && SPL == 2), "FUSE1 rides on the row-streaming P2 loop");
     // PRE_IN: the input is in the P2 (pre-split) layout; PRE_OUT: the epilogue writes that layout (both f16x2 only)
     static_assert(!(PRE_IN || PRE_OUT) || SPL == 2, "the pre-split activation layout is the f16x2 representation");
     static_assert(!(PRE_IN && UPCAT), "the layout network keeps fp32 activations");
     // SPL = planes per operand: 3 = bf16x3 (six MFMAs per 32-deep product block), 2 = f16x2 (three)
     static_assert(SPL == 2 || SPL == 3, "operand split: 3 bf16 planes or 2 f16 planes");
-    constexpr bool TR = SPL == 2 && PRE_OUT && POCR_EPI_T != 0;      // result layout [channel][pixel] (mfma_conv_f16) and the epilogue written for it
+    constexpr bool TR = SPL == 2 && PRE_OUT;      // result layout [channel][pixel] (mfma_conv_f16) and the epilogue written for it
     constexpr int NWAVE = 4, WN = NWAVE / WM, KC = 32, NTAP = KH * KW, WU = SPL * 64, NMF = SPL == 3 ? 6 : 3;
     static_assert(MW % WM == 0, "column strips must divide among the M waves");
     constexpr int TW = 16 * MW, MWW = MW / WM, MS = TH * MWW, NT = NS * WN * 16, NTHR = 256;
@@ -386,7 +362,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     // a 9-tap chunk amortises and a 1-tap chunk does not -> own loop, A double-buffered (+5 %: profiles/r03_gemm_pipe.txt; the same
     // loop with the weights straight from L2 - one register set, reloaded channel tile by channel tile - measured the same
     // 210 TFLOP/s on the 53248 x 512 x 2048 projection, so it is not the LDS traffic that holds this tile shape at ~37 % MFMA issue)
-    constexpr bool GEMM2 = !BDIR && NTAP == 1 && SPL == 2 && POCR_GEMM_PIPE && POCR_BF16X3_DBG == 0;
+    constexpr bool GEMM2 = !BDIR && NTAP == 1 && SPL == 2;
     constexpr int A_BUFS = (BDIR || GEMM2) ? 2 : 1;
     constexpr int F1_PW = HW + 2, F1_N = (HH + 2) * F1_PW * 3;            // FUSE1: conv1's input patch ([row][col][c] floats) behind the A buffers
     constexpr int F1_Z = kConv1Tail + (2 * F1_PW + 3) * 3;            // the patch's tail + a zero 3 x 3 x 3 neighbourhood (conv1_x_frag)
@@ -397,23 +373,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const int wm = wave % WM, wn = wave / WM;
 
-    POCR_TRACE_STAMP(0);
-#if POCR_CONV_STAGGER
-    {   // (experiment) de-phase the workgroups that share a CU: the one whose LDS allocation does not start at 0 begins late
-        unsigned la;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(la));
-        if ((la & 0xffu) != 0u && blockIdx.x < POCR_CONV_STAGGER_BLOCKS)
-            for (int q = 0; q < POCR_CONV_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-#ifdef POCR_BF16X3_TRACE
-    if (threadIdx.x == 0 && blockIdx.x < (1u << 15)) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_conv_trace[blockIdx.x * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
-    }
-#endif
     // block -> tile mapping (as conv_igemm_kernel)
     int nt, ptile;
     {
@@ -499,21 +458,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     const f32x4 *wt4 = reinterpret_cast<const f32x4 *>(a.wfrag) + (size_t)nt * (NT / 16) * WU;      // WU x 16 B per cout tile
     const size_t chunk_stride = (size_t)a.cout16 * WU, tap_stride = (size_t)nchunks * chunk_stride;
     f32x4 ra[A_LD], rb[B_LD];
-#if POCR_LDA_BUFFER
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)0xF0000000u, 0x00020000);
-    unsigned xbo[A_LD];
-#pragma unroll
-    for (int r = 0; r < A_LD; ++r) xbo[r] = (PRE_IN && a_ok[r]) ? (unsigned)(img_base * 4) + a_off[r] * 16u : 0xF0000000u;
-#endif
     auto ldA = [&](int chunk) {
 #pragma unroll
         for (int r = 0; r < A_LD; ++r) {
             if constexpr (PRE_IN) {
-#if POCR_LDA_BUFFER
-                ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)xbo[r], chunk * 128, 0));
-#else
                 ra[r] = a_ok[r] ? reinterpret_cast<const f32x4 *>(ximg)[a_off[r] + chunk * 8] : (f32x4){0.f, 0.f, 0.f, 0.f};
-#endif
                 continue;
             }
             const float *src = ximg + chunk * KC + a_off[r];
@@ -561,7 +510,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     // f16x2 3x3: the tap-by-tap loops walk the taps column by column (dx outer, dy inner) - the order in which the row-streaming
     // loop adds them up - so that every f16x2 build of a layer gives the same bits whatever loop and tile it uses
     auto tap_w = [](int t) { return (SPL == 2 && KH == 3 && KW == 3) ? (t % 3) * 3 + t / 3 : t; };
-    constexpr bool ROWS = BDIR && POCR_CONV_ROWSTREAM && KH == 3 && KW == 3 && SPL == 2 && POCR_BF16X3_DBG == 0;
+    constexpr bool ROWS = BDIR && KH == 3 && KW == 3 && SPL == 2;
     if constexpr (ROWS) {
     // ---- halo-row streaming (3x3, f16x2, weights straight from L2).  The tap-by-tap loop reads every A fragment once per
     // tap - 9 x MS reads of (h, l) per chunk, each issued right before the MFMAs that need it, so a wave sits out the LDS
@@ -569,11 +518,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     // chunk is walked column offset by column offset (dx), and inside one dx halo row by halo row: the fragment of halo row j
     // (pixels j, dx .. dx + 15) is the A operand of output row j - dy for all three dy, so it is read ONCE and used by up to
     // 3 x 3 NS MFMAs: 3 (TH + 2) reads per chunk instead of 9 TH (2.1x fewer for TH = 5), and each read is requested
-    // POCR_ROW_AHEAD units before its first use (a ring of register pairs).  The three taps (dy, dx) of a column offset are
+    // kRowAhead units before its first use (a ring of register pairs).  The three taps (dy, dx) of a column offset are
     // needed together: two sets of 3 taps of weight fragments, the set of the next (chunk, dx) group requested while the
     // current one computes (~1400 cycles of MFMA issue ahead).  Accumulation order per output element: chunk, dx, dy.
     const u32x4 *wq = reinterpret_cast<const u32x4 *>(wt4) + (wn * NS) * WU + lane;
-    constexpr int NROW = TH + 2, NU = NROW * MWW, AH = POCR_ROW_AHEAD, RING = AH + 1;
+    constexpr int NROW = TH + 2, NU = NROW * MWW, AH = kRowAhead, RING = AH + 1;
     static_assert(NU >= 3 && AH >= 1 && AH <= NU, "row streaming: units per column offset");
     u32x4 bw[2][3][NS][2], ar[RING][2];
     auto ldW = [&](u32x4 (&dst)[NS][2], const u32x4 *tile) {
@@ -653,7 +602,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         stA(0);
     }
     __syncthreads();
-    POCR_TRACE_STAMP(1);
     for (int c0 = 0; c0 < nchunks; c0 += 2) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {                    // two chunks = six groups: the weight-set parity is static
@@ -671,7 +619,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                     const int qq = dx * NU + q, pq = qq + AH;
                     if (pq < 3 * NU) rdA(ar[pq % RING], abuf, pq / NU, pq % NU);
                     if (q < 3) ldW(bw[par ^ 1][q], wtap(nchunk, q * 3 + ndx));
-                    if (!FUSE1 && dx == 0 && q == (POCR_ROW_LDA_Q < NU ? POCR_ROW_LDA_Q : NU - 1)) ldA(chunk + 1 < nchunks ? chunk + 1 : chunk);
+                    if (!FUSE1 && dx == 0 && q == (kRowLdaQ < NU ? kRowLdaQ : NU - 1)) ldA(chunk + 1 < nchunks ? chunk + 1 : chunk);
                     const int j = q / MWW, mw = q % MWW;
                     const u32x4 ah = ar[qq % RING][0], al = ar[qq % RING][1];
 #pragma unroll
@@ -689,7 +637,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);   // units stay in source order: reads of unit q + AH, then the MFMAs of unit q
                 }
-                if (!FUSE1 && dx == POCR_ROW_STA_DX) stA(abuf ^ 1);   // the other A buffer: its last readers passed the barrier of the previous chunk
+                if (!FUSE1 && dx == kRowStaDx) stA(abuf ^ 1);   // the other A buffer: its last readers passed the barrier of the previous chunk
             }
             __syncthreads();
         }
@@ -706,7 +654,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     ldA(nchunks > 1 ? 1 : 0);
     ldB(wt4 + (size_t)(nchunks > 1 ? 1 : 0) * chunk_stride);
     __syncthreads();
-    POCR_TRACE_STAMP(1);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int cur = chunk & 1;
         const u32x4 *Ab = ldsA + cur * A_U + li + kq * NPPAD + wm * MWW * 16;
@@ -747,8 +694,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     // three register sets of weight fragments, rotated with the step (statically: 9 taps = 3 x 3; other tap counts unroll
     // three chunks): the set of step s + 2 is requested while step s computes - two steps (~2000 cycles) cover an L2
     // miss, one does not
-    constexpr int NSETS = POCR_BDIR_SETS, AHEAD = NSETS - 1;
-    constexpr bool APRE = SPL == 2 && MS <= 4 && POCR_BDIR_APRE && POCR_BF16X3_DBG == 0;
+    constexpr int NSETS = kBdirSets, AHEAD = NSETS - 1;
+    constexpr bool APRE = SPL == 2 && MS <= 4;
     u32x4 bw[NSETS][NS][SPL];
     u32x4 apre[APRE ? 2 : 1][APRE ? MS : 1][2];
     auto ldW = [&](u32x4 (&dst)[NS][SPL], const u32x4 *tile) {
@@ -768,7 +715,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     for (int q = 0; q < AHEAD; ++q) ldW(bw[q], wstep(q));
     stA(0);
     __syncthreads();
-    POCR_TRACE_STAMP(1);
     for (int c0 = 0; c0 < nchunks; c0 += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -779,21 +725,13 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             // no conditionals around the prefetches (the last chunk re-reads itself): the compiler then counts the loads in
             // flight exactly (s_waitcnt vmcnt(n)) instead of draining the queue wherever control flow merges
             const int chunk_n = next_chunk ? chunk + 1 : chunk;
-#if !(POCR_BF16X3_DBG & 4)
             ldA(chunk_n);
-#endif
 #pragma unroll
             for (int tap = 0; tap < NTAP; ++tap) {
                 const int sl = u * NTAP + tap;            // step within the unrolled body: static
-#if !(POCR_BF16X3_DBG & 2)
                 ldW(bw[(sl + AHEAD) % NSETS], wstep(chunk * NTAP + tap + AHEAD));
-#endif
                 const int dy = tap_w(tap) / KW, dx = tap_w(tap) % KW;
-#if POCR_BF16X3_DBG & 1
-                const u32x4 *Ab = ldsA + li + kq * NPPAD;
-#else
                 const u32x4 *Ab = ldsA + abuf * A_U + dy * HW + dx + li + kq * NPPAD + wm * MWW * 16;
-#endif
                 u32x4 (&bc)[NS][SPL] = bw[sl % NSETS];
                 // f16x2, few row strips (the aggregation conv: 18 MFMAs per step): the A fragments of tap t + 1 are read while tap t
                 // multiplies (within a chunk: the other A buffer is only valid behind the chunk's barrier)
@@ -813,12 +751,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                 for (int m = 0; m < MS; ++m) {
                     const int o = (m / MWW) * HW + (m % MWW) * 16;
                     if constexpr (SPL == 2) {
-#if POCR_BF16X3_DBG & 1
-                        const u32x4 ah = bc[0][0] ^ (unsigned)m, al = bc[0][1] ^ (unsigned)m;
-                        (void)o; (void)Ab;
-#else
                         const u32x4 ah = APRE ? apre[tap & 1][m][0] : Ab[o], al = APRE ? apre[tap & 1][m][1] : Ab[o + PS];
-#endif
 #pragma unroll
                         for (int n = 0; n < NS; ++n) acc2[m][n] = mfma_conv_f16<TR>(al, bc[n][0], acc2[m][n]);
 #pragma unroll
@@ -826,39 +759,28 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
                         for (int n = 0; n < NS; ++n) acc2[m][n] = mfma_conv_f16<TR>(ah, bc[n][1], acc2[m][n]);
                     } else {
-#if POCR_BF16X3_DBG & 1
-                    const u32x4 ah = bc[0][0] ^ (unsigned)m, am = bc[0][1] ^ (unsigned)m, al = bc[0][SPL - 1] ^ (unsigned)m;     // no LDS reads
-                    (void)o; (void)Ab;
-#else
                     const u32x4 ah = Ab[o], am = Ab[o + PS], al = Ab[o + 2 * PS];
-#endif
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(al, bc[n][0], acc2[m][n]);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = mfma16_bf16(al, bc[n][0], acc2[m][n]);
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_BF16(ah, bc[n][0], acc[m][n]);
+                    for (int n = 0; n < NS; ++n) acc[m][n] = mfma16_bf16(ah, bc[n][0], acc[m][n]);
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bc[n][1], acc2[m][n]);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = mfma16_bf16(am, bc[n][1], acc2[m][n]);
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bc[n][SPL - 1], acc2[m][n]);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = mfma16_bf16(ah, bc[n][SPL - 1], acc2[m][n]);
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bc[n][0], acc2[m][n]);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = mfma16_bf16(am, bc[n][0], acc2[m][n]);
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bc[n][SPL - 2], acc2[m][n]);
+                    for (int n = 0; n < NS; ++n) acc2[m][n] = mfma16_bf16(ah, bc[n][SPL - 2], acc2[m][n]);
                     }
                 }
-#if POCR_BF16X3_SCHED
                 // issue order of one step, as a template for the scheduler: the A reads and the weight loads of the step after
                 // next spread between the MFMAs instead of bunched where the source puts them (mask 8 MFMA, 0x100 DS read, 0x20 VMEM read)
                 // one A read per group of TOT / G MFMAs; NV weight loads spread over the G groups
                 sched_template_dir<MS * SPL, MS * NS * NMF, NS * SPL>(std::make_integer_sequence<int, MS * SPL>{});
-#endif
-#if !(POCR_BF16X3_DBG & 4)
-                if (tap == POCR_STA_TAP) stA(abuf ^ 1);   // the other A buffer: its last readers passed the barrier of the previous chunk
-#endif
+                if (tap == (NTAP / 2)) stA(abuf ^ 1);   // the other A buffer: its last readers passed the barrier of the previous chunk
             }
-#if !(POCR_BF16X3_DBG & 8)
             __syncthreads();
-#endif
         }
     }
     } else {
@@ -867,7 +789,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
     stA();
     stB(0);
     __syncthreads();
-    POCR_TRACE_STAMP(1);
     int step = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool next_chunk = chunk + 1 < nchunks;
@@ -902,21 +823,19 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
                 // small terms round at their own magnitude, 2^-8 of the main one.  Measured against float64: 3x closer than
                 // the fp32-MFMA chain.  Terms outermost, so consecutive MFMAs never depend on each other.
 #pragma unroll
-                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(al, bh[n], acc2[m][n]);
+                for (int n = 0; n < NS; ++n) acc2[m][n] = mfma16_bf16(al, bh[n], acc2[m][n]);
 #pragma unroll
-                for (int n = 0; n < NS; ++n) acc[m][n] = POCR_MFMA_BF16(ah, bh[n], acc[m][n]);
+                for (int n = 0; n < NS; ++n) acc[m][n] = mfma16_bf16(ah, bh[n], acc[m][n]);
 #pragma unroll
-                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bm[n], acc2[m][n]);
+                for (int n = 0; n < NS; ++n) acc2[m][n] = mfma16_bf16(am, bm[n], acc2[m][n]);
 #pragma unroll
-                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bl[n], acc2[m][n]);
+                for (int n = 0; n < NS; ++n) acc2[m][n] = mfma16_bf16(ah, bl[n], acc2[m][n]);
 #pragma unroll
-                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(am, bh[n], acc2[m][n]);
+                for (int n = 0; n < NS; ++n) acc2[m][n] = mfma16_bf16(am, bh[n], acc2[m][n]);
 #pragma unroll
-                for (int n = 0; n < NS; ++n) acc2[m][n] = POCR_MFMA_BF16(ah, bm[n], acc2[m][n]);
+                for (int n = 0; n < NS; ++n) acc2[m][n] = mfma16_bf16(ah, bm[n], acc2[m][n]);
             }
-#if POCR_BF16X3_SCHED
             sched_template_lds<(MS + NS) * SPL, MS * NS * NMF>(std::make_integer_sequence<int, (MS + NS) * SPL>{});
-#endif
             if (more) stB(bcur ^ 1);
             if (last && next_chunk) {
                 __syncthreads();                        // every wave has read the last tap of this chunk's halo tile
@@ -926,17 +845,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         }
     }
 
-    }
-    POCR_TRACE_STAMP(2);
-    if constexpr (TR && FUSE1 && POCR_FUSE1_STAGED != 0) {
-        // ---- conv2 with conv1 in its prologue: the pooled tile out through LDS as whole lines (conv_epilogue_staged; the A buffers are free)
-        unsigned rmax = 0u;
-        __syncthreads();
-        conv_epilogue_staged<TH, MWW, NS, WM, POOLH, POOLW, ACT, BN, NT, TW>(acc, acc2, a.bias + nt * NT, BN ? a.bn_scale + nt * NT : nullptr,
-                                                                             BN ? a.bn_shift + nt * NT : nullptr, reinterpret_cast<char *>(lds),
-                                                                             a.y + out_base, h0, w0, Win, a.Ho, a.out_stride, nt, rmax);
-        range_publish(a.range_max, rmax, lane);
-        return;
     }
     if constexpr (TR) {
         // ---- epilogue for the [channel][pixel] result layout: lane (li, kq) holds channels 4 kq .. + 3 of pixel li of every 16-pixel
@@ -1003,11 +911,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
             }
         }
         range_publish(a.range_max, rmax, lane);
-#ifdef POCR_BF16X3_TRACE
-        POCR_TRACE_STAMP(3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        POCR_TRACE_STAMP(4);
-#endif
         return;
     }
 #pragma unroll
@@ -1098,11 +1001,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bf16x3_kernel(ConvArgs a) {
         }
     }
     if constexpr (SPL == 2) range_publish(a.range_max, rmax, lane);
-#ifdef POCR_BF16X3_TRACE
-    POCR_TRACE_STAMP(3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    POCR_TRACE_STAMP(4);
-#endif
 }
 
 }  // namespace pocr

@@ -21,12 +21,6 @@
 #pragma once
 #include "conv_bf16x3.hpp"
 
-#ifndef POCR_ROWS_AHEAD_NS2
-#define POCR_ROWS_AHEAD_NS2 0        // > 0: A fragments requested this many units ahead in the 128-channel tiles instead of POCR_ROW_AHEAD (experiment knob)
-#endif
-#ifndef POCR_ROWS_EPI_PRIO
-#define POCR_ROWS_EPI_PRIO 0
-#endif
 namespace pocr {
 
 // PERS = false: one block per workgroup (the tile loop runs once and everything that looks at a next tile is compiled out)
@@ -139,7 +133,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_rows_kernel(ConvArgs a) {
     const size_t chunk_stride = (size_t)a.cout16 * WU, tap_stride = (size_t)nchunks * chunk_stride;      // 16-byte units
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wfrag), 0, (int)(9 * tap_stride * 16), 0x00020000);
     const int wlane = (int)((((size_t)nt * (NT / 16) + wn * NS) * WU + lane) * 16);
-    constexpr int NROW = TH + 2, NU = NROW * MWW, AH = POCR_ROWS_AHEAD_NS2 > 0 && NS >= 2 ? POCR_ROWS_AHEAD_NS2 : POCR_ROW_AHEAD, RING = AH + 1;
+    constexpr int NROW = TH + 2, NU = NROW * MWW, AH = kRowAhead, RING = AH + 1;
     static_assert(NU >= 3 && AH >= 1 && AH <= NU, "row streaming: units per column offset");
     u32x4 bw[2][3][NS][2], ar[RING][2];
     auto ldW = [&](u32x4 (&dst)[NS][2], int chunk, int tap) {       // past the last chunk: chunk 0 again - the next tile's (same channel tile)
@@ -163,13 +157,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_rows_kernel(ConvArgs a) {
     }
     unsigned rmax = 0u;                                 // f16x2 range guard (conv_igemm.hpp: range_note), published once per workgroup
 
-#ifdef POCR_BF16X3_TRACE
-    unsigned long long tr_t = wall_clock64(), tr_main = 0, tr_epi = 0, tr_oth = 0, tr_tiles = 0;
-    const unsigned long long tr_start = tr_t;
-#define POCR_ROWS_TICK(acc) do { const unsigned long long t1_ = wall_clock64(); acc += t1_ - tr_t; tr_t = t1_; } while (0)
-#else
-#define POCR_ROWS_TICK(acc) do { } while (0)
-#endif
     __amdgpu_buffer_rsrc_t rs = in_rsrc(cur);
     bool pre = false;                                   // chunk 0 of `cur` is in LDS buffer 0 and bw[0] holds its first weight set
     for (;;) {
@@ -192,7 +179,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_rows_kernel(ConvArgs a) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) { acc[m][s] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[m][s] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-        POCR_ROWS_TICK(tr_oth);
         for (int c0 = 0; c0 < nchunks; c0 += 2) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {               // two chunks = six groups: the weight-set parity is static
@@ -211,7 +197,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_rows_kernel(ConvArgs a) {
                         const int qq = dx * NU + q, pq = qq + AH;
                         if (pq < 3 * NU) rdA(ar[pq % RING], abuf, pq / NU, pq % NU);
                         if (q < 3) ldW(bw[par ^ 1][q], nchunk, q * 3 + ndx);
-                        if (dx == 0 && q == (POCR_ROW_LDA_Q < NU ? POCR_ROW_LDA_Q : NU - 1)) ldA(rs, lchunk);
+                        if (dx == 0 && q == (kRowLdaQ < NU ? kRowLdaQ : NU - 1)) ldA(rs, lchunk);
                         const int j = q / MWW, mw = q % MWW;
                         const u32x4 ah = ar[qq % RING][0], al = ar[qq % RING][1];
 #pragma unroll
@@ -229,42 +215,25 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_rows_kernel(ConvArgs a) {
                         }
                         __builtin_amdgcn_sched_barrier(0);   // units stay in source order: reads of unit q + AH, then the MFMAs of unit q
                     }
-                    if (dx == POCR_ROW_STA_DX) stA(abuf ^ 1);    // the other A buffer: its last readers passed the barrier of the previous chunk
+                    if (dx == kRowStaDx) stA(abuf ^ 1);    // the other A buffer: its last readers passed the barrier of the previous chunk
                 }
                 __syncthreads();
             }
         }
 
-        POCR_ROWS_TICK(tr_main);
-#if POCR_ROWS_EPI_PRIO
-        __builtin_amdgcn_s_setprio(POCR_ROWS_EPI_PRIO);   // the epilogue's vector instructions ahead of the co-resident workgroup's MFMA stream
-#endif
         // the NEXT tile's chunk 0 is requested here and lands while the epilogue computes and stores (the weight fragments of its first
         // group are in bw[0] already: the stream wrapped in the last chunk)
         if (has_next) { offsets(nx); rs = in_rsrc(nx); ldA(rs, 0); }
         // ---- epilogue of `cur` (conv_bf16x3.hpp: conv_epilogue_staged)
         conv_epilogue_staged<TH, MWW, NS, WM, POOLH, POOLW, ACT, BN, NT, TW>(acc, acc2, cst, cst + NT, cst + 2 * NT, reinterpret_cast<char *>(ldsA),
                                                                              a.y + cur.out_base, cur.h0, cur.w0, cur.Win, a.Ho, a.out_stride, nt, rmax);
-        POCR_ROWS_TICK(tr_epi);
-#ifdef POCR_BF16X3_TRACE
-        ++tr_tiles;
-#endif
         if (!more) break;
         cur = nx; vb = vbn; nt = nt_n;                  // (the mapping keeps nt; an odd chunk count re-stages from scratch)
         pre = has_next;
-#if POCR_ROWS_EPI_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         if (pre) { stA(0); __syncthreads(); }           // (buffer 0: its last readers passed the barrier of the second-last chunk)
         else { rs = in_rsrc(cur); __syncthreads(); }
     }
     range_publish(a.range_max, rmax, lane);
-#ifdef POCR_BF16X3_TRACE
-    if (tid == 0 && blockIdx.x < (1u << 15)) {
-        unsigned long long *q = g_conv_trace + blockIdx.x * 8;
-        q[0] = tr_start; q[1] = tr_main; q[2] = tr_epi; q[3] = tr_oth; q[4] = wall_clock64(); q[6] = tr_tiles;
-    }
-#endif
 }
 
 }  // namespace pocr

@@ -362,9 +362,9 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(const void *qkv
                     const u32x4 kl = *reinterpret_cast<const u32x4 *>(buf + (2 * c + 1) * K_IMG + kt * 1024 + frag);
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {
-                        s1[t][kt] = POCR_MFMA_F16(kh, qh[t][c], s1[t][kt]);
-                        s2[t][kt] = POCR_MFMA_F16(kh, ql[t][c], s2[t][kt]);
-                        s2[t][kt] = POCR_MFMA_F16(kl, qh[t][c], s2[t][kt]);
+                        s1[t][kt] = mfma16_f16(kh, qh[t][c], s1[t][kt]);
+                        s2[t][kt] = mfma16_f16(kh, ql[t][c], s2[t][kt]);
+                        s2[t][kt] = mfma16_f16(kl, qh[t][c], s2[t][kt]);
                     }
                 }
             // ---- online softmax: this lane holds keys k0 + 16 kt + 4 kq + r of query li
@@ -406,9 +406,9 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(const void *qkv
                 const u32x4 vl = *reinterpret_cast<const u32x4 *>(buf + K_BYTES + V_IMG + dt * 1024 + frag);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
-                    o1[t][dt] = POCR_MFMA_F16(vh, ph[t], o1[t][dt]);
-                    o2[t][dt] = POCR_MFMA_F16(vh, pl[t], o2[t][dt]);
-                    o2[t][dt] = POCR_MFMA_F16(vl, ph[t], o2[t][dt]);
+                    o1[t][dt] = mfma16_f16(vh, ph[t], o1[t][dt]);
+                    o2[t][dt] = mfma16_f16(vh, pl[t], o2[t][dt]);
+                    o2[t][dt] = mfma16_f16(vl, ph[t], o2[t][dt]);
                 }
             }
         }

@@ -52,25 +52,19 @@ struct GemmP2Args {
     unsigned *range_flag;     // [8]: the f16x2 range guard (conv_igemm.hpp: range_publish); NULL = off
 };
 
-#ifndef POCR_GEMM_DBG
-#define POCR_GEMM_DBG 0              // tools/gemm_bench.hip ablations (results wrong, time only): 1 no DMA in the loop, 2 no fragment reads, 4 no MFMAs
-#endif
 constexpr int kGemmBM = 256, kGemmBN = 128, kGemmThreads = 512;
 constexpr int kGemmStageU = 3072;                 // 16-byte units per stage: 2048 of A, 1024 of B
 constexpr int kGemmBiasMax = 3072;                // bias columns kept in LDS (an ordinary global load inside the stream would drain the DMA queue)
 constexpr int kGemmLdsU = 3 * kGemmStageU + kGemmBiasMax / 4;
 
-#ifndef POCR_GEMM_SPLIT
-#define POCR_GEMM_SPLIT 0            // where a stage's six DMA requests are issued: 0 all in the memory phase, 1 the B pieces there and the A pieces between the MFMA groups, 2 all between the MFMA groups
-#endif
-#ifndef POCR_GEMM_PRIO
-#define POCR_GEMM_PRIO 0             // 1: s_setprio(1) around a stage's MFMAs (the multiplying wave ahead of its partner's memory phase)
-#endif
-#ifndef POCR_GEMM_A_AUX
-#define POCR_GEMM_A_AUX 2            // cache policy of the A pieces: 2 = nt (streamed: the weights, re-read by every row tile, keep their place in L2), 0 = default
-#endif
-#define POCR_GLDS16(gptr, lptr, aux) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), \
-                                                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, aux)
+constexpr int kGemmAAux = 2;                      // cache policy of the A pieces: 2 = nt (streamed: the weights, re-read by every row tile, keep their place in L2)
+// (measured and dropped in round 4, profiles/r04_gemm_split_issue.txt, r04_gemm_dma_*: DMA requests between the MFMA groups instead of in
+// the memory phase, s_setprio around a stage's MFMAs, default cache policy for A)
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4); AUX: the cache policy bits
+template <int AUX, class TG, class TL>
+__device__ __forceinline__ void glds16(const TG *gptr, TL *lptr) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lptr), 16, 0, AUX);
+}
 
 template <int ACT, bool P2OUT, bool GATHER>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args a) {
@@ -130,13 +124,13 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
         const char *src;
         if constexpr (GATHER) src = arow[j] + p_tap * atap[j] + (size_t)p_c * 128;
         else src = arow[j] + (size_t)p_k * 128;
-        POCR_GLDS16(src, dst + (j * 8 + wave) * 64, POCR_GEMM_A_AUX);
+        glds16<kGemmAAux>(src, dst + (j * 8 + wave) * 64);
     };
     auto issue_b = [&](int buf) __attribute__((always_inline)) {
         u32x4 *dst = lds + buf * kGemmStageU;
         const char *wsrc = wcol + (size_t)(GATHER ? p_tap * a.cpt + p_c : p_k) * a.N16 * 2048;
-        POCR_GLDS16(wsrc, dst + 2048 + wave * 64, 0);                    // (tile, plane) pieces wave and wave + 8
-        POCR_GLDS16(wsrc + 8 * 1024, dst + 2048 + (8 + wave) * 64, 0);
+        glds16<0>(wsrc, dst + 2048 + wave * 64);                    // (tile, plane) pieces wave and wave + 8
+        glds16<0>(wsrc + 8 * 1024, dst + 2048 + (8 + wave) * 64);
     };
     auto advance = [&]() __attribute__((always_inline)) {
         if constexpr (GATHER) { if (++p_tap == a.ntap) { p_tap = 0; ++p_c; } }
@@ -250,78 +244,39 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
         // fragment reads first, the six DMA requests behind them (in the shadow of the reads' latency)
         const u32x4 *S = lds + buf * kGemmStageU;
         u32x4 bh[4], bl[4], ah[4], al[4];
-#if POCR_GEMM_DBG & 2
-#pragma unroll
-        for (int n = 0; n < 4; ++n) { bh[n] = (u32x4){(unsigned)(buf + n), 1u, 2u, (unsigned)lane}; bl[n] = bh[n] ^ 5u; ah[n] = bh[n] ^ 9u; al[n] = bh[n] ^ 17u; }
-        (void)S;
-#else
 #pragma unroll
         for (int n = 0; n < 4; ++n) { bh[n] = S[b_u + n * 128]; bl[n] = S[b_u + n * 128 + 64]; }
 #pragma unroll
         for (int m = 0; m < 4; ++m) { ah[m] = S[a_h + m * 128]; al[m] = S[a_l + m * 128]; }
-#endif
-#if !(POCR_GEMM_DBG & 1)
         {
             const int nb_ = buf == 0 ? 2 : buf - 1;
-            if constexpr (POCR_GEMM_SPLIT == 0) issue(nb_);
-            else if constexpr (POCR_GEMM_SPLIT == 1) issue_b(nb_);
+            issue(nb_);
         }
-#endif
         // the pieces of stage g + 1: all but the 6 just requested - and, behind a full tile's epilogue, its NST stores, which
         // are younger than the pieces of stage g + 1 and older than those of g + 2 (so the NEXT stage's wait covers them)
-#if POCR_GEMM_DBG & 1
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-        // (POCR_GEMM_SPLIT: the pieces requested in THIS memory phase are the only ones younger than the stage waited for:
-        //  6 / 2 / 0, plus a full epilogue's NST stores)
+        // (the six pieces requested in THIS memory phase are the only ones younger than the stage waited for, plus a full epilogue's
+        //  NST stores)
         if (stores_young) {
             if constexpr (P2OUT) {
-                if constexpr (POCR_GEMM_SPLIT == 0) asm volatile("s_waitcnt vmcnt(38) lgkmcnt(0)" ::: "memory");
-                else if constexpr (POCR_GEMM_SPLIT == 1) asm volatile("s_waitcnt vmcnt(34) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(38) lgkmcnt(0)" ::: "memory");
             } else {
-                if constexpr (POCR_GEMM_SPLIT == 0) asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)" ::: "memory");
-                else if constexpr (POCR_GEMM_SPLIT == 1) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)" ::: "memory");
             }
         } else {
-            if constexpr (POCR_GEMM_SPLIT == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-            else if constexpr (POCR_GEMM_SPLIT == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         }
-#endif
         stores_young = false;
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-#if POCR_GEMM_DBG & 4
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) { acc[m][n][0] += __builtin_bit_cast(float, ah[m][0] ^ bh[n][0]); acc2[m][n][0] += __builtin_bit_cast(float, al[m][0] ^ bl[n][0]); }
-#else
-#if POCR_GEMM_PRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-#if !(POCR_GEMM_DBG & 1)
-            if constexpr (POCR_GEMM_SPLIT >= 1) issue_a(buf == 0 ? 2 : buf - 1, m);       // one A piece per 12 MFMAs
-            if constexpr (POCR_GEMM_SPLIT == 2) { if (m == 1) issue_b(buf == 0 ? 2 : buf - 1); }
-#endif
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc2[m][n] = POCR_MFMA_F16(bh[n], al[m], acc2[m][n]);
+            for (int n = 0; n < 4; ++n) acc2[m][n] = mfma16_f16(bh[n], al[m], acc2[m][n]);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = POCR_MFMA_F16(bh[n], ah[m], acc[m][n]);
+            for (int n = 0; n < 4; ++n) acc[m][n] = mfma16_f16(bh[n], ah[m], acc[m][n]);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc2[m][n] = POCR_MFMA_F16(bl[n], ah[m], acc2[m][n]);
+            for (int n = 0; n < 4; ++n) acc2[m][n] = mfma16_f16(bl[n], ah[m], acc2[m][n]);
         }
-#if POCR_GEMM_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#if !(POCR_GEMM_DBG & 1)
-        if constexpr (POCR_GEMM_SPLIT >= 1) advance();
-#endif
-#endif
         if (++c_k == nk) { c_k = 0; pending = true; }
     };
 

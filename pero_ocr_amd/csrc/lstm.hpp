@@ -101,11 +101,11 @@ __device__ __forceinline__ void lstm_mfma_f16x2(const f32x4 (&x0)[(2 * KPW + 3) 
         split2_quad(x1[q], h23, l23);
         const u32x4 ah = {h01[0], h01[1], h23[0], h23[1]}, al = {l01[0], l01[1], l23[0], l23[1]};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) cross[g] = POCR_MFMA_F16(al, w.b[q][g][0], cross[g]);
+        for (int g = 0; g < 4; ++g) cross[g] = mfma16_f16(al, w.b[q][g][0], cross[g]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) main_[g] = POCR_MFMA_F16(ah, w.b[q][g][0], main_[g]);
+        for (int g = 0; g < 4; ++g) main_[g] = mfma16_f16(ah, w.b[q][g][0], main_[g]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) cross[g] = POCR_MFMA_F16(ah, w.b[q][g][1], cross[g]);
+        for (int g = 0; g < 4; ++g) cross[g] = mfma16_f16(ah, w.b[q][g][1], cross[g]);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = main_[g] + cross[g] * (1.0f / kF16x2Scale);

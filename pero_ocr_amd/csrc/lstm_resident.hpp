@@ -34,12 +34,6 @@
 #include "conv_igemm.hpp"
 #include "lstm.hpp"
 
-#ifndef POCR_LSTM_PREFETCH
-#define POCR_LSTM_PREFETCH 1         // the NEXT slice-step's hidden state is copied into LDS (global_load_lds) while the current one computes (f16x2, SL >= 2)
-#endif
-#ifndef POCR_LSTM_RES_DBG
-#define POCR_LSTM_RES_DBG 0          // 1: workgroup 0 accumulates cycles per phase into err[8..] (timing experiments only)
-#endif
 namespace pocr {
 
 struct LstmResidentArgs {
@@ -72,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
     // ONE shared object (a second one makes hipcc drain the LDS-DMA queue before every ds_read, gemm_f16x2.hpp):
     // [part: wave x gate x lane x reg partial sums | hpre: the NEXT slice-step's h_{s-1}, 16 rows of H floats + 4 pad, landed by LDS-DMA | xl | flags]
     constexpr int HP = H + 4;                   // row pitch of the landing zone in floats: +16 bytes, so the 16 rows of an MFMA A fragment hit 16 different bank groups
-    constexpr int PART_F = 4 * 4 * 64 * 4, HPRE_F = (POCR_LSTM_PREFETCH && SL >= 2 && H == 256) ? 16 * HP : 0;
+    constexpr int PART_F = 4 * 4 * 64 * 4, HPRE_F = (SL >= 2 && H == 256) ? 16 * HP : 0;
     constexpr int XL_F = SL * 1024;             // xl: the gate pre-activations x of each slice's next step ([slice][wave][lane][4]: every wave lands and reads its own 1 KB)
     __shared__ float smem[PART_F + HPRE_F + XL_F + 4];
     float *part = smem, *hpre = smem + PART_F, *xl = smem + PART_F + HPRE_F;
@@ -172,12 +166,6 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
     const int src = (((i >> 2) * 16 + u) * 4) + ((i & 3) ^ ((u >> 3) * 2));      // D layout of the reduced gates (as lstm_step_kernel), halves swapped for u >= 8 (below)
     const bool hi8 = li >= 8;
 
-#if POCR_LSTM_RES_DBG
-    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;
-#define POCR_TICK(k) do { if (b == 0 && tid == 0) { const unsigned long long t1 = __builtin_readcyclecounter(); tph[k] += t1 - t0; t0 = t1; } } while (0)
-#else
-#define POCR_TICK(k) do { } while (0)
-#endif
     unsigned *pend = nullptr;                                  // sync word of the slice whose last state store is not yet published
     auto bump = [&](unsigned *sy) {                            // (everybody's stores are acknowledged and a barrier has been passed)
         if (tid == 0) {
@@ -215,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
     // The next slice-step then starts with its operand in LDS: no counter poll, no L2 round trip for h (profiles/r03_lstm_resident.txt
     // section 8: wait 580 + h loads ~1500 of a slice-step's ~5000 cycles).  Not ready (a single slice left, the first step): the
     // blocking path below, as before.  Same values, same MFMAs: bit-identical.
-    constexpr bool PREF = POCR_LSTM_PREFETCH && SL >= 2 && H == 256;       // (one 1 KB LDS-DMA piece = one row of h)
+    constexpr bool PREF = SL >= 2 && H == 256;       // (one 1 KB LDS-DMA piece = one row of h)
     bool have_pre = false;                                     // hpre holds h_{s-1} of the slice-step that starts now
     for (int s = 0; s < Tmax; ++s) {
 #pragma unroll
@@ -233,9 +221,6 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
             }
             const bool use_pre = have_pre;
             have_pre = false;
-#if POCR_LSTM_RES_DBG
-            if (b == 0 && tid == 0) t0 = __builtin_readcyclecounter();
-#endif
             const int cl = (sg * SL + j) * 2 + dir;
             unsigned *sync = a.sync + (size_t)cl * 32;
             float *hc = a.hbuf + (size_t)cl * 2 * 16 * H;     // [2][16][H]
@@ -270,7 +255,6 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
             if (!use_pre) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this slice-step's x piece (requested at the slice's previous turn) and the stores just issued
             float xcur[4];
             read_x(j, xcur);                                   // (before this slice's NEXT piece is requested, behind the barrier below, into the same 1 KB)
-            POCR_TICK(0);                                      // wait for the hand-off
             // look-ahead poll of the next slice-step's counter: requested now, looked at behind the MFMAs
             unsigned look = 0u;
             const bool look_ok = PREF && f16 && ns > 0 && !(ns == s + 1 && nj == j);
@@ -313,7 +297,6 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<f32x4 *>(&part[((wave * 4 + g) * 64 + lane) * 4]) =
                     hi8 ? (f32x4){acc[g][2], acc[g][3], acc[g][0], acc[g][1]} : acc[g];
-            POCR_TICK(1);                                      // h loads + MFMAs
             // The previous slice-step's state store is published HERE, one slice-step late: its L2 acknowledgement has had this
             // step's wait + GEMM to arrive, and the barrier that orders everybody's acknowledgement is the one the LDS reduction
             // needs anyway (before: acknowledgement + a barrier of its own behind every store, 400-2000 cycles of a ~5 k slice-step)
@@ -343,7 +326,6 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
             }
             asm volatile("" ::: "memory");                     // the x piece below stays BEHIND the h pieces (the counted wait assumes that order)
             load_x(j, s + 1);                                  // x of this slice's next step: due at this slice's next turn
-            POCR_TICK(2);                                      // barrier
             float gate[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -359,7 +341,6 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
                 lstm_cell(gate, xcur, cprev[j], cn, hn);
                 cprev[j] = cn;
             }
-            POCR_TICK(3);                                      // gates
             d_hn = hn;
             if (s + 1 < Ts[j]) {
                 d_hdst = hc + (size_t)((s + 1) & 1) * 16 * H + (size_t)i * H + unit;
@@ -370,10 +351,6 @@ __global__ __launch_bounds__(256, 2) void lstm_resident_kernel(LstmResidentArgs 
     }
     flush_stores();
     if (pend) publish_pending();
-#if POCR_LSTM_RES_DBG
-    if (b == 0 && tid == 0)
-        for (int q = 0; q < 6; ++q) reinterpret_cast<unsigned long long *>(a.err + 8)[q] = tph[q];
-#endif
 }
 
 }  // namespace pocr

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <functional>
@@ -34,10 +35,6 @@
 #include "parsenet.hpp"
 
 using namespace pocr;
-
-#ifndef POCR_FRONT_PRIORITY_DEFAULT_HIGH
-#define POCR_FRONT_PRIORITY_DEFAULT_HIGH false
-#endif
 
 namespace {
 
@@ -125,18 +122,11 @@ inline void parallel_memcpy(void *dst, const void *src, size_t bytes) {
     for (std::thread &h : helpers) h.join();
 }
 
-// The streams of the page front (layout network, cropper).  In a page stream their kernels share the GPU with the recogniser's
-// convolutions of EARLIER pages; the front is a chain of short dependent launches with host steps between them, so what it needs is
-// latency: POCR_FRONT_PRIORITY=high puts its streams at the device's greatest priority (default: see DESIGN section 5).
-inline hipError_t create_front_stream(hipStream_t *st) {
-    const char *e = getenv("POCR_FRONT_PRIORITY");
-    const bool high = e ? (strcmp(e, "high") == 0 || strcmp(e, "1") == 0) : POCR_FRONT_PRIORITY_DEFAULT_HIGH;
-    if (!high) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    int lo = 0, hi = 0;
-    hipError_t r = hipDeviceGetStreamPriorityRange(&lo, &hi);          // numerically lowest = greatest priority
-    if (r != hipSuccess) return r;
-    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
-}
+// The streams of the page front (layout network, cropper): ordinary priority.  In a page stream their kernels share the GPU with the
+// recogniser's convolutions of EARLIER pages.  Greatest priority for them (and a third front pair) was measured in rounds 4 and 6 on
+// the c5 stream - 72.9-75.6 pages/s as shipped, 73.6-74.7 with high priority, 74.1-75.1 with three fronts, 74.1-74.4 with both
+// (profiles/r06_c5_front_ab.txt): the stream is bound by the GPU's work per page, not by the front's latency - and removed.
+inline hipError_t create_front_stream(hipStream_t *st) { return hipStreamCreateWithFlags(st, hipStreamNonBlocking); }
 inline hipError_t locked_memcpy(void *d, const void *s_, size_t n, hipMemcpyKind k) { UnsafeLock l; return hipMemcpy(d, s_, n, k); }
 inline hipError_t locked_memcpy2d(void *d, size_t dp, const void *s_, size_t sp, size_t w, size_t h, hipMemcpyKind k) { UnsafeLock l; return hipMemcpy2D(d, dp, s_, sp, w, h, k); }
 
@@ -199,12 +189,11 @@ int launch_conv(Kern kern, int TH, int TW, int NT, int nthreads, ConvArgs a, hip
         a.tiles_h = (a.Ho + TH - 1) / TH;
     }
     a.tiles_n = (a.cout16 * 16) / NT;
-    // Channel tiles per XCD (ConvArgs::xcd_g).  One per XCD (the default) keeps 1 / tiles_n of a layer's weights in each L2 and
-    // lets tiles_n XCDs fetch the same halo tile; two per XCD was measured: same time, and the HBM-side read bytes of conv9
-    // do NOT drop (2.34 -> 2.14 GB per launch: what the halo re-reads save, the weight stream - now 4.7 MB per XCD, over
-    // the 4 MB L2 - costs) - profiles/r03_xcd_mapping_experiment.txt.  POCR_XCD_G=2|4 selects the other mappings.
-    static const int xcd_g_env = getenv("POCR_XCD_G") ? atoi(getenv("POCR_XCD_G")) : 1;
-    if (a.xcd_g == 0) a.xcd_g = xcd_g_env;
+    // Channel tiles per XCD (ConvArgs::xcd_g): one.  That keeps 1 / tiles_n of a layer's weights in each L2 and lets tiles_n XCDs fetch
+    // the same halo tile; two per XCD was measured: same time, and the HBM-side read bytes of conv9 do NOT drop (2.34 -> 2.14 GB per
+    // launch: what the halo re-reads save, the weight stream - then 4.7 MB per XCD, over the 4 MB L2 - costs;
+    // profiles/r03_xcd_mapping_experiment.txt).  The kernels' tile map still takes the group size as an argument.
+    if (a.xcd_g == 0) a.xcd_g = 1;
     const size_t blocks = conv_grid_blocks(a);
     if (blocks == 0) return 0;
     if (blocks > 0x7fffffffull) return fail("conv grid too large (%zu blocks)", blocks);
@@ -221,18 +210,16 @@ int launch_conv(Kern kern, int TH, int TW, int NT, int nthreads, ConvArgs a, hip
 // rows / rows persistent): conv3 0.657 / 0.603 / 0.555, conv4 0.95 / 0.92 / 0.97, conv5 0.544 / 0.507 / 0.527, conv6 0.943 / 0.926 /
 // 0.962, conv7 0.92 / 0.945 / 0.966 (0.96 either way in the evidence run, within the boxes' spread), conv8 0.977 / 0.974 / 0.972, conv9 1.815 / 1.79 / 1.83 - the two workgroups of a CU already cover
 // each other's prologue, so persistence pays only where the prologue is a third of a tile (conv3).
-// POCR_CONV_ROWS_MASK / POCR_CONV_PERSIST_MASK: bit i = conv(i + 1) (defaults 0x1FC: conv3 .. conv9; 0x4: conv3); POCR_CONV_ROWS=0: none.
+// POCR_CONV_ROWS=0: conv3 .. conv9 on the conv_bf16x3.hpp kernels they replace; POCR_CONV_PERSIST_MASK: bit i = conv(i + 1) in the
+// persistent form (default 0x4: conv3) - both are the A / B switches of test_conv_rows_kernels_are_bit_identical_to_the_one_tile_kernels.
 thread_local int g_conv_layer = -1;                     // index of the layer being launched (run_network)
 inline int conv_rows_mode() {                           // 0: conv_bf16x3.hpp, 1: conv_rows.hpp, 2: conv_rows.hpp persistent
-    static const int rows_mask = [] {
-        if (const char *e = getenv("POCR_CONV_ROWS")) if (atoi(e) == 0) return 0;
-        const char *m = getenv("POCR_CONV_ROWS_MASK");
-        return m ? (int)strtol(m, nullptr, 0) : 0x1FC;
-    }();
+    static const bool rows_on = [] { const char *e = getenv("POCR_CONV_ROWS"); return !(e && atoi(e) == 0); }();
     static const int pers_mask = [] { const char *m = getenv("POCR_CONV_PERSIST_MASK"); return m ? (int)strtol(m, nullptr, 0) : 0x4; }();
     const int l = g_conv_layer;
-    if (l < 0 || l > 30) return rows_mask ? 1 : 0;
-    return !((rows_mask >> l) & 1) ? 0 : ((pers_mask >> l) & 1) ? 2 : 1;
+    if (!rows_on) return 0;
+    if (l < 2 || l > 8) return 1;                       // (conv3 .. conv9 are layers 2 .. 8; other callers: the plain form)
+    return ((pers_mask >> l) & 1) ? 2 : 1;
 }
 template <class Kern>
 int launch_conv_rows(Kern kern, int TH, int TW, int NT, ConvArgs a, hipStream_t st) {
@@ -241,8 +228,7 @@ int launch_conv_rows(Kern kern, int TH, int TW, int NT, ConvArgs a, hipStream_t 
         a.tiles_h = (a.Ho + TH - 1) / TH;
     }
     a.tiles_n = (a.cout16 * 16) / NT;
-    static const int xcd_g_env = getenv("POCR_XCD_G") ? atoi(getenv("POCR_XCD_G")) : 1;
-    if (a.xcd_g == 0) a.xcd_g = xcd_g_env;
+    if (a.xcd_g == 0) a.xcd_g = 1;
     const size_t blocks = conv_grid_blocks(a);
     if (blocks == 0) return 0;
     if (blocks > 0x7fffffffull) return fail("conv grid too large (%zu blocks)", blocks);
@@ -367,19 +353,11 @@ POCR_CONVP(conv8_p2,  5, 1, 2, 1, 1, 1, ACT_LEAKY, false, 2, true)
 int conv2_p2_fused(ConvArgs a, hipStream_t st) {
     return launch_conv(conv3x3_bf16x3_kernel<10, 1, 1, 1, 2, 2, ACT_RELU, false, 2, true, 3, 3, 1, 1, false, 2, true, true, true>, 10, 16, 64, 256, a, st);
 }
-int conv2_p2_fused8(ConvArgs a, hipStream_t st) {      // 8 x 16 pixels, three workgroups per CU (52 KB of LDS each): POCR_P2_ALT_TILES bit 7
+int conv2_p2_fused8(ConvArgs a, hipStream_t st) {      // 8 x 16 pixels, three workgroups per CU (52 KB of LDS each): networks without a recurrence (pocr_create)
     return launch_conv(conv3x3_bf16x3_kernel<8, 1, 1, 1, 2, 2, ACT_RELU, false, 3, true, 3, 3, 1, 1, false, 2, true, true, true>, 8, 16, 64, 256, a, st);
 }
-// experiment knob (POCR_P2_ALT_TILES = bit mask over conv2 .. conv7 = bits 1 .. 6): the round-2 tiles
-POCR_CONVP(conv2_p2_alt,  4, 2, 2, 2, 2, 2, ACT_RELU, false, 2, false)
-POCR_CONVP(conv3_p2_alt,  5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
-POCR_CONVP(conv4_p2_alt,  4, 1, 2, 1, 2, 2, ACT_RELU, false, 2, true)
-POCR_CONVP(conv56_p2_alt, 5, 1, 2, 1, 1, 1, ACT_RELU, false, 2, true)
-POCR_CONVP(conv7_p2_alt,  2, 2, 2, 1, 2, 1, ACT_RELU, false, 2, true)
-int p2_alt_tiles() {
-    static const int m = getenv("POCR_P2_ALT_TILES") ? atoi(getenv("POCR_P2_ALT_TILES")) : 0;
-    return m;
-}
+// (the round-2 tiles - 4 x 32 / 5 x 16 x 128 / 4 x 16 / 2 x 32 pixels for conv2 .. conv7 - lost to these on every layer and were removed in round 6:
+// profiles/r03_conv_rowstream.txt, r05_conv_rows.txt)
 POCR_CONVP(conv9_p2,  5, 1, 2, 1, 1, 1, ACT_LEAKY, true, 2, true)
 #define POCR_CONVPG(name, TH, MW, NS, WM, ACT, MINW, KH, BDIR)                                                      \
     int name(ConvArgs a, hipStream_t st) {                                                                         \
@@ -433,13 +411,14 @@ const int kConvTW[10] = {32, 64, 32, 32, 16, 16, 16, 16, 16, 48};
 const int kConvTW3[10] = {32, 32, 16, 16, 16, 16, 32, 16, 16, 48};
 const int kConvTHP[10] = {4, 10, 10, 10, 10, 10, 10, 5, 5, 1};       // the P2 configurations (POCR_CONVP)
 const int kConvTWP[10] = {32, 16, 16, 16, 16, 16, 16, 16, 16, 48};
-inline int conv_tile_h(bool p2, bool b3, int k, bool conv2_tile8 = false) { return p2 ? (k == 1 && conv2_tile8 ? 8 : (p2_alt_tiles() >> k) & 1 ? kConvTH3[k] : kConvTHP[k]) : b3 ? kConvTH3[k] : kConvTH[k]; }
-inline int conv_tile_w(bool p2, bool b3, int k) { return p2 ? ((p2_alt_tiles() >> k) & 1 ? kConvTW3[k] : kConvTWP[k]) : b3 ? kConvTW3[k] : kConvTW[k]; }
+inline int conv_tile_h(bool p2, bool b3, int k, bool conv2_tile8 = false) { return p2 ? (k == 1 && conv2_tile8 ? 8 : kConvTHP[k]) : b3 ? kConvTH3[k] : kConvTH[k]; }
+inline int conv_tile_w(bool p2, bool b3, int k) { return p2 ? kConvTWP[k] : b3 ? kConvTW3[k] : kConvTW[k]; }
 // input width level of each conv (0: W_pad, 1: W_pad/2, 2: (W_pad/2)/2) and of its output
 const int kConvLvlIn[10] = {0, 0, 1, 1, 2, 2, 2, 2, 2, 2};
 const int kConvLvlOut[10] = {0, 1, 1, 2, 2, 2, 2, 2, 2, 2};
 const int kAggNT = 256, kProjNT = 128, kHeadNT = 64, kSkinnyNT = 64;
 const int kConvWaitLayer = 4;        // index into kConvPlan (conv5): see run_network
+const int kLstmDecayAfter = 64;      // resident launches in a row without a hand-off timeout that halve the back-off again (sync_and_guard)
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -558,6 +537,7 @@ struct Slot {
     DevBuf lstm_sync;                    // resident recurrence (lstm_resident.hpp): [clusters][32] sync words, then 4 error / diagnostic words
     size_t lstm_err_off = 0;             // index (uint32) of the error words inside lstm_sync
     bool lstm_resident_used = false;     // this launch ran the resident kernel: collect checks the error word
+    bool lstm_judged = false;            // ... and sync_and_guard has counted its outcome for the back-off (once per launch)
     bool lstm_force_step = false;        // the repeat of a launch whose resident recurrence timed out: step kernels
     uint32_t *lstm_err_host = nullptr;   // pinned copy of the error words
     DevBuf nf_flag;                      // set by frame_argmax_kernel when a winning logit is NaN / inf
@@ -620,14 +600,17 @@ struct pocr_engine {
     bool lstm_resident = true;       // one launch per BiLSTM layer with the hidden state handed over inside an XCD (lstm_resident.hpp); POCR_LSTM_RESIDENT=0: one launch per step
     // A hand-off timeout (a cluster that was not fully resident: other tenants on the chip) sends the NEXT lstm_skip launches to the
     // step kernels, then the resident path is tried again; every further timeout doubles the pause (4 .. 256 launches).
-    int lstm_skip = 0, lstm_skip_len = 0;
-    int64_t lstm_timeouts = 0;       // launches repeated on the step kernels after a timeout (pocr_lstm_timeouts)
+    // The pause decays: every kLstmDecayAfter resident launches in a row that hand over in time halve it again (below 4: gone), so a
+    // long-lived server pays for a handful of sporadic timeouts once, not for the rest of its life.  The counters are
+    // touched by run_network / sync_and_guard of several slots, which may run on worker threads (decoding loops): atomics.
+    std::atomic<int> lstm_skip{0}, lstm_skip_len{0}, lstm_ok_run{0};
+    std::atomic<int64_t> lstm_timeouts{0};       // launches repeated on the step kernels after a timeout (pocr_lstm_timeouts)
     int lstm_spin_limit = 1 << 22;   // POCR_LSTM_SPIN_LIMIT at creation (tests force the timeout path with a tiny limit)
     bool warned_nonfinite = false, warned_placement = false, warned_range = false;
     bool fuse12 = false;             // conv1 inside conv2's prologue (P2 only; POCR_NO_FUSE12=1: conv1 as its own launch, its activation in HBM)
     bool conv2_tile8 = false;        // the fused conv1+2 kernel as 8 x 16 tiles, three workgroups per CU (networks without a recurrence)
     DevBuf conv1_w2;                 // conv1's weights as f16x2 fragments (Conv1Args::w1x2)
-    pocr_engine *shadow = nullptr;   // f16x2 range guard: the same network on bf16x3 (fp32's range); built by shadow_builder behind pocr_create
+    std::atomic<pocr_engine *> shadow{nullptr};   // f16x2 range guard: the same network on bf16x3 (fp32's range); built by shadow_builder behind pocr_create
                                      // (POCR_FALLBACK_EAGER=0: when a launch first leaves f16's range)
     std::mutex shadow_mu;            // creation of / launches on the fall-back engine (decoding loops of several slots run on worker threads)
     std::thread shadow_builder;      // holds shadow_mu while it builds: a fall-back that comes earlier waits for it instead of building twice
@@ -640,7 +623,7 @@ struct pocr_engine {
     bool p2 = false;                 // f16x2 with pre-split activations between conv1 and the aggregation conv (conv_bf16x3.hpp "P2"; POCR_NO_P2=1: split in every consumer)
     DevBuf head_w2, head_b2;         // the output layer's weights in the wsplit layout + its bias padded to 128 columns: the head on the persistent GEMM
     int head2_cout16 = 0;
-    bool head_fp32 = false, att_fp32 = false;      // POCR_HEAD_FP32 / POCR_ATT_FP32 at creation: the fp32-MFMA head / attention kernels
+    bool head_fp32 = false;          // POCR_HEAD_FP32 at creation: the head on the fp32-MFMA GEMM (A / B test of the f16x2 head)
     bool bf16x3 = true;              // conv2..conv9 on the bf16 matrix pipe with the exact 3-way operand split (POCR_CONV_FP32=1: fp32 MFMA)
     DevBuf cconst[9];                // per conv layer: the output column [H_out][cout] far inside zero padding
     bool pad_skip = false;           // skip + fill constant padding tiles (POCR_NO_PAD_SKIP=1 turns it off)
@@ -793,14 +776,13 @@ int run_network(pocr_engine *e, Slot &s) {
     // ahead and fill the ends of its kernels - every kernel of a stream leaves the CUs half empty while its last round of
     // workgroups finishes (conv6 .. conv9: 18 rounds of 45-95 us tiles) and the next one cannot start before it has.
     // Measured on one box (profiles/r04_backbone_overlap.txt): c2 9.73 -> 9.39 ms per step, c4 +1.2 %, c3 / c5 unchanged;
-    // no wait at all (POCR_CONV_NOWAIT=1) is as good on c2 and costs the c3 stream 3 %; behind the WHOLE backbone
-    // (POCR_CONV_WAIT_LAYER=-1, rounds 1-3) two backbones never share the chip.
-    static const int conv_wait_layer = getenv("POCR_CONV_WAIT_LAYER") ? atoi(getenv("POCR_CONV_WAIT_LAYER")) : kConvWaitLayer;
+    // no wait at all is as good on c2 and costs the c3 stream 3 %; behind the WHOLE backbone (rounds 1-3) two backbones never share
+    // the chip.
+    constexpr int conv_wait_layer = kConvWaitLayer;
     {
         Slot &prev = e->slot[e->last_slot];
-        static const bool conv_nowait = getenv("POCR_CONV_NOWAIT") && atoi(getenv("POCR_CONV_NOWAIT")) != 0;
-        if (&prev != &s && prev.conv_done_valid && !conv_nowait) {
-            if (conv_wait_layer >= 0 && conv_wait_layer < 9 && prev.conv_part_valid) HIP_TRY(hipStreamWaitEvent(st, prev.conv_part, 0));
+        if (&prev != &s && prev.conv_done_valid) {
+            if (prev.conv_part_valid) HIP_TRY(hipStreamWaitEvent(st, prev.conv_part, 0));
             else HIP_TRY(hipStreamWaitEvent(st, prev.conv_done, 0));
         }
     }
@@ -850,13 +832,13 @@ int run_network(pocr_engine *e, Slot &s) {
                             a.f1_lut = e->lut.as<float>(); a.f1_w = e->conv1_w2.p; a.f1_bias = e->conv_b[0].as<float>(); a.f1_src_h = 0;
                             rc = e->conv2_tile8 ? conv2_p2_fused8(a, st) : conv2_p2_fused(a, st);
                         } else {
-                            rc = (p2_alt_tiles() >> 1) & 1 ? conv2_p2_alt(a, st) : conv2_p2(a, st);
+                            rc = conv2_p2(a, st);
                         }
                         break;
-                    case 2: rc = (p2_alt_tiles() >> 2) & 1 ? conv3_p2_alt(a, st) : conv3_p2(a, st); break;
-                    case 3: rc = (p2_alt_tiles() >> 3) & 1 ? conv4_p2_alt(a, st) : conv4_p2(a, st); break;
-                    case 4: case 5: rc = (p2_alt_tiles() >> i) & 1 ? conv56_p2_alt(a, st) : conv56_p2(a, st); break;
-                    case 6: rc = (p2_alt_tiles() >> 6) & 1 ? conv7_p2_alt(a, st) : conv7_p2(a, st); break;
+                    case 2: rc = conv3_p2(a, st); break;
+                    case 3: rc = conv4_p2(a, st); break;
+                    case 4: case 5: rc = conv56_p2(a, st); break;
+                    case 6: rc = conv7_p2(a, st); break;
                     case 7: rc = conv8_p2(a, st); break;
                     default: rc = conv9_p2(a, st); break;
                 }
@@ -885,7 +867,7 @@ int run_network(pocr_engine *e, Slot &s) {
         if (rc) return rc;
         h /= L.ph;
         s.act_h[i] = h; s.act_c[i] = L.cout;
-        if (conv_wait_layer >= 0 && i == conv_wait_layer) { HIP_TRY(hipEventRecord(s.conv_part, st)); s.conv_part_valid = true; }
+        if (i == conv_wait_layer) { HIP_TRY(hipEventRecord(s.conv_part, st)); s.conv_part_valid = true; }
     }
     // ---- aggregation conv: line i [H/8][T_i][512] -> rows row_off[i] .. of feat [rows][E]
     {
@@ -928,10 +910,9 @@ int run_network(pocr_engine *e, Slot &s) {
     // aggregation conv and before the next launch's backbone may start - alone on the chip, 0.27 ms for a c2 chunk - instead
     // of on the sequence stream, where its 256 persistent workgroups (147 KB of LDS each: a CU must drain both of its conv
     // workgroups before one fits) took 0.55 ms next to the other slot's convolutions and held the recurrence back
-    // (profiles/r04_bench_c2_kernel_stats.txt).  POCR_PROJ0_ON_SEQ=1: as before.
-    static const bool proj0_early_env = !(getenv("POCR_PROJ0_ON_SEQ") && atoi(getenv("POCR_PROJ0_ON_SEQ")) != 0);
+    // (profiles/r04_bench_c2_kernel_stats.txt).
     bool proj0_done = false, xproj_moved = false;
-    if (c.arch == POCR_ARCH_BLSTM && proj0_early_env && s.feat_is_p2) {
+    if (c.arch == POCR_ARCH_BLSTM && s.feat_is_p2) {
         const int Hh0 = c.lstm_hidden;
         const void *xp0 = s.xproj.p;
         if (s.xproj.reserve((size_t)rows * 8 * Hh0 * sizeof(float))) return 1;
@@ -943,15 +924,13 @@ int run_network(pocr_engine *e, Slot &s) {
         if (launch_gemm2<ACT_NONE, false, false>(e, g, st)) return 1;
         proj0_done = true;
     }
-    // POCR_SEQ_SAME_STREAM=1 (experiments; config 4, where both halves of a launch are MFMA-bound): the sequence stage stays
-    // on the conv stream and the next launch's backbone starts behind the WHOLE network - no two launches share the chip
-    static const bool seq_same_stream = getenv("POCR_SEQ_SAME_STREAM") && atoi(getenv("POCR_SEQ_SAME_STREAM")) != 0;
-    if (!seq_same_stream) {
-        HIP_TRY(hipEventRecord(s.conv_done, st));
-        s.conv_done_valid = true;
-        HIP_TRY(hipStreamWaitEvent(s.seq_stream, s.conv_done, 0));
-        st = s.seq_stream;
-    }
+    // The sequence stage runs on the slot's second stream, so that the next launch's backbone shares the chip with it.  (Keeping it on the
+    // conv stream - no two launches ever share the chip - was measured for config 4, whose two halves are both matrix-pipe work: equal
+    // within 0.5 %)
+    HIP_TRY(hipEventRecord(s.conv_done, st));
+    s.conv_done_valid = true;
+    HIP_TRY(hipStreamWaitEvent(s.seq_stream, s.conv_done, 0));
+    st = s.seq_stream;
     const float *layer_in = s.feat.as<float>();
     int din = E;
     // head2: the output layer on the persistent f16x2 GEMM, reading the last sequence layer's output in P2 (POCR_HEAD_FP32=1:
@@ -1018,9 +997,9 @@ int run_network(pocr_engine *e, Slot &s) {
     for (int l = 0; l < c.sa_layers; ++l) {
         pocr_engine::SaLayer &L = e->sa[l];
         if (s.sa_y[l].reserve(xe)) return 1;
-        // att2: q | k | v leave the projection in P2 and attention runs on f16x2 MFMAs (encoder.hpp); POCR_ATT_FP32=1 keeps
+        // att2: q | k | v leave the projection in P2 and attention runs on f16x2 MFMAs (encoder.hpp); the other arithmetics keep
         // the fp32-MFMA kernel on fp32 q | k | v
-        const bool att2 = g2 && !e->att_fp32 && conv_split() == 2 && (D == 32 || D == 64 || D == 128);
+        const bool att2 = g2 && conv_split() == 2 && (D == 32 || D == 64 || D == 128);
         if (gemm(g2 ? s.sa_xp2.p : (const void *)xin, E, L.w_in, L.b_in, 3 * E, s.sa_qkv.p, false, g2, att2)) return 1;
         const dim3 agrid((T + 15) / 16, heads, n);
         const float scale = 1.0f / sqrtf((float)D);
@@ -1059,11 +1038,6 @@ int run_network(pocr_engine *e, Slot &s) {
         }
         mark(POCR_STAGE_HEAD); mark(POCR_STAGE_CTC); mark(POCR_NUM_STAGES);
         if (guard) HIP_TRY(hipMemcpyAsync(s.range_host, s.range.p, kRangeWords * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        if (seq_same_stream) {
-            HIP_TRY(hipEventRecord(s.conv_done, st));
-            s.conv_done_valid = true;
-            HIP_TRY(hipStreamWaitEvent(s.seq_stream, s.conv_done, 0));
-        }
         return 0;
     }
     } else {
@@ -1126,10 +1100,8 @@ int run_network(pocr_engine *e, Slot &s) {
     // slices per workgroup: 1 for launches of a few slices (pages of long lines: the chain's latency is what counts),
     // 2 / 4 for many slices (the chain hides behind the next launch's convolutions: fewer resident workgroups cost
     // those less).  Measured (profiles/r03_lstm_resident.txt): c5 SL 1, c3 SL 2, c2 SL 4.
-    static const int sl_env = getenv("POCR_LSTM_SL") ? atoi(getenv("POCR_LSTM_SL")) : 0;
     const int n_sl = npad / 16, ug_n = Hh / 16;
-    int SLn = sl_env ? sl_env : (n_sl <= 4 ? 1 : (n_sl >= 16 && T <= 160) ? 4 : 2);
-    if (SLn != 1 && SLn != 2 && SLn != 4) SLn = 2;
+    int SLn = n_sl <= 4 ? 1 : (n_sl >= 16 && T <= 160) ? 4 : 2;
     // The clusters of a launch wait for one another's members inside ONE ordinary launch: every workgroup of the grid must be
     // able to be resident at the same time, or a cluster whose tail was not dispatched spins until its timeout.  The capacity
     // is what the runtime reports for this kernel (workgroups per CU x CUs, one taken off per CU as the margin the guide asks
@@ -1161,11 +1133,16 @@ int run_network(pocr_engine *e, Slot &s) {
     };
     while (SLn < 4 && resident_grid(SLn) > capacity(SLn)) SLn *= 2;
     const bool resident_shape = e->lstm_resident && (Hh == 64 || Hh == 128 || Hh == 256) && c.lstm_layers <= 8;
-    const bool paused = resident_shape && !s.lstm_force_step && e->lstm_skip > 0;      // back-off after a timeout (sync_and_guard)
-    if (paused) --e->lstm_skip;
+    bool paused = false;                                                               // back-off after a timeout (sync_and_guard)
+    if (resident_shape && !s.lstm_force_step) {
+        int left = e->lstm_skip.load();
+        while (left > 0 && !e->lstm_skip.compare_exchange_weak(left, left - 1)) {}
+        paused = left > 0;
+    }
     const bool resident = resident_shape && !s.lstm_force_step && !paused && resident_grid(SLn) <= capacity(SLn);
     const size_t sync_words = (size_t)n_clusters * 32 + 32;     // + error / diagnostic words
     s.lstm_resident_used = resident;
+    s.lstm_judged = false;
     if (resident) {
         if (s.lstm_sync.reserve(((sync_words + 3) / 4 * 4) * sizeof(uint32_t))) return 1;
         s.lstm_err_off = (size_t)n_clusters * 32;
@@ -1229,16 +1206,6 @@ int run_network(pocr_engine *e, Slot &s) {
 #undef POCR_RES
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(s.lstm_err_host + 4 * l, s.lstm_sync.as<unsigned>() + s.lstm_err_off, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-#if POCR_LSTM_RES_DBG
-            {
-                unsigned long long ph[6];
-                HIP_TRY(hipStreamSynchronize(st));
-                HIP_TRY(locked_memcpy(ph, s.lstm_sync.as<unsigned>() + s.lstm_err_off + 8, sizeof(ph), hipMemcpyDeviceToHost));
-                const double items = (double)T * SLn;
-                fprintf(stderr, "[lstm resident dbg] layer %d SL %d T %d: cycles per slice-step: wait %.0f  loads+mfma %.0f  barrier %.0f  gates %.0f  store-ack %.0f  barrier2 %.0f\n",
-                        l, SLn, T, ph[0] / items, ph[1] / items, ph[2] / items, ph[3] / items, ph[4] / items, ph[5] / items);
-            }
-#endif
             layer_in = s.lstm_y[l].as<float>();
             din = 2 * Hh;
             continue;
@@ -1323,11 +1290,6 @@ int run_network(pocr_engine *e, Slot &s) {
         mark(POCR_NUM_STAGES);
     }
     if (guard) HIP_TRY(hipMemcpyAsync(s.range_host, s.range.p, kRangeWords * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    if (seq_same_stream) {
-        HIP_TRY(hipEventRecord(s.conv_done, st));
-        s.conv_done_valid = true;
-        HIP_TRY(hipStreamWaitEvent(s.seq_stream, s.conv_done, 0));
-    }
     return 0;
 }
 
@@ -1591,6 +1553,8 @@ static int compute_pad_constants(pocr_engine *e) {
     return 0;
 }
 
+static void register_builder(pocr_engine *e);
+
 int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, int device_id, pocr_engine **out) {
     if (!out) return fail("out is NULL");
     *out = nullptr;
@@ -1615,26 +1579,27 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
     if (const char *env = getenv("POCR_LSTM_RESIDENT")) e->lstm_resident = atoi(env) != 0;
     if (const char *env = getenv("POCR_LSTM_SPIN_LIMIT")) e->lstm_spin_limit = std::max(1, atoi(env));
     e->p2 = conv_split() == 2 && !(getenv("POCR_NO_P2") && atoi(getenv("POCR_NO_P2")) != 0);
-    e->fuse12 = e->p2 && !(getenv("POCR_NO_FUSE12") && atoi(getenv("POCR_NO_FUSE12")) != 0) && !((p2_alt_tiles() >> 1) & 1);
+    e->fuse12 = e->p2 && !(getenv("POCR_NO_FUSE12") && atoi(getenv("POCR_NO_FUSE12")) != 0);
     // The fused conv1+2 kernel as 8 x 16 pixel tiles with THREE workgroups per CU (52 KB of LDS each) is 14 % faster alone than the 10 x 16 /
     // two-per-CU tiles, but it leaves no LDS for a resident recurrence of the launch ahead on the same CU: networks WITHOUT a recurrence (the
     // self-attention encoder) take it (c4 18.15 -> 18.49 k lines/s, three alternating pairs), the BiLSTM network keeps the larger tile (c3 -2.2 %
-    // with the small one; profiles/r04_backbone_overlap.txt).  POCR_P2_ALT_TILES (bit 7) overrides either way.
-    e->conv2_tile8 = e->fuse12 && (getenv("POCR_P2_ALT_TILES") ? ((p2_alt_tiles() >> 7) & 1) != 0 : cfg->arch == POCR_ARCH_SA);
+    // with the small one; profiles/r04_backbone_overlap.txt).
+    e->conv2_tile8 = e->fuse12 && cfg->arch == POCR_ARCH_SA;
     e->gemm2 = e->p2 && !(getenv("POCR_NO_GEMM2") && atoi(getenv("POCR_NO_GEMM2")) != 0);
     e->head_fp32 = getenv("POCR_HEAD_FP32") && atoi(getenv("POCR_HEAD_FP32")) != 0;
-    e->att_fp32 = getenv("POCR_ATT_FP32") && atoi(getenv("POCR_ATT_FP32")) != 0;
     e->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->device = device_id;
     auto bail = [&](int rc) { pocr_destroy(e); return rc; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
     for (Slot &sl : e->slot) {
-        // (A CU-masked partition - backbone on 256-k CUs, sequence kernels on k - was measured and is
-        //  slower on this stack: 6.9k / 4.7k / 8.4k lines/s for k = 8 / 16 / 32 vs 8.4k unmasked.)
+        // (A CU-masked partition - backbone on 256-k CUs, sequence kernels on k - was measured twice and is not faster: round 1, step
+        //  kernels: 6.9k / 4.7k / 8.4k lines/s for k = 8 / 16 / 32 vs 8.4k unmasked; round 6, the resident recurrence and the persistent
+        //  GEMMs on hipExtStreamCreateWithCUMask streams of 64 / 96 / 128 CUs: 8.83 / 8.83 / 8.77 ms per c2 step against 8.69-8.70
+        //  unmasked on the same box - conv2's stage time falls (3.5 -> 2.8 ms with 64 CUs) and the recurrence's rises by as much:
+        //  profiles/r06_seq_cu_mask.txt.)
         if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically lower = higher priority
-        if (const char *env = getenv("POCR_SEQ_PRIO")) prio_hi = atoi(env) == 0 ? 0 : (atoi(env) < 0 ? prio_lo : prio_hi);   // A/B: 0 normal, -1 low
         if (hipStreamCreateWithPriority(&sl.seq_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(fail("hipStreamCreate failed"));
         if (hipEventCreateWithFlags(&sl.conv_part, hipEventDisableTiming) != hipSuccess) return bail(fail("hipEventCreate failed"));
         for (auto &ev : sl.ev)
@@ -1783,9 +1748,8 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         e->proj_cout16 = round_up(8 * Hh, kProjNT) / 16;
         e->proj_w.resize(cfg->lstm_layers); e->proj_b.resize(cfg->lstm_layers);
         e->whh.resize(cfg->lstm_layers);
-        // the recurrent GEMM follows the conv arithmetic: f16x2 (hidden sizes the unrolled kernels cover), POCR_LSTM_FP32=1: fp32 MFMA
-        const bool lstm_f16 = conv_split() == 2 && (cfg->lstm_hidden == 64 || cfg->lstm_hidden == 128 || cfg->lstm_hidden == 256 || cfg->lstm_hidden == 512) &&
-                              !(getenv("POCR_LSTM_FP32") && atoi(getenv("POCR_LSTM_FP32")) != 0);
+        // the recurrent GEMM follows the conv arithmetic: f16x2 for the hidden sizes the unrolled kernels cover, fp32 MFMA otherwise
+        const bool lstm_f16 = conv_split() == 2 && (cfg->lstm_hidden == 64 || cfg->lstm_hidden == 128 || cfg->lstm_hidden == 256 || cfg->lstm_hidden == 512);
         if (lstm_f16) e->whh2.resize(cfg->lstm_layers);
         for (int l = 0; l < cfg->lstm_layers; ++l) {
             const int din = l == 0 ? cfg->conv_out : 2 * Hh;
@@ -1880,17 +1844,24 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
         const char *env = getenv("POCR_FALLBACK_EAGER");
         if (!(env && atoi(env) == 0)) {
             e->shadow_state.store(1);
+            register_builder(e);
             e->shadow_builder = std::thread([e] {
                 std::lock_guard<std::mutex> lock(e->shadow_mu);
-                if (e->shadow) return;                  // a launch needed it before this thread ran (ensure_shadow built it)
-                SplitScope scope(3);
-                pocr_engine *sh = nullptr;
-                if (hipSetDevice(e->device) == hipSuccess &&
-                    pocr_create(&e->cfg, e->weights_host.data(), e->weights_host.size(), e->device, &sh) == 0) {
-                    sh->is_shadow = true;
-                    e->shadow = sh;
-                    e->shadow_state.store(2);
-                } else {
+                if (e->shadow.load()) return;           // a launch needed it before this thread ran (ensure_shadow built it)
+                // (an exception leaving a thread's function is std::terminate: a failed allocation here must only mean "no eager
+                // fall-back engine" - it is then built on demand, where the error can be reported to the caller)
+                try {
+                    SplitScope scope(3);
+                    pocr_engine *sh = nullptr;
+                    if (hipSetDevice(e->device) == hipSuccess &&
+                        pocr_create(&e->cfg, e->weights_host.data(), e->weights_host.size(), e->device, &sh) == 0) {
+                        sh->is_shadow = true;
+                        e->shadow.store(sh);
+                        e->shadow_state.store(2);
+                    } else {
+                        e->shadow_state.store(-1);
+                    }
+                } catch (...) {
                     e->shadow_state.store(-1);
                 }
             });
@@ -1902,12 +1873,30 @@ int pocr_create(const pocr_config *cfg, const float *weights, size_t n_floats, i
 
 static void comm_release(pocr_engine *e);
 
+// Engines whose fall-back builder thread may still be inside HIP calls: a process that exits without pocr_destroy (an interpreter
+// that never closed its engines) joins them before the runtime is torn down under them.
+static std::mutex g_builders_mu;
+static std::unordered_set<pocr_engine *> g_builders;
+static void join_builders_at_exit() {
+    std::vector<pocr_engine *> live;
+    { std::lock_guard<std::mutex> lock(g_builders_mu); live.assign(g_builders.begin(), g_builders.end()); g_builders.clear(); }
+    for (pocr_engine *e : live)
+        if (e->shadow_builder.joinable()) e->shadow_builder.join();
+}
+static void register_builder(pocr_engine *e) {
+    static std::once_flag once;
+    std::call_once(once, [] { std::atexit(join_builders_at_exit); });
+    std::lock_guard<std::mutex> lock(g_builders_mu);
+    g_builders.insert(e);
+}
+
 void pocr_destroy(pocr_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    { std::lock_guard<std::mutex> lock(g_builders_mu); g_builders.erase(e); }
     if (e->shadow_builder.joinable()) e->shadow_builder.join();
     (void)locked_device_sync();
-    if (e->shadow) { pocr_destroy(e->shadow); e->shadow = nullptr; }
+    if (pocr_engine *sh = e->shadow.exchange(nullptr)) pocr_destroy(sh);
     if (e->comm.active()) comm_release(e);
     for (auto &b : e->conv_w) b.release();
     for (auto &b : e->cconst) b.release();
@@ -2207,11 +2196,11 @@ static int ensure_shadow(pocr_engine *e, int verdict, int which) {
                         "are re-run on bf16x3 (fp32's range, ~0.6x the speed).  POCR_CONV_SPLIT=3 selects bf16x3 for everything.\n",
                 verdict == 1 ? "|x| >= 65504 or not finite" : verdict == 2 ? "a whole tensor below 2^-13" : "POCR_FORCE_RANGE_FALLBACK", which);
     }
-    if (e->shadow) return 0;
+    if (e->shadow.load()) return 0;
     pocr_engine *sh = nullptr;
     if (pocr_create(&e->cfg, e->weights_host.data(), e->weights_host.size(), e->device, &sh)) return 1;
     sh->is_shadow = true;
-    e->shadow = sh;
+    e->shadow.store(sh);
     e->shadow_state.store(2);
     return 0;
 }
@@ -2231,9 +2220,9 @@ static int run_fallback(pocr_engine *e, int32_t slot, int verdict, int which) {
     SplitScope scope(3);
     std::lock_guard<std::mutex> lock(e->shadow_mu);
     if (ensure_shadow(e, verdict, which)) return 1;
-    pocr_engine *sh = e->shadow;
+    pocr_engine *sh = e->shadow.load();
     sh->lstm_resident = e->lstm_resident; sh->lstm_spin_limit = e->lstm_spin_limit;
-    sh->lstm_skip = std::max(sh->lstm_skip, e->lstm_skip);
+    sh->lstm_skip.store(std::max(sh->lstm_skip.load(), e->lstm_skip.load()));
     if (e->cfg.embed_num > 0 && e->embed_id >= 0 && sh->embed_id != e->embed_id && pocr_set_embed_id(sh, e->embed_id)) return 1;
     Slot &t = sh->slot[slot];
     if (t.in_flight && pocr_slot_reset(sh, slot)) return 1;
@@ -2267,9 +2256,11 @@ static int sync_and_guard(pocr_engine *e, int32_t slot) {
             // A cluster's workgroups did not all become resident in time (other tenants on the chip, CU masking, a partitioned
             // device ...): THIS launch is run again on the step kernels - same slot, same requests - before anything of it is
             // read, and the next launches pause the resident path (4, then 8 ... 256 of them) before it is tried again.
-            e->lstm_skip_len = std::min(256, std::max(4, 2 * e->lstm_skip_len));
-            e->lstm_skip = e->lstm_skip_len;
-            if (e->lstm_timeouts++ == 0)
+            const int pause = std::min(256, std::max(4, 2 * e->lstm_skip_len.load()));
+            e->lstm_skip_len.store(pause);
+            e->lstm_skip.store(pause);
+            e->lstm_ok_run.store(0);
+            if (e->lstm_timeouts.fetch_add(1) == 0)
                 fprintf(stderr, "NOTE: a hand-off of the resident BiLSTM recurrence timed out; the launch is repeated with one launch per step and "
                                 "the resident path pauses for the next launches (pocr_lstm_timeouts counts; POCR_LSTM_RESIDENT=0 turns it off).\n");
             memset(s.lstm_err_host, 0, 8 * 4 * sizeof(uint32_t));
@@ -2280,7 +2271,13 @@ static int sync_and_guard(pocr_engine *e, int32_t slot) {
             if (rc) return 1;
             HIP_TRY(hipStreamSynchronize(s.seq_stream));
             s.guard_checked = checked;
+        } else if (!s.lstm_judged && e->lstm_skip_len.load() > 0 && e->lstm_ok_run.fetch_add(1) + 1 >= kLstmDecayAfter) {
+            // kLstmDecayAfter resident launches in a row handed over in time: the pause a later timeout would start from is halved
+            e->lstm_ok_run.store(0);
+            const int len = e->lstm_skip_len.load();
+            e->lstm_skip_len.store(len / 2 < 4 ? 0 : len / 2);
         }
+        s.lstm_judged = true;
     }
     if (s.guard_checked) return 0;
     s.guard_checked = true;
@@ -2291,10 +2288,14 @@ static int sync_and_guard(pocr_engine *e, int32_t slot) {
     return run_fallback(e, slot, verdict, which);
 }
 // the slot (and engine) whose buffers hold the results of the launch on `slot`
-static inline pocr_engine *result_engine(pocr_engine *e, int32_t slot) { return e->slot[slot].redirect ? e->shadow : e; }
+static inline pocr_engine *result_engine(pocr_engine *e, int32_t slot) { return e->slot[slot].redirect ? e->shadow.load() : e; }
 
 int64_t pocr_range_fallbacks(pocr_engine *e) { return e ? e->range_fallbacks : 0; }
-int64_t pocr_lstm_timeouts(pocr_engine *e) { return e ? e->lstm_timeouts + (e->shadow ? e->shadow->lstm_timeouts : 0) : 0; }
+int64_t pocr_lstm_timeouts(pocr_engine *e) {
+    if (!e) return 0;
+    const pocr_engine *sh = e->shadow.load();
+    return e->lstm_timeouts.load() + (sh ? sh->lstm_timeouts.load() : 0);
+}
 
 int pocr_slot_launch(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t want_argmax) {
     if (check_slot(e, slot)) return 1;
@@ -2653,7 +2654,7 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
             SplitScope scope(3);
             std::lock_guard<std::mutex> lock(e->shadow_mu);
             if (ensure_shadow(e, verdict, which)) return 1;
-            pocr_engine *sh = e->shadow;
+            pocr_engine *sh = e->shadow.load();
             Slot &t = sh->slot[slot];
             if (t.in_flight && pocr_slot_reset(sh, slot)) return 1;
             const uint8_t *base = s.crops_ext ? s.crops_ext : s.crops.as<uint8_t>();
@@ -2711,7 +2712,7 @@ int pocr_s2s_decode(pocr_engine *e, int32_t slot, int32_t want_logits, int32_t *
         else if (D == 64) hipLaunchKernelGGL((dec_attention_kernel<64, false>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((dec_attention_kernel<128, false>), grid, dim3(256), 0, st, a);
     };
-    const bool fuse_ln = (E == 512 || E == 256) && getenv("POCR_S2S_NO_LN_FUSION") == nullptr;
+    const bool fuse_ln = E == 512 || E == 256;
     int blocks = 0;
     bool finished = false;
     for (int step = 0; step < S_cap && !finished; ++step) {

@@ -80,18 +80,22 @@ def labels_to_strings(labels: np.ndarray, lens: np.ndarray, characters, col0: in
                 _CP_CACHE.clear()
             ent = _CP_CACHE[key] = (characters, cps)
         cps = ent[1]
+    width = max(int(labels.shape[1]) - int(col0), 0)        # symbols a row can hold: a length beyond it is clipped, never read from the next row
     if cps is None and not identity:
         pick = range(n) if rows is None else [int(r) for r in rows]
-        return ["".join(characters[c] for c in labels[i, col0:col0 + max(int(lens[i]), 0)]) for i in pick]
-    ln = np.maximum(np.asarray(lens, dtype=np.int64), 0)
+        return ["".join(characters[c] for c in labels[i, col0:col0 + min(max(int(lens[i]), 0), width)]) for i in pick]
+    ln = np.minimum(np.maximum(np.asarray(lens, dtype=np.int64), 0), width)
     row_id = np.arange(n, dtype=np.int64) if rows is None else np.asarray(rows, dtype=np.int64)
     if rows is not None:
         ln = ln[row_id]
     ends = np.cumsum(ln)
     total = int(ends[-1])
+    if total == 0:                                          # nothing but empty lines (or rows of zero columns)
+        return [""] * n
     flat_labels = (labels if labels.flags.c_contiguous else np.ascontiguousarray(labels)).reshape(-1)
+    sym_of = (lambda c: chr(int(c))) if identity else (lambda c: characters[c])
     if flat_labels.size >= 2 ** 31 or total + n >= 2 ** 31:
-        return ["".join(characters[c] for c in labels[int(i), col0:col0 + int(k)]) for i, k in zip(row_id, ln)]
+        return ["".join(sym_of(c) for c in labels[int(i), col0:col0 + int(k)]) for i, k in zip(row_id, ln)]
     # Work proportional to the SYMBOLS, not to lines x the widest row (a gathered page stream is 2048 rows of 272 columns holding
     # ~30 symbols each), 32-bit indices, np.take: the output is the page's symbols with one NUL behind every line - position q
     # belongs to line line_of[q] and is read at that row's start + its offset in the line -, then one decode and one split
@@ -107,6 +111,12 @@ def labels_to_strings(labels: np.ndarray, lens: np.ndarray, characters, col0: in
     src[stops] = 0
     sym = np.take(flat_labels, src)
     sym = sym.astype("<u4") if identity else np.take(cps, sym, mode="clip")
+    if identity:                                            # rows of code points may hold a NUL themselves: then slice per line, as above
+        sym[stops] = 1
+        if not bool(np.all(sym)):
+            sym[stops] = 0
+            text = sym.astype("<u4", copy=False).tobytes().decode("utf-32-le")
+            return [text[e - k - 1:e - 1] for e, k in zip(ends1.tolist(), ln.tolist())]
     sym[stops] = 0
     return sym.astype("<u4", copy=False).tobytes().decode("utf-32-le").split("\x00")[:n]
 
@@ -210,7 +220,8 @@ def _csc_from_device(data, indices, indptr, shape):
         with _FAST_CSC_LOCK:         # (decoding loops of the sequence-to-sequence engine build matrices on worker threads: one probe)
             if _FAST_CSC is None:
                 _FAST_CSC = _probe_fast_csc(data, indices, indptr, shape)
-    if not _FAST_CSC:
+    state = _FAST_CSC               # one snapshot: another thread may switch the fast path off between the check and the use
+    if not state:
         return sparse.csc_matrix((data, indices, indptr), shape=shape)
     # the GPU compaction's contract, verified where it is cheap and where a new path would first show: the first matrices of the
     # process, the first of every row count, and a sample of the rest
@@ -223,7 +234,7 @@ def _csc_from_device(data, indices, indptr, shape):
             _FAST_CSC = False
             return sparse.csc_matrix((data, indices, indptr), shape=shape)
     m = sparse.csc_matrix.__new__(sparse.csc_matrix)
-    m.__dict__.update(_FAST_CSC)
+    m.__dict__.update(state)
     m.data, m.indices, m.indptr, m._shape = data, indices, indptr, (int(shape[0]), int(shape[1]))
     return m
 

@@ -524,7 +524,9 @@ def test_c3_page_stream_over_rccl_matches_reference_golden(golden, tmp_path):
     # (the fp32-MFMA fall-back, POCR_CONV_FP32=1, is an fp32 fma chain like the reference's own arithmetic and as noisy: RMS 2.2e-5)
     assert st["rms_hip"] <= st["rms_ref"] * (1.1 if _native.conv_split() == 0 else 1.0) and st["rows_hip_off"] <= n_ref_t, st
     assert n_hip_ref <= n_ref_t, (n_hip_ref, n_ref_t)
-    assert hip_t < 2.0 * LOGIT_TOL, hip_t                 # (a sanity bound only: a broken kernel is off by far more)
+    # ... and the worst sampled logit stays bounded RELATIVE to the reference's own worst (the count / RMS gate above came
+    # instead of `hip_t <= ref_t + 1e-4`; both hold - 9.9e-4 against the reference's 1.14e-3 - so both are asserted)
+    assert hip_t <= max(ref_t, LOGIT_TOL) + 1e-4, (hip_t, ref_t)
     # ... and the frames on which the reference itself is furthest from exact arithmetic (oracle/gen_worst_rows.py: the 64 worst of
     # the stream's 335 368 frames, found by running the restated network in float32 and float64 over all of it): a COUNT again
     if "worst_line_frame" in g.arrays.files:
@@ -537,6 +539,7 @@ def test_c3_page_stream_over_rccl_matches_reference_golden(golden, tmp_path):
               f"({int((d_ref > LOGIT_TOL).sum())} above 1e-3), this build {d_hip.max():.3e} (line {int(wl[k, 0])}, frame {int(wl[k, 1])}; "
               f"{int((d_hip > LOGIT_TOL).sum())} above 1e-3), rms {np.sqrt(np.mean(np.square(got_w - truth_w))):.3e} against {np.sqrt(np.mean(np.square(ref_w - truth_w))):.3e}")
         assert int((d_hip > LOGIT_TOL).sum()) <= int((d_ref > LOGIT_TOL).sum()), (d_hip.max(), int(wl[k, 0]))
+        assert float(d_hip.max()) <= max(float(d_ref.max()), LOGIT_TOL) + 1e-4, (d_hip.max(), d_ref.max())
         assert float(np.mean(np.square(got_w - truth_w))) <= float(np.mean(np.square(ref_w - truth_w)))
     # the statistics are 1-Lipschitz in the max norm: the reference's own deviation from exact arithmetic (ref_t, measured
     # above on the sampled rows) is the part of the difference that is not this build's

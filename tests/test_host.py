@@ -1,8 +1,10 @@
 """CPU tests of the product's host logic and of the C-ABI library surface
 (no compute calls: there is no GPU here)."""
 import ctypes
+import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -189,6 +191,58 @@ def test_bench_json_shape_for_rccl_and_gloo_fallback():
     assert bench.conv_peak_tflops(0) == 157.3
 
 
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_rank_launch_plan_for_eight_gpus(tmp_path):
+    """what `bench.py --gpus 8` starts when no launcher did - one process per GPU behind
+    torch.distributed.run, rendezvous on 127.0.0.1 at a free port, dmabuf IPC kept for RCCL - and, executed for real with a
+    stand-in script, the environment the eight ranks see (RANK / LOCAL_RANK 0..7, WORLD_SIZE 8, the same MASTER_* everywhere)."""
+    import subprocess
+    bench = _load_bench()
+    cmd, env = bench.rank_launch_plan(8, ["--gpus", "8", "--steps", "3"], environ={"PATH": os.environ.get("PATH", "")})
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    port = int(cmd[cmd.index("--master-port") + 1])
+    assert 1024 <= port <= 65535
+    assert cmd[-5:] == [os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "3"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"                    # set when the caller's environment lacks it
+    _c, env1 = bench.rank_launch_plan(8, [], environ={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})
+    assert env1["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"                   # ... and kept when it has it
+    _c, _e = bench.rank_launch_plan(2, [], port=29555)
+    assert _c[_c.index("--master-port") + 1] == "29555"
+    # the same plan with a stand-in for bench.py: every rank writes what it was given
+    probe = tmp_path / "probe.py"
+    probe.write_text("import json, os, sys\n"
+                     "keys = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY')\n"
+                     "json.dump({k: os.environ.get(k) for k in keys} | {'argv': sys.argv[1:]},\n"
+                     "          open(os.path.join(os.path.dirname(__file__), 'rank%s.json' % os.environ['RANK']), 'w'))\n")
+    cmd, env = bench.rank_launch_plan(8, ["--gpus", "8"])
+    cmd[cmd.index(os.path.join(REPO, "bench.py"))] = str(probe)
+    assert subprocess.call(cmd, env=dict(env, OMP_NUM_THREADS="1"), timeout=300) == 0
+    seen = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(8)]
+    assert [s["RANK"] for s in seen] == [str(r) for r in range(8)]
+    assert [s["LOCAL_RANK"] for s in seen] == [str(r) for r in range(8)]
+    assert {s["WORLD_SIZE"] for s in seen} == {"8"} and {s["MASTER_ADDR"] for s in seen} == {"127.0.0.1"}
+    assert {s["MASTER_PORT"] for s in seen} == {cmd[cmd.index("--master-port") + 1]}
+    assert {s["HSA_ENABLE_IPC_MODE_LEGACY"] for s in seen} == {os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+    assert all(s["argv"] == ["--gpus", "8"] for s in seen)
+
+
+def test_bench_refuses_a_world_of_another_size():
+    """`--gpus N` under a launcher of another world size must not print a line (a 4-rank number read as the 8-GPU result)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=4" in p.stderr and not p.stdout.strip()
+
+
 def test_resize_area_sparse_equals_dense_definition():
     """The fractional INTER_AREA host resample (every page after the first takes it once the adaptive factor is remembered):
     the separable sparse form equals the dense area-weight definition, and a 2000 x 1500 page takes well under a second."""
@@ -298,6 +352,20 @@ def test_no_kernel_of_the_library_spills():
     assert max(scratch) == 0, bad[:5]
 
 
+def test_no_kernel_has_the_store_data_hazard():
+    """Round 5's "masked store" corruption, root-caused in round 6 (profiles/r06_store_hazard.txt): on gfx950 a
+    `buffer_store_dwordx4 ... sN offen` followed in the very next issue slot by a VALU write of one of its data registers can store the
+    LATER value; LLVM's hazard recogniser pads that pair only when the store has no SGPR offset.  The shipped library must not contain
+    the pair anywhere (the compiler emits it or not depending on how it schedules the address arithmetic of the next store)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_scan", os.path.join(REPO, "tools", "isa_store_hazard_scan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hits, n_stores, n_soff = mod.scan(_native.lib_path())
+    assert n_stores >= 40 and n_soff >= 40, (n_stores, n_soff)            # (the scanner still sees the staged epilogues' stores)
+    assert not hits, hits[:4]
+
+
 def test_chunk_plan_is_a_lazy_sequence_with_the_plan_as_arrays():
     """plan_chunks returns the plan as arrays (what a rank of a sharded pass reads) and makes `Chunk` objects on demand:
     the arrays and the objects must say the same, slicing / iteration / equality behave like a list's, and the plan equals
@@ -339,3 +407,20 @@ def test_labels_to_strings_paths():
     nul = ["\\x00"] + chars[1:]                                          # NUL in the set: no split on it
     assert labels_to_strings(labels, lens, nul) == ["".join(nul[c] for c in labels[i, :lens[i]]) for i in range(30)]
     assert labels_to_strings(labels[:0], lens[:0], chars) == []
+    # rows of zero columns, lengths beyond the row (clipped, never read from the next row), all lines empty,
+    # rows that already hold code points (sharding._CodePoints) incl. a NUL among them
+    from pero_ocr_amd.sharding import _CodePoints
+    assert labels_to_strings(np.zeros((3, 0), np.int32), np.array([0, 2, 0], np.int32), chars) == ["", "", ""]
+    assert labels_to_strings(labels, np.zeros(30, np.int32), chars) == [""] * 30
+    over = lens.copy(); over[5] = 40; over[29] = 1000
+    want_over = ["".join(chars[c] for c in labels[i, :min(over[i], 17)]) for i in range(30)]
+    assert labels_to_strings(labels, over, chars) == want_over
+    assert labels_to_strings(labels, over, multi) == ["".join(multi[c] for c in labels[i, :min(over[i], 17)]) for i in range(30)]
+    cp = (labels + 0x100).astype(np.int32)
+    assert labels_to_strings(cp, lens, _CodePoints()) == want
+    cp0 = cp.copy(); cp0[2, 1] = 0; cp0[7, 0] = 0
+    l0 = lens.copy(); l0[2] = max(l0[2], 2); l0[7] = max(l0[7], 1)                 # (both NULs inside their lines)
+    want0 = ["".join(chr(c) for c in cp0[i, :l0[i]]) for i in range(30)]
+    assert "\x00" in want0[2] and want0[7].startswith("\x00")
+    assert labels_to_strings(cp0, l0, _CodePoints()) == want0
+    assert labels_to_strings(np.zeros((2, 0), np.int32), np.array([1, 0], np.int32), _CodePoints()) == ["", ""]

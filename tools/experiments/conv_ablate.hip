@@ -1,3 +1,6 @@
+// PARKED (round 6): this tool drives per-workgroup phase stamps (POCR_BF16X3_TRACE) and the POCR_BF16X3_DBG ablations of csrc/conv_bf16x3.hpp, which were compile-time switches of the
+// library until round 6 removed them (the measurements they produced: profiles/r02_conv_bf16x3_bench.txt, r03_conv_f16x2_ablation.txt,
+// r03_conv_tile_trace.txt, r05_conv_rows.txt).  It builds against the round-5 tree: `git worktree add /tmp/r05 4aef8f0` and compile there.
 // conv_ablate.hip — where the time of the split-precision conv kernel goes: one layer's shipped configuration, built
 // several times with parts of the main loop switched off (-DPOCR_BF16X3_DBG=n: 1 no A reads, 2 no weight loads, 4 no A
 // staging, 8 no barrier; results are then wrong, only the time matters).

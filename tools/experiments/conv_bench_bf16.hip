@@ -1,3 +1,6 @@
+// PARKED (round 6): this tool drives the POCR_BF16X3_DBG ablations (no A reads / no weight loads / no staging / no barrier) of csrc/conv_bf16x3.hpp, which were compile-time switches of the
+// library until round 6 removed them (the measurements they produced: profiles/r02_conv_bf16x3_bench.txt, r03_conv_f16x2_ablation.txt,
+// r03_conv_tile_trace.txt, r05_conv_rows.txt).  It builds against the round-5 tree: `git worktree add /tmp/r05 4aef8f0` and compile there.
 // conv_bench_bf16.hip — the bf16x3 conv kernel (csrc/conv_bf16x3.hpp) against the shipped fp32-MFMA kernel on one layer:
 // time, max |difference| between the two, and both against a float64 CPU reference on sampled outputs.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -o /tmp/conv_bench_bf16 tools/conv_bench_bf16.hip

@@ -55,6 +55,9 @@ inline size_t wino_grid_blocks(const WinoArgs &a) {    // (conv_grid_blocks with
     return P * tn;
 }
 
+#ifndef POCR_TRACE_STAMP                 // (the library's phase stamps were removed in round 6; the experiment's two call sites stay no-ops)
+#define POCR_TRACE_STAMP(k) do { } while (0)
+#endif
 #ifndef POCR_WINO_XF_A
 #define POCR_WINO_XF_A 1               // unit (halo row) of the chunk's MFMA stream behind which the next chunk's transform runs: waves 0..3
 #endif
@@ -338,11 +341,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WinoArgs a) {
                         if (r < 0 || r >= TH) continue;
                         u32x4 (&bc)[NS][2] = bw[u][dy];
 #pragma unroll
-                        for (int n = 0; n < NS; ++n) acc2[r][n] = POCR_MFMA_F16(al, bc[n][0], acc2[r][n]);
+                        for (int n = 0; n < NS; ++n) acc2[r][n] = mfma16_f16(al, bc[n][0], acc2[r][n]);
 #pragma unroll
-                        for (int n = 0; n < NS; ++n) acc[r][n] = POCR_MFMA_F16(ah, bc[n][0], acc[r][n]);
+                        for (int n = 0; n < NS; ++n) acc[r][n] = mfma16_f16(ah, bc[n][0], acc[r][n]);
 #pragma unroll
-                        for (int n = 0; n < NS; ++n) acc2[r][n] = POCR_MFMA_F16(ah, bc[n][1], acc2[r][n]);
+                        for (int n = 0; n < NS; ++n) acc2[r][n] = mfma16_f16(ah, bc[n][1], acc2[r][n]);
                     }
                     if (j == XF) {
                         // the other buffer: its last readers passed the barrier of the previous chunk.  After the last chunk: a

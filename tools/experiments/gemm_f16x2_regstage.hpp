@@ -203,11 +203,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16x2_kernel(GemmP2Args 
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc2[m][n] = POCR_MFMA_F16(al[m], bh[n], acc2[m][n]);
+            for (int n = 0; n < 4; ++n) acc2[m][n] = mfma16_f16(al[m], bh[n], acc2[m][n]);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = POCR_MFMA_F16(ah[m], bh[n], acc[m][n]);
+            for (int n = 0; n < 4; ++n) acc[m][n] = mfma16_f16(ah[m], bh[n], acc[m][n]);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc2[m][n] = POCR_MFMA_F16(ah[m], bl[n], acc2[m][n]);
+            for (int n = 0; n < 4; ++n) acc2[m][n] = mfma16_f16(ah[m], bl[n], acc2[m][n]);
         }
 #endif
         if (++c_k == nk) {

@@ -1,7 +1,11 @@
 """Three launches in flight on one engine, fresh engines: the activations of the middle launch must equal those of the same lines
 run alone, bit for bit.  (Found a store that was masked by an out-of-range buffer offset instead of a branch: rare wrong low planes
 in another launch's activations, only with three launches in flight, only in the first round after the engine's creation.)
-    python tools/three_in_flight.py [trials=6]        exit code 1 if any trial differs"""
+    python tools/three_in_flight.py [trials=6] [--prealloc] [--detail]        exit code 1 if any trial differs
+--prealloc: every slot first runs its lines ALONE (all activation buffers exist at their final size before three launches share the
+GPU) - separates "three launches in flight" from "device memory is allocated while other launches run"; --detail: where the
+differing values lie (runs of consecutive channels, magnitudes).  POCR_TMP_LIB=<path>: a variant build of the library
+(tools/masked_store_repro.sh builds the one with round 5's masked stores)."""
 import os
 import sys
 
@@ -28,7 +32,20 @@ def run(eng, sl, P):
     eng.slot_launch(sl, want_logits=True, want_argmax=True)
 
 
-def main(trials=6):
+def describe(got, ref, k):
+    """Where activation k differs: runs of consecutive flat indices (a lost 16-byte unit of the P2 layout = 8 channels of one
+    plane; a lost 128-byte line = 32 channels), relative size of the differences (low plane: ~2^-11 of the value and below)."""
+    g, r = got.reshape(-1), ref.reshape(-1)
+    idx = np.flatnonzero(g != r)
+    runs = np.split(idx, np.flatnonzero(np.diff(idx) > 1) + 1)
+    rel = np.abs(g[idx] - r[idx]) / np.maximum(np.abs(r[idx]), 1e-30)
+    lens = sorted({len(x) for x in runs})
+    return (f"activation {k}: {len(idx)} values in {len(runs)} runs (run lengths {lens[:8]}), first run at flat index {int(runs[0][0])} "
+            f"(mod 32: {int(runs[0][0]) % 32}), |d|/|ref| median {float(np.median(rel)):.2e} max {float(rel.max()):.2e}, "
+            f"got == 0 in {int(np.count_nonzero(g[idx] == 0))}, got finite {bool(np.all(np.isfinite(g[idx])))}")
+
+
+def main(trials=6, prealloc=False, detail=False):
     chars = synth.make_charset(99)
     spec = netspec.NetSpec(num_classes=len(chars) + 1)
     weights = netspec.pack_weights(spec, netspec.generate_weights(spec, 20260928))
@@ -41,6 +58,10 @@ def main(trials=6):
         run(eng, 0, S)
         ref_logits = eng.slot_collect(0)[0].copy()
         ref = [eng.debug_read(k) for k in range(12)]
+        if prealloc:
+            for sl, P in ((0, A), (2, B), (1, S)):
+                run(eng, sl, P)
+                eng.slot_collect(sl)
         for rep in range(2):
             run(eng, 0, A); run(eng, 2, B); run(eng, 1, S)
             eng.slot_collect(0); eng.slot_collect(2)
@@ -51,10 +72,15 @@ def main(trials=6):
                 bad += 1
                 n = int(np.count_nonzero(got[first] != ref[first])) if first is not None else 0
                 print(f"trial {trial} round {rep}: first differing activation {first} ({n} values), logits equal {np.array_equal(ls, ref_logits)}")
+                if detail:
+                    for k in range(12):
+                        if not np.array_equal(got[k], ref[k]):
+                            print("    " + describe(got[k], ref[k], k))
         eng.close()
-    print(f"three launches in flight, {trials} fresh engines x 2 rounds: {bad} rounds differ from the lines run alone")
+    print(f"three launches in flight{' (buffers pre-allocated)' if prealloc else ''}, {trials} fresh engines x 2 rounds: {bad} rounds differ from the lines run alone")
     return 1 if bad else 0
 
 
 if __name__ == "__main__":
-    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 6))
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    sys.exit(main(int(args[0]) if args else 6, "--prealloc" in sys.argv, "--detail" in sys.argv))
