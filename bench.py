@@ -285,8 +285,44 @@ def default_contract_region(engine, eng, crops, n_lines, width, wl, spec, weight
         dt = sorted(dts)[1]
         nnz = sum(m.nnz for m in lg) / float(sum(m.shape[0] for m in lg))
         assert len(tr) == len(big) and tr[:n_lines] == tr[n_lines:2 * n_lines]
+        # The same calls as a STREAM: call k + 1 is begun (planned, its first launches enqueued) before call k is ended - the two
+        # halves of process_lines that document_ocr.page_stream uses - so the engine's launch pipeline is not drained between
+        # calls.  A lone call pays the pipeline's fill and tail once (one launch's latency minus one period, ~8 ms of a 79 ms
+        # call: profiles/r04_launch_timeline.txt); a caller with further pages does not.  Same plan, same launches, same results.
+        n_stream = 6
+
+        def stream(k):
+            ticket, outs_ = e_.process_lines_begin(big), []
+            for _ in range(k - 1):
+                nxt = e_.process_lines_begin(big)
+                outs_.append(e_.process_lines_end(ticket))
+                ticket = nxt
+            outs_.append(e_.process_lines_end(ticket))
+            e_.model.device_synchronize()
+            return outs_
+        stream(2)                                             # (warm: the speculative read-back size settles on this launch pattern)
+        t0 = time.perf_counter()
+        outs = stream(n_stream)
+        dt_stream = (time.perf_counter() - t0) / n_stream
+        assert all(o[0] == tr for o in outs) and all(a.nnz == b.nnz for a, b in zip(outs[-1][1], lg))
+        # ... and the SAME call without logits (process_lines(crops, no_logits=True), one call at a time): what the sparse logits cost a
+        # call is the difference to this figure - not the difference to `value`, whose step loop never drains its pipeline
+        e_.process_lines(big, no_logits=True)
+        e_.model.device_synchronize()
+        dts_nl = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            e_.process_lines(big, no_logits=True)
+            e_.model.device_synchronize()
+            dts_nl.append(time.perf_counter() - t0)
+        dt_nl = sorted(dts_nl)[1]
+        e_.process_lines(big)                                 # (leave the read-back size as a sparse call left it)
         return {"value": round(len(big) / dt, 1), "ms_per_256_lines": round(1e3 * dt / reps, 3), "nnz_per_frame": round(nnz, 1),
-                "calls_ms": [round(1e3 * d, 1) for d in dts]}
+                "calls_ms": [round(1e3 * d, 1) for d in dts],
+                "same_call_no_logits": {"value": round(len(big) / dt_nl, 1), "calls_ms": [round(1e3 * d, 1) for d in dts_nl],
+                                        "sparse_logits_cost_ms_per_call": round(1e3 * (dt - dt_nl), 2)},
+                "streamed": {"value": round(len(big) / dt_stream, 1), "ms_per_256_lines": round(1e3 * dt_stream / reps, 3), "calls": n_stream,
+                             "what": "the same calls with call k + 1 begun before call k is ended (process_lines_begin / _end)"}}
 
     out["seeded_weights"] = timed(engine)
     w8 = dict(weights)
@@ -309,7 +345,9 @@ def run_extra_workloads(timeout_s=170.0):
     the ONE JSON line the default run prints."""
     jobs = {"c3": ["--workload", "c3", "--steps", "2", "--warmup", "1"],
             "c4": ["--workload", "c4", "--steps", "5", "--warmup", "2"],
-            "c5": ["--workload", "c5", "--steps", "16", "--warmup", "4"]}
+            # (64 pages = 16 recogniser calls of four pages: with 16 pages the stream's fill and tail - one call's latency - were a quarter of
+            # the region, and the figure moved by 10 % between runs of the same build: 67.6 / 70.5 here against 72.9-75.6 for 20 pages)
+            "c5": ["--workload", "c5", "--steps", "64", "--warmup", "8"]}
     only = os.environ.get("POCR_BENCH_EXTRAS")          # e.g. "c3,c5" or "" (none): which child workloads to run
     if only is not None:
         jobs = {k: v for k, v in jobs.items() if k in only.split(",")}
@@ -840,8 +878,8 @@ def main():
         if w_pad is not None:
             traffic = None          # HBM bytes per launch of the dominant kernel, from the committed PMC passes
             pmc_meta = {}
-            pmc_file = {2: "r05_pmc_summary.json", 3: "r02_pmc_summary.json", 0: "pmc_summary.json"}[split]
-            for older in ("r04_pmc_summary.json", "r03_pmc_summary.json"):
+            pmc_file = {2: "r06_pmc_summary.json", 3: "r02_pmc_summary.json", 0: "pmc_summary.json"}[split]
+            for older in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json"):
                 if not os.path.exists(os.path.join(REPO, "profiles", pmc_file)):
                     pmc_file = older
             rows_on = os.environ.get("POCR_CONV_ROWS", "1") != "0"     # (csrc/conv_rows.hpp runs conv9 in the default mode)
@@ -940,7 +978,20 @@ def main():
         result.update(extra)
         if args.workload == "c2" and world == 1 and not args.no_extras:
             eng.device_synchronize()
-            result["extra"] = dict(c2_sparse=result.pop("c2_sparse"), **run_extra_workloads())
+            c2s = result.pop("c2_sparse")
+            # the reference's DEFAULT call next to `value`: `value` times launches that return label ids only
+            # (process_lines(..., no_logits=True)); PageOCR.process_page calls process_lines(crops) and gets sparse logits back
+            result["default_call"] = {"value": c2s["head_x8"]["value"], "unit": "lines/s", "nnz_per_frame": c2s["head_x8"]["nnz_per_frame"],
+                                      "same_call_no_logits": c2s["head_x8"]["same_call_no_logits"]["value"],
+                                      "streamed": c2s["head_x8"]["streamed"]["value"],
+                                      "flat_head": {"value": c2s["seeded_weights"]["value"], "nnz_per_frame": c2s["seeded_weights"]["nnz_per_frame"],
+                                                    "same_call_no_logits": c2s["seeded_weights"]["same_call_no_logits"]["value"],
+                                                    "streamed": c2s["seeded_weights"]["streamed"]["value"]},
+                                      "what": "process_lines(2048 host crops @40x512) with the reference's default arguments -> strings + scipy CSC logits + "
+                                              "logit_coords: one call at a time (median of 3), the same call with no_logits=True (the sparse logits' own cost is "
+                                              "the difference), and as a stream of calls (call k + 1 begun before call k is ended).  A lone call pays the launch "
+                                              "pipeline's fill and tail (~8 ms of ~77), which `value`'s step loop never does; details: extra.c2_sparse"}
+            result["extra"] = dict(c2_sparse=c2s, **run_extra_workloads())
         if world == 1 and not args.no_cpu_baseline and args.workload in ("c2", "c4"):
             try:
                 result["cpu_baseline"] = cpu_baseline(args.workload)
