@@ -69,6 +69,10 @@ class RcclTransport:
 
     def barrier(self):
         self.engine.allreduce_max(0.0)
+        port = getattr(self, "rendezvous_port", None)
+        if port is not None:                    # every rank holds its communicator now: the fallback carrier's id file can go
+            self.rendezvous_port = None
+            comm_rendezvous_cleanup(self.rank, port)
 
 
 class LocalTransport:
@@ -111,18 +115,42 @@ class TorchDistTransport:
         self.dist.barrier()
 
 
+def _id_file(port: int) -> str:
+    """Fallback carrier of the unique id on ONE node: a file keyed by the rendezvous port and the launcher's pid (all ranks of a
+    torchrun job are children of the same agent process)."""
+    import os
+    import tempfile
+    return os.path.join(tempfile.gettempdir(), f"pocr_rccl_id_{port}_{os.getppid()}")
+
+
+_ID_MAGIC = b"POCRUID1"
+
+
 def exchange_unique_id(rank: int, world: int, addr: str, port: int, make_id: Callable[[], bytes], timeout_s: float = 300.0) -> bytes:
     """Out-of-band rendezvous of RCCL's 128-byte unique id: rank 0 creates it and serves it on (addr, port) to the
-    other world - 1 ranks, which connect (retrying until rank 0 listens)."""
+    other world - 1 ranks, which connect (retrying until rank 0 listens).  If rank 0 cannot bind the port (something else
+    owns MASTER_PORT + 1 on this box) it leaves the id in a file instead (`_id_file`: single node, which is all the launchers
+    here start); the other ranks look for that file between their connection attempts, so neither side needs to know which
+    carrier the other one chose."""
+    import os
     import socket
     import time
     if world == 1:
         return make_id()
+    path = _id_file(port)
     if rank == 0:
         uid = make_id()
         srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind((addr, port))
+        try:
+            srv.bind((addr, port))
+        except OSError:
+            srv.close()
+            tmp = path + ".tmp"
+            with open(tmp, "wb") as f:
+                f.write(_ID_MAGIC + uid)
+            os.replace(tmp, path)                 # (atomic: a reader sees nothing or all 136 bytes; removed by comm_rendezvous_cleanup)
+            return uid
         srv.listen(world)
         srv.settimeout(timeout_s)
         try:
@@ -136,7 +164,15 @@ def exchange_unique_id(rank: int, world: int, addr: str, port: int, make_id: Cal
     deadline = time.monotonic() + timeout_s
     while True:
         try:
+            with open(path, "rb") as f:
+                blob = f.read()
+            if len(blob) == len(_ID_MAGIC) + 128 and blob.startswith(_ID_MAGIC):
+                return blob[len(_ID_MAGIC):]
+        except OSError:
+            pass
+        try:
             with socket.create_connection((addr, port), timeout=5.0) as conn:
+                conn.settimeout(5.0)
                 buf = b""
                 while len(buf) < 128:
                     part = conn.recv(128 - len(buf))
@@ -148,8 +184,18 @@ def exchange_unique_id(rank: int, world: int, addr: str, port: int, make_id: Cal
         except OSError:
             pass
         if time.monotonic() > deadline:
-            raise RuntimeError(f"rank {rank}: no RCCL unique id from rank 0 at {addr}:{port} within {timeout_s:.0f} s")
+            raise RuntimeError(f"rank {rank}: no RCCL unique id from rank 0 at {addr}:{port} (or in {path}) within {timeout_s:.0f} s")
         time.sleep(0.05)
+
+
+def comm_rendezvous_cleanup(rank: int, port: int) -> None:
+    """Rank 0, after the communicator exists on every rank (its first barrier): drop the id file of the fallback carrier."""
+    import os
+    if rank == 0:
+        try:
+            os.remove(_id_file(port))
+        except OSError:
+            pass
 
 
 def init_rccl_from_env(engine, rank: Optional[int] = None, world: Optional[int] = None) -> RcclTransport:
@@ -164,7 +210,10 @@ def init_rccl_from_env(engine, rank: Optional[int] = None, world: Optional[int] 
     port = int(os.environ.get("POCR_RDZV_PORT", int(os.environ.get("MASTER_PORT", "29533")) + 1))
     uid = exchange_unique_id(rank, world, addr, port, _native.comm_unique_id)
     engine.comm_init(uid, rank, world)
-    return RcclTransport(engine)
+    tr = RcclTransport(engine)
+    if world > 1:
+        tr.rendezvous_port = port               # (the first barrier's caller may drop the fallback carrier's file: comm_rendezvous_cleanup)
+    return tr
 
 
 ROW_FAILED = -2          # length field of a payload row whose rank could not produce it

@@ -218,3 +218,39 @@ def test_host_share_of_a_sharded_pass():
     t_plan = best(lambda: sharding.assign_chunks(plan_chunks(widths, 480 * 8), 8))
     print(f"[host share] process_lines {t_call:.2f} ms per call, plan + deal {t_plan:.2f} ms (2048 lines, 8 ranks)")
     assert t_call <= 1.5 and t_plan <= 0.5, (t_call, t_plan)
+
+
+def test_unique_id_rendezvous_over_tcp_and_over_the_file_fallback(tmp_path):
+    """The RCCL unique id reaches every rank over MASTER_PORT + 1 - and, when rank 0 cannot bind that port (it belongs to something
+    else on the box), through the id file the other ranks look for between their connection attempts.  Threads stand in for the
+    ranks (same parent pid, as under torchrun)."""
+    import socket
+    import threading
+    from pero_ocr_amd import sharding
+
+    def run(port, world=4):
+        uid = bytes(range(128))
+        got = [None] * world
+
+        def rank_fn(r):
+            got[r] = sharding.exchange_unique_id(r, world, "127.0.0.1", port, lambda: uid, timeout_s=20.0)
+        ths = [threading.Thread(target=rank_fn, args=(r,)) for r in range(world)]
+        for t in reversed(ths):                   # (rank 0 last: the others are already retrying)
+            t.start()
+        for t in ths:
+            t.join(30.0)
+        assert all(g == uid for g in got), [None if g is None else len(g) for g in got]
+
+    free = socket.socket(); free.bind(("127.0.0.1", 0)); port = free.getsockname()[1]; free.close()
+    run(port)                                     # TCP carrier
+    assert not os.path.exists(sharding._id_file(port))
+    # the port is taken by a listener that never answers: rank 0's bind fails, the id travels through the file
+    squat = socket.socket(); squat.bind(("127.0.0.1", 0)); squat.listen(8)
+    try:
+        busy = squat.getsockname()[1]
+        run(busy)
+        assert os.path.exists(sharding._id_file(busy))
+        sharding.comm_rendezvous_cleanup(0, busy)
+        assert not os.path.exists(sharding._id_file(busy))
+    finally:
+        squat.close()
