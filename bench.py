@@ -304,6 +304,11 @@ def default_contract_region(engine, eng, crops, n_lines, width, wl, spec, weight
             e_.model.device_synchronize()
             return last, ok and last[0] == tr
         stream(2)                                             # (warm: the speculative read-back size settles on this launch pattern)
+        # A collected heap at the start of the region: the calls above left ~10^5 tracked objects (csc_matrix instances, their
+        # dicts and arrays) in the young generations, and the full collection they trigger fell INTO the stream of whichever
+        # engine was measured second - 24.9 k instead of 27.8 k lines/s, either engine (profiles/r06_default_call_stream.txt)
+        import gc
+        gc.collect()
         t0 = time.perf_counter()
         last, ok = stream(n_stream)
         dt_stream = (time.perf_counter() - t0) / n_stream

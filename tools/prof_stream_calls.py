@@ -12,7 +12,9 @@ trials = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 meta, spec, weights = bench.fixture_model("c2")
 crops = synth.make_crops(305, [512] * 256, spec.height)
 big = [crops[i % 256] for i in range(2048)]
-for temp in (8.0, 1.0):
+keep = []
+order = (1.0, 8.0) if os.environ.get("FLAT_FIRST") else (8.0, 1.0)
+for temp in order:
     w = dict(weights)
     w["head.weight"] = w["head.weight"] * np.float32(temp); w["head.bias"] = w["head.bias"] * np.float32(temp)
     tmp = tempfile.mkdtemp()
@@ -43,4 +45,6 @@ for temp in (8.0, 1.0):
         nl = (time.perf_counter() - t0) / n_stream
         print(f"head x{temp:g} trial {t}: one call at a time {[round(1e3 * d, 1) for d in single]} ms = {2048 / sorted(single)[1]:.0f} lines/s; "
               f"stream of {n_stream} calls {1e3 * st:.1f} ms per call = {2048 / st:.0f} lines/s; no_logits calls one at a time {1e3 * nl:.1f} ms = {2048 / nl:.0f} lines/s", flush=True)
+    if os.environ.get("KEEP_ENGINES"):
+        keep.append(eng)
     del eng
