@@ -34,6 +34,17 @@ constexpr unsigned kGarbage = 0xDEADBEEFu;
                  : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(voff), "s"(rsv), "s"(soff_u), "v"(kGarbage)                 \
                  : "v4", "v5", "v6", "v7", "memory")
 
+// the same pair with a GLOBAL store (FLAT encoding: the case LLVM always pads - two wait states on gfx940+): SGPR base + VGPR offset
+#define HAZARD_ASM_GLOBAL(NOP_TXT)                                                                                     \
+    asm volatile("v_mov_b32 v4, %0\n\tv_mov_b32 v5, %1\n\tv_mov_b32 v6, %2\n\tv_mov_b32 v7, %3\n\t"                     \
+                 "s_nop 4\n\t"                                                                                         \
+                 "global_store_dwordx4 %4, v[4:7], %5\n\t" NOP_TXT                                                     \
+                 "v_mov_b32 v4, %6\n\t"                                                                                \
+                 "s_nop 4\n\t"                                                                                         \
+                 :                                                                                                     \
+                 : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(goff), "s"(gbase), "v"(kGarbage)                            \
+                 : "v4", "v5", "v6", "v7", "memory")
+
 template <int VARIANT>
 __global__ __launch_bounds__(256) void hazard_kernel(unsigned *buf, unsigned bytes_per_wg, int iters, unsigned id) {
     // the workgroup's region as a raw buffer; iteration `it` stores 256 consecutive 16-byte units (a wave instruction = eight 128-byte lines)
@@ -49,6 +60,13 @@ __global__ __launch_bounds__(256) void hazard_kernel(unsigned *buf, unsigned byt
         const unsigned soff_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((VARIANT & 1) ? (unsigned)it * 4096u : 0u));
         const unsigned voff = oor ? 0x80000000u : ((VARIANT & 1) ? threadIdx.x * 16u : off);
         const unsigned d0 = unit * 0x9E3779B9u + id, d1 = unit ^ 0x5555AAAAu, d2 = unit, d3 = id;
+        if constexpr ((VARIANT & 16) != 0) {
+            const unsigned goff = off;                                  // (global store: no range check, every lane in range)
+            const unsigned long long gbase = ba;
+            if constexpr ((VARIANT & 6) == 0) HAZARD_ASM_GLOBAL("");
+            else if constexpr ((VARIANT & 6) == 2) HAZARD_ASM_GLOBAL("s_nop 0\n\t");
+            else HAZARD_ASM_GLOBAL("s_nop 1\n\t");
+        } else
         if constexpr ((VARIANT & 7) == 1) HAZARD_ASM("%6", "");
         else if constexpr ((VARIANT & 7) == 3) HAZARD_ASM("%6", "s_nop 0\n\t");
         else if constexpr ((VARIANT & 7) == 5) HAZARD_ASM("%6", "s_nop 1\n\t");
@@ -94,7 +112,7 @@ static void run_variant(const char *name, int rounds) {
             hipLaunchKernelGGL((hazard_kernel<VARIANT>), dim3(n_wg), dim3(256), 0, st[s], buf[s], bytes_per_wg, iters, (unsigned)(r * 8 + s + 1));
         CHECK(hipDeviceSynchronize());
         for (int s = 0; s < n_streams; ++s) {
-            CHECK(hipMemset(cnt, 0, 4 * sizeof(unsigned long long)));
+            CHECK(hipMemsetAsync(cnt, 0, 4 * sizeof(unsigned long long), st[0]));      // (same stream as the check: the streams are non-blocking)
             hipLaunchKernelGGL(check_kernel, dim3(2048), dim3(256), 0, st[0], reinterpret_cast<const u32x4 *>(buf[s]), units_per_wg, n_wg, (unsigned)(r * 8 + s + 1), (VARIANT & 8) ? 1 : 0, cnt);
             CHECK(hipDeviceSynchronize());
             unsigned long long got[4];
@@ -102,7 +120,10 @@ static void run_variant(const char *name, int rounds) {
             for (int k = 0; k < 4; ++k) tot[k] += got[k];
         }
     }
-    printf("%-78s units right %llu, dword 0 = the LATER v_mov's value %llu, otherwise wrong %llu, masked units written %llu\n", name, tot[0], tot[1], tot[2], tot[3]);
+    const unsigned long long expect = (unsigned long long)rounds * n_streams * n_wg * units_per_wg;
+    const unsigned long long seen = tot[0] + tot[1] + tot[2], masked = (VARIANT & 8) ? expect / 4 : 0;
+    printf("%-78s units right %llu, dword 0 = the LATER v_mov's value %llu (%.2f %%), otherwise wrong %llu, masked units written %llu%s\n", name, tot[0], tot[1],
+           100.0 * (double)tot[1] / (double)(expect - masked), tot[2], tot[3], seen + masked == expect ? "" : "  [COUNT MISMATCH]");
     for (int s = 0; s < n_streams; ++s) { CHECK(hipFree(buf[s])); CHECK(hipStreamDestroy(st[s])); }
     CHECK(hipFree(cnt));
 }
@@ -122,5 +143,9 @@ int main(int argc, char **argv) {
     run_variant<2>("no SGPR offset, one wait state", rounds);
     run_variant<8>("no SGPR offset, directly behind, a quarter of the lanes out of range", rounds);
     run_variant<10>("no SGPR offset, one wait state, a quarter of the lanes out of range", rounds);
+    run_variant<4>("no SGPR offset, two wait states (what LLVM emits on gfx940+)", rounds);
+    run_variant<16>("global_store_dwordx4 (SGPR base), v_mov directly behind", rounds);
+    run_variant<18>("global_store_dwordx4 (SGPR base), one wait state", rounds);
+    run_variant<20>("global_store_dwordx4 (SGPR base), two wait states (what LLVM emits)", rounds);
     return 0;
 }
