@@ -5,6 +5,7 @@ cd $GRAFT_REPO_ROOT
 export POCR_SOURCE_HEAD=$(cat gpurun_out/.source_head 2>/dev/null || cat .source_head 2>/dev/null)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06; rm -rf $O; mkdir -p $O
 timeout 1700 python -m pytest tests -x -q -m gpu -s > $O/pytest_gpu.txt 2>&1; echo "rc $?" >> $O/pytest_gpu.txt
+timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.txt 2>&1; echo "rc $?" >> $O/smoke.txt
 timeout 900 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 POCR_CONV_SPLIT=3 timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_c2_bf16x3.json 2> $O/bench_c2_bf16x3.err
 POCR_CONV_FP32=1 timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_c2_fp32mfma.json 2> $O/bench_c2_fp32mfma.err
@@ -35,6 +36,6 @@ for w in c2 c4 s2s; do f=$(find $O/prof_$w -name "*.db" | head -1); [ -n "$f" ] 
 python tools/pmc_summary.py $(find $O/pmc -name "*.db") > $O/pmc_summary.json 2> $O/pmc_summary.err
 python tools/s2s_roofline.py $O/s2s_kernel_stats.txt $O/s2s_bench.json 512 > $O/s2s_roofline.json 2> $O/s2s_roofline.err
 find $O -name "*.db" -delete
-tail -2 $O/pytest_gpu.txt
+tail -2 $O/pytest_gpu.txt; tail -2 $O/smoke.txt
 for f in bench_c2 bench_c2_bf16x3 bench_c2_fp32mfma bench_c3 bench_c3_rccl_world1 bench_c4 bench_c5 bench_c5_host_crops; do echo $f; cut -c1-200 $O/$f.json; echo; done
 head -16 $O/c2_kernel_stats.txt | cut -c1-200; cat $O/stage_ms_c2_alone.txt $O/stage_ms_c4_alone.txt; cat $O/s2s_roofline.json | cut -c1-600; cat $O/crop_bench.txt | tail -3
