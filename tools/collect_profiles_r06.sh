@@ -11,6 +11,6 @@ cp $O/s2s_kernel_stats.txt $P/r06_s2s_kernel_stats.txt
 cp $O/stage_ms_c2_alone.txt $P/r06_stage_ms_c2_single_chunk_alone.txt
 cp $O/stage_ms_c4_alone.txt $P/r06_stage_ms_c4_single_chunk_alone.txt
 cp $O/crop_bench.txt $P/r06_crop_bench_resident.txt
-cp $O/stream_calls.txt $P/r06_default_call_stream.txt
+# (r06_default_call_stream.txt carries a hand-written appendix: refreshed by hand from $O/stream_calls.txt, not overwritten here)
 grep -oE "\[c[0-9a-z ]*\].*|\[rescale.*|\[range.*|\[smoke.*|\[full.*|\[host.*|\[s2s range.*|^[0-9]+ passed.*|^[0-9]+ failed.*" $O/pytest_gpu.txt > $P/r06_parity_prints.txt || true
 ls $P | grep r06_ | wc -l
