@@ -39,6 +39,16 @@ def test_two_ranks_c3_stream_end_to_end_on_the_gloo_fallback():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(1000)
+def test_eight_ranks_deal_the_c3_stream_and_reproduce_the_fixture():
+    """The size the driver's scaling run ends with: eight ranks (all on GPU 0 here), the 343 reference chunks of the c3 stream dealt to them,
+    one all-gather per pass, every transcription equal to the reference fixture (asserted by the bench on every rank before it prints)."""
+    r, _err = _run(["--gpus", "8", "--workload", "c3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert r["n_gpus"] == 8 and r["rccl_ranks"] == 0 and r["value"] is None and r["value_gloo_fallback"] > 0
+    assert "8 rank(s)" in r["config"]["workload"] and "transcriptions checked against the reference fixture" in r["config"]["workload"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1000)
 def test_two_ranks_c2_weak_scaling_step_loop_on_the_gloo_fallback():
     r, _err = _run(["--gpus", "2", "--workload", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["lines_per_step"] == 512
